@@ -1,0 +1,271 @@
+/*
+ * plsvo_hip.h -- C ABI of the MI355X (gfx950) hot path of PL-SVO:
+ *   sparse image alignment (points + sampled line segments) and motion-only pose optimisation.
+ *
+ * This header IS the drop-in boundary.  The reference has no FFI layer; its boundary is two C++
+ * call signatures (reference file:line given per entry point below).  The C++ adapter in
+ * pl-svo_amd/host/plsvo/ re-creates those signatures on top of this ABI.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative PLSVO_E_* code on failure; nothing throws,
+ *     nothing aborts; plsvo_hip_last_error() gives a human-readable string for the last failure.
+ *   - plain pointers and sizes only; no C++/torch types.  Pointers are HOST pointers unless the
+ *     parameter name starts with d_ (device pointer, HBM of the ctx's device).
+ *   - a ctx is bound to one device and one HIP stream; use one ctx per calling thread.
+ *   - poses travel as double[7] = { qx, qy, qz, qw, tx, ty, tz } (unit quaternion + translation),
+ *     the storage of the reference's Sophus::SE3 (SO3 as unit quaternion, Vector3d translation).
+ *   - there is NO CPU fallback behind this ABI: without a gfx950 device plsvo_hip_create() fails.
+ */
+#ifndef PLSVO_HIP_H_
+#define PLSVO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLSVO_MAX_LEVELS 8
+#define PLSVO_PATCH_SIZE 4   /* reference: include/plsvo/sparse_img_align.h:48-50 (halfsize 2, size 4, area 16) */
+#define PLSVO_PATCH_AREA 16
+
+/* error codes */
+#define PLSVO_OK              0
+#define PLSVO_E_INVALID      -1  /* bad argument */
+#define PLSVO_E_NODEVICE     -2  /* no usable HIP device (there is no CPU fallback) */
+#define PLSVO_E_HIP          -3  /* a HIP runtime call failed; see plsvo_hip_last_error */
+#define PLSVO_E_CAPACITY     -4  /* a ctx capacity (slots, features, patches) would be exceeded */
+#define PLSVO_E_STATE        -5  /* call order violated (e.g. run before stage) */
+#define PLSVO_E_RCCL         -6  /* an RCCL call failed */
+
+typedef struct plsvo_ctx plsvo_ctx;
+
+/* undistorted pinhole camera: the only model the reference demo hands the VO
+ * (app/run_pipeline.cpp:786-795; vk::PinholeCamera with zero distortion, [ext] vikit) */
+typedef struct plsvo_pinhole {
+  double fx, fy, cx, cy;
+  int32_t width, height;      /* level-0 image size */
+} plsvo_pinhole;
+
+/* ------------------------------------------------------------------------------------------ */
+/* context                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+/* device_id: HIP ordinal.  stream: a hipStream_t (as void*) to enqueue on, or NULL to let the
+ * ctx create its own non-blocking stream. */
+int plsvo_hip_create(int device_id, void* stream, plsvo_ctx** out);
+void plsvo_hip_destroy(plsvo_ctx* ctx);
+const char* plsvo_hip_last_error(const plsvo_ctx* ctx);   /* ctx may be NULL: last create error */
+void* plsvo_hip_stream(plsvo_ctx* ctx);                   /* the hipStream_t all work is enqueued on */
+int plsvo_hip_synchronize(plsvo_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------ */
+/* image pyramids (input of both frames; replaces Frame::img_pyr_, include/plsvo/frame.h:64,   */
+/* filled by frame_utils::createImgPyramid, src/frame.cpp:171-180)                             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Allocate n_slots pyramid slots of n_levels u8 images, level l = (width>>l) x (height>>l),
+ * rows stored tightly (stride == width of the level).  Re-configuring frees the old slab. */
+int plsvo_hip_config_pyramids(plsvo_ctx* ctx, int n_slots, int width, int height, int n_levels);
+
+/* Upload an existing host pyramid (what the reference keeps in Frame::img_pyr_) into a slot. */
+int plsvo_hip_upload_pyramid(plsvo_ctx* ctx, int slot, int n_levels,
+                             const uint8_t* const* level_ptr, const int* width, const int* height,
+                             const int* stride_bytes);
+
+/* Upload level 0 only and build levels 1.. on the device with the 2x2 half-sampler
+ * (replaces vk::halfSample, [ext] vikit/vision.h, called from src/frame.cpp:178).
+ * rounding: 0 = vikit SSE2 path  avg(avg(a,c),avg(b,d)) with (x+y+1)>>1
+ *           1 = vikit scalar path (a+b+c+d)/4 truncating. */
+int plsvo_hip_build_pyramid(plsvo_ctx* ctx, int slot, const uint8_t* level0, int stride_bytes,
+                            int rounding);
+/* Same, level 0 already in HBM (tight rows or stride_bytes), for n consecutive slots starting at
+ * first_slot; image i is at d_level0 + i*image_pitch_bytes. */
+int plsvo_hip_build_pyramids_dev(plsvo_ctx* ctx, int first_slot, int n, const void* d_level0,
+                                 int stride_bytes, size_t image_pitch_bytes, int rounding);
+/* Read one level of a slot back to the host (tight rows); for tests. */
+int plsvo_hip_download_level(plsvo_ctx* ctx, int slot, int level, uint8_t* out);
+
+/* ------------------------------------------------------------------------------------------ */
+/* sparse image alignment                                                                      */
+/* replaces plsvo::SparseImgAlign::run   (include/plsvo/sparse_img_align.h:64-66,              */
+/*                                        src/sparse_img_align.cpp:54-95; call sites           */
+/*                                        src/frame_handler_mono.cpp:272-274, 418-420)         */
+/* ------------------------------------------------------------------------------------------ */
+
+/* One alignment job = one SparseImgAlign::run(ref_frame, cur_frame).
+ * Features are those of the REFERENCE frame, flattened (the adapter walks the std::lists once):
+ *   points  (ref_frame->pt_fts_ with feat3D != NULL):
+ *     pt_px      2*n_pts  Feature::px, level-0 pixels                (include/plsvo/feature.h:42)
+ *     pt_xyz_ref 3*n_pts  f * ||feat3D->pos_ - ref_frame->pos()||    (src/sparse_img_align.cpp:229-230)
+ *   segments (ref_frame->seg_fts_, ALL of them, so indices stay stable):
+ *     seg_spx/seg_epx 2*n_seg  LineFeat::spx / epx                   (include/plsvo/feature.h:85-86)
+ *     seg_len    n_seg    LineFeat::length                           (include/plsvo/feature.h:92)
+ *     seg_p_ref  3*n_seg  sf * ||feat3D->spos_ - ref_pos||           (src/sparse_img_align.cpp:327-328)
+ *     seg_q_ref  3*n_seg  ef * ||feat3D->epos_ - ref_pos||           (src/sparse_img_align.cpp:329-330)
+ *     seg_alive_in n_seg  1 if feat3D != NULL, 0 otherwise; NULL = all alive
+ */
+typedef struct plsvo_align_in {
+  int32_t ref_slot, cur_slot;       /* pyramid slots of ref_frame / cur_frame */
+  plsvo_pinhole cam;                /* cur_frame->cam_ == ref_frame->cam_ */
+  int32_t max_level, min_level;     /* SparseImgAlign ctor (src/sparse_img_align.cpp:40-52) */
+  int32_t n_iter;                   /* n_iter_ (30 at the call sites) */
+  int32_t reserved0;
+  double eps;                       /* eps_ = 1e-6 (src/sparse_img_align.cpp:51) */
+  double T_cur_from_ref[7];         /* cur.T_f_w * ref.T_f_w^-1 (src/sparse_img_align.cpp:80) */
+  int32_t n_pts, n_seg;
+  const double* pt_px;
+  const double* pt_xyz_ref;
+  const double* seg_spx;
+  const double* seg_epx;
+  const double* seg_len;
+  const double* seg_p_ref;
+  const double* seg_q_ref;
+  const uint8_t* seg_alive_in;
+} plsvo_align_in;
+
+typedef struct plsvo_align_out {
+  double T_cur_from_ref[7];         /* after all levels (src/sparse_img_align.cpp:92 multiplies by ref.T_f_w) */
+  uint64_t n_meas;                  /* n_meas_ of the last computeResiduals call */
+  uint64_t n_tracked;               /* run()'s return value n_meas_/16 (src/sparse_img_align.cpp:94) */
+  double H[36];                     /* H_ of the last computeResiduals (row-major; getFisherInformation, :97-102) */
+  double chi2;                      /* chi2_ of the solver ([ext] vk::NLLSSolver) */
+  uint8_t* seg_alive_out;           /* caller buffer of n_seg bytes or NULL; 0 = LineFeat::feat3D set to NULL
+                                       (src/sparse_img_align.cpp:687-688) */
+  int32_t iters_per_level[PLSVO_MAX_LEVELS];  /* #computeResiduals calls in the GN loop, index = level */
+  int32_t status;                   /* bit 0: solver stop_ flag was raised (NaN in solve, :700) */
+  int32_t reserved0;
+} plsvo_align_out;
+
+/* per-iteration trace (debug/parity): one record per GN iteration, in execution order */
+typedef struct plsvo_align_iterlog {
+  int32_t level, iter;
+  int32_t accepted;                 /* 1: update applied; 0: rolled back / stopped at this iteration */
+  int32_t stop;                     /* solver stop_ flag after this iteration */
+  uint64_t n_meas;
+  double new_chi2;                  /* value returned by computeResiduals (float chi2 / n_meas) */
+  double H[36], Jres[6], x[6];
+  double T_after[7];                /* model after this iteration's accept/rollback decision */
+} plsvo_align_iterlog;
+
+/* one job, synchronous: stage + run + fetch (the drop-in call) */
+int plsvo_sparse_align(plsvo_ctx* ctx, const plsvo_align_in* in, plsvo_align_out* out);
+/* n independent jobs in one batch, synchronous (BASELINE config 4: many streams) */
+int plsvo_sparse_align_batch(plsvo_ctx* ctx, int n, const plsvo_align_in* in, plsvo_align_out* out);
+
+/* the same, split so that a batch can stay resident in HBM and be re-run (bench, pipelining):
+ *   stage: copy job descriptors + features to the device (replaces any previously staged batch)
+ *   run  : enqueue the kernels on the ctx stream (asynchronous); re-initialises poses and alive
+ *          masks from the staged inputs each time it is called
+ *   fetch: wait for the stream and copy the results back */
+int plsvo_align_stage(plsvo_ctx* ctx, int n, const plsvo_align_in* in);
+int plsvo_align_run(plsvo_ctx* ctx);
+int plsvo_align_fetch(plsvo_ctx* ctx, int n, plsvo_align_out* out);
+
+/* per-iteration trace: enable before plsvo_align_run; max_records_per_job bounds the trace */
+int plsvo_align_set_trace(plsvo_ctx* ctx, int max_records_per_job);
+int plsvo_align_fetch_trace(plsvo_ctx* ctx, int job, plsvo_align_iterlog* out, int max_records,
+                            int* n_records);
+
+/* device pointer to the staged batch's result poses, n*7 doubles (for a device-side gather) */
+const double* plsvo_align_poses_dev(plsvo_ctx* ctx);
+
+/* work counters of the last plsvo_align_run (for the roofline accounting):
+ *   patch_levels = sum over jobs and levels of patches precomputed (497 B each)
+ *   patch_iters  = sum over jobs, levels and GN iterations of patches evaluated (485 B each) */
+int plsvo_align_work(plsvo_ctx* ctx, uint64_t* patch_levels, uint64_t* patch_iters);
+
+/* ------------------------------------------------------------------------------------------ */
+/* pose optimisation                                                                           */
+/* replaces plsvo::pose_optimizer::optimizeGaussNewton (include/plsvo/pose_optimizer.h:47-64,  */
+/*          src/pose_optimizer.cpp:38-260 and :262-582; call site frame_handler_mono.cpp:327)  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Features are those of the frame being optimised, flattened, only entries with feat3D != NULL:
+ *   pt_f   3*n_pts  Feature::f (bearing)         pt_pos  3*n_pts  feat3D->pos_ (world)
+ *   pt_level n_pts  Feature::level
+ *   seg_line 3*n_seg LineFeat::line (src/feature.cpp:103-104)
+ *   seg_spos/seg_epos 3*n_seg feat3D->spos_/epos_ (world)     seg_level n_seg */
+typedef struct plsvo_poseopt_in {
+  double T_f_w[7];                  /* frame->T_f_w_ on entry */
+  double fx;                        /* frame->cam_->errorMultiplier2() = |fx| ([ext] vikit) */
+  double reproj_thresh;             /* 2.0 at the call site (src/config.cpp:102) */
+  int32_t n_iter;                   /* 10 at the call site (src/config.cpp:103) */
+  int32_t n_iter_ref;               /* <0: 9-argument overload (:38); >=0: 10-argument overload (:262) */
+  int32_t n_pts, n_seg;
+  const double* pt_f;
+  const double* pt_pos;
+  const int32_t* pt_level;
+  const double* seg_line;
+  const double* seg_spos;
+  const double* seg_epos;
+  const int32_t* seg_level;
+} plsvo_poseopt_in;
+
+typedef struct plsvo_poseopt_out {
+  double T_f_w[7];                  /* frame->T_f_w_ on exit */
+  double cov[36];                   /* frame->Cov_ (src/pose_optimizer.cpp:198-199), row-major */
+  double estimated_scale, error_init, error_final;
+  uint64_t num_obs_pt, num_obs_ls;
+  uint8_t* pt_keep;                 /* caller buffers (n_pts / n_seg bytes) or NULL; 0 = feat3D set to NULL */
+  uint8_t* seg_keep;                /*   (src/pose_optimizer.cpp:218, 239) */
+  int32_t iters;                    /* GN iterations executed in the first loop */
+  int32_t iters_ref;                /* ... in the refinement loop of the 10-argument overload */
+  int32_t status;                   /* bit 0: early return, nothing written (errors.empty(), :88-89) */
+  int32_t reserved0;
+} plsvo_poseopt_out;
+
+typedef struct plsvo_poseopt_iterlog {
+  int32_t phase;                    /* 0: first loop, 1: refinement loop */
+  int32_t iter;
+  int32_t accepted;
+  int32_t reserved0;
+  double new_chi2;
+  double A[36], b[6], dT[6];
+  double T_after[7];
+} plsvo_poseopt_iterlog;
+
+int plsvo_pose_optimize(plsvo_ctx* ctx, const plsvo_poseopt_in* in, plsvo_poseopt_out* out);
+int plsvo_pose_optimize_batch(plsvo_ctx* ctx, int n, const plsvo_poseopt_in* in, plsvo_poseopt_out* out);
+int plsvo_poseopt_stage(plsvo_ctx* ctx, int n, const plsvo_poseopt_in* in);
+int plsvo_poseopt_run(plsvo_ctx* ctx);
+int plsvo_poseopt_fetch(plsvo_ctx* ctx, int n, plsvo_poseopt_out* out);
+int plsvo_poseopt_set_trace(plsvo_ctx* ctx, int max_records_per_job);
+int plsvo_poseopt_fetch_trace(plsvo_ctx* ctx, int job, plsvo_poseopt_iterlog* out, int max_records,
+                              int* n_records);
+const double* plsvo_poseopt_poses_dev(plsvo_ctx* ctx);
+/* feature-iterations of the last run: points (24 B each) and lines (40 B each), SURVEY 8d */
+int plsvo_poseopt_work(plsvo_ctx* ctx, uint64_t* pt_iters, uint64_t* seg_iters);
+
+/* ------------------------------------------------------------------------------------------ */
+/* multi-GPU: gather of per-stream pose records (new; the reference is single-process)         */
+/* ------------------------------------------------------------------------------------------ */
+
+/* All-gather of n_local pose records (7 doubles each, device memory) over an RCCL communicator
+ * (ncclComm_t passed as void*), enqueued on the ctx stream: d_all receives world_size*n_local
+ * records, rank-major.  No other collective exists on this path (streams are independent). */
+int plsvo_gather_poses(plsvo_ctx* ctx, void* rccl_comm, const double* d_local, int n_local,
+                       double* d_all);
+
+/* ------------------------------------------------------------------------------------------ */
+/* timing (hipEvent pairs recorded on the ctx stream around each kernel family)                */
+/* ------------------------------------------------------------------------------------------ */
+#define PLSVO_K_ALIGN_INIT    0
+#define PLSVO_K_ALIGN_LEVEL   1   /* the residual/Jacobian + GN kernel (dominant) */
+#define PLSVO_K_POSEOPT       2
+#define PLSVO_K_HALFSAMPLE    3
+#define PLSVO_K_COUNT         4
+int plsvo_hip_set_profiling(plsvo_ctx* ctx, int enable);
+/* accumulated GPU time and launch count of kernel family k since the last reset (synchronises) */
+int plsvo_hip_kernel_time(plsvo_ctx* ctx, int k, double* total_ms, int64_t* launches);
+int plsvo_hip_reset_profiling(plsvo_ctx* ctx);
+
+/* library / device info */
+const char* plsvo_hip_version(void);
+int plsvo_hip_device_info(plsvo_ctx* ctx, char* name, int name_len, int* cu_count, size_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLSVO_HIP_H_ */

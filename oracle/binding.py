@@ -1,0 +1,232 @@
+"""ctypes binding of the CPU oracle (oracle/libplsvo_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (pl-svo_amd/) never imports this module.
+"""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+abi = importlib.import_module("pl-svo_amd.abi")
+
+_LIB_PATH = os.path.join(_HERE, "libplsvo_oracle.so")
+
+
+class OraclePyr(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("reserved0", C.c_int32), ("img", abi.c_u8_p * abi.MAX_LEVELS),
+                ("width", C.c_int32 * abi.MAX_LEVELS), ("height", C.c_int32 * abi.MAX_LEVELS),
+                ("stride", C.c_int32 * abi.MAX_LEVELS)]
+
+
+def build(force=False):
+    """Compile the oracle with its Makefile (gcc only; no reference sources involved)."""
+    src = os.path.join(_HERE, "plsvo_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.plsvo_oracle_sparse_align.restype = C.c_int
+        L.plsvo_oracle_sparse_align.argtypes = [C.POINTER(abi.AlignIn), C.POINTER(OraclePyr), C.POINTER(OraclePyr),
+                                                C.POINTER(abi.AlignOut), C.POINTER(abi.AlignIterLog), C.c_int,
+                                                C.POINTER(C.c_int)]
+        L.plsvo_oracle_pose_optimize.restype = C.c_int
+        L.plsvo_oracle_pose_optimize.argtypes = [C.POINTER(abi.PoseOptIn), C.POINTER(abi.PoseOptOut),
+                                                 C.POINTER(abi.PoseOptIterLog), C.c_int, C.POINTER(C.c_int)]
+        L.plsvo_oracle_halfsample.restype = None
+        L.plsvo_oracle_halfsample.argtypes = [abi.c_u8_p, C.c_int, C.c_int, C.c_int, abi.c_u8_p, C.c_int, C.c_int]
+        d = abi.c_double_p
+        for name, args, res in [
+            ("plsvo_oracle_se3_exp", [d, d], None), ("plsvo_oracle_se3_mul", [d, d, d], None),
+            ("plsvo_oracle_se3_inv", [d, d], None), ("plsvo_oracle_se3_act", [d, d, d], None),
+            ("plsvo_oracle_se3_matrix", [d, d, d], None), ("plsvo_oracle_ldlt_solve6", [d, d, d], C.c_int),
+            ("plsvo_oracle_inv6", [d, d], None), ("plsvo_oracle_jacobian_xyz2uv", [d, d], None),
+            ("plsvo_oracle_setup_sampling", [d, d, C.c_double, C.c_uint64, d], C.c_uint64),
+            ("plsvo_oracle_line_normal", [d, d, d], None), ("plsvo_oracle_scaled_bearing", [d, d, d, d], None),
+            ("plsvo_oracle_cam2world", [C.POINTER(abi.Pinhole), d, d], None),
+            ("plsvo_oracle_world2cam", [C.POINTER(abi.Pinhole), d, d], None),
+            ("plsvo_oracle_tukey", [C.c_float], C.c_float),
+            ("plsvo_oracle_mad_scale", [C.POINTER(C.c_float), C.c_uint64], C.c_float),
+            ("plsvo_oracle_median_f64", [d, C.c_uint64], C.c_double),
+        ]:
+            f = getattr(L, name)
+            f.argtypes = args
+            f.restype = res
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(abi.c_double_p)
+
+
+def make_pyr(levels):
+    """levels: list of 2-D uint8 numpy arrays (level 0 first).  Returns (OraclePyr, keepalive)."""
+    keep = [np.ascontiguousarray(l, dtype=np.uint8) for l in levels]
+    p = OraclePyr()
+    p.n_levels = len(keep)
+    for i, l in enumerate(keep):
+        p.img[i] = l.ctypes.data_as(abi.c_u8_p)
+        p.height[i], p.width[i] = l.shape
+        p.stride[i] = l.strides[0]
+    return p, keep
+
+
+def halfsample(img, rounding=0):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.empty((h // 2, w // 2), dtype=np.uint8)
+    lib().plsvo_oracle_halfsample(img.ctypes.data_as(abi.c_u8_p), w, h, img.strides[0],
+                                  out.ctypes.data_as(abi.c_u8_p), out.strides[0], rounding)
+    return out
+
+
+def build_pyramid(img0, n_levels, rounding=0):
+    pyr = [np.ascontiguousarray(img0, dtype=np.uint8)]
+    for _ in range(1, n_levels):
+        pyr.append(halfsample(pyr[-1], rounding))
+    return pyr
+
+
+def sparse_align(job, ref_levels, cur_levels, max_log=0):
+    """job: abi.AlignJob.  Returns (abi.AlignResult, [iteration log dicts])."""
+    L = lib()
+    rp, k1 = make_pyr(ref_levels)
+    cp, k2 = make_pyr(cur_levels)
+    out = abi.AlignOut()
+    alive = np.ones(max(job.n_seg, 1), dtype=np.uint8)
+    out.seg_alive_out = alive.ctypes.data_as(abi.c_u8_p)
+    n_log = C.c_int(0)
+    log = (abi.AlignIterLog * max(max_log, 1))()
+    rc = L.plsvo_oracle_sparse_align(C.byref(job.c), C.byref(rp), C.byref(cp), C.byref(out),
+                                     log if max_log > 0 else None, max_log, C.byref(n_log))
+    if rc != 0:
+        raise RuntimeError(f"oracle sparse_align failed rc={rc}")
+    res = abi.AlignResult(out, alive[:job.n_seg].copy())
+    return res, abi.align_log_to_dicts(log, min(n_log.value, max_log))
+
+
+def pose_optimize(job, max_log=0):
+    L = lib()
+    out = abi.PoseOptOut()
+    pk = np.ones(max(job.n_pts, 1), dtype=np.uint8)
+    sk = np.ones(max(job.n_seg, 1), dtype=np.uint8)
+    out.pt_keep = pk.ctypes.data_as(abi.c_u8_p)
+    out.seg_keep = sk.ctypes.data_as(abi.c_u8_p)
+    n_log = C.c_int(0)
+    log = (abi.PoseOptIterLog * max(max_log, 1))()
+    rc = L.plsvo_oracle_pose_optimize(C.byref(job.c), C.byref(out), log if max_log > 0 else None, max_log,
+                                      C.byref(n_log))
+    if rc != 0:
+        raise RuntimeError(f"oracle pose_optimize failed rc={rc}")
+    res = abi.PoseOptResult(out, pk[:job.n_pts].copy(), sk[:job.n_seg].copy())
+    return res, abi.poseopt_log_to_dicts(log, min(n_log.value, max_log))
+
+
+# --- small helpers for unit tests -------------------------------------------------------------
+
+def se3_exp(u):
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    T = np.empty(7)
+    lib().plsvo_oracle_se3_exp(_dp(u), _dp(T))
+    return T
+
+
+def se3_mul(A, B):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    Cc = np.empty(7)
+    lib().plsvo_oracle_se3_mul(_dp(A), _dp(B), _dp(Cc))
+    return Cc
+
+
+def se3_inv(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    B = np.empty(7)
+    lib().plsvo_oracle_se3_inv(_dp(A), _dp(B))
+    return B
+
+
+def se3_act(T, p):
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    o = np.empty(3)
+    lib().plsvo_oracle_se3_act(_dp(T), _dp(p), _dp(o))
+    return o
+
+
+def se3_matrix(T):
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    R = np.empty(9)
+    t = np.empty(3)
+    lib().plsvo_oracle_se3_matrix(_dp(T), _dp(R), _dp(t))
+    return R.reshape(3, 3), t
+
+
+def ldlt_solve6(H, b):
+    H = np.ascontiguousarray(H, dtype=np.float64).reshape(36)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.empty(6)
+    lib().plsvo_oracle_ldlt_solve6(_dp(H), _dp(b), _dp(x))
+    return x
+
+
+def inv6(A):
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(36)
+    o = np.empty(36)
+    lib().plsvo_oracle_inv6(_dp(A), _dp(o))
+    return o.reshape(6, 6)
+
+
+def jacobian_xyz2uv(xyz):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    J = np.empty(12)
+    lib().plsvo_oracle_jacobian_xyz2uv(_dp(xyz), _dp(J))
+    return J.reshape(2, 6)
+
+
+def setup_sampling(spx, epx, length, patch_size=4):
+    spx = np.ascontiguousarray(spx, dtype=np.float64)
+    epx = np.ascontiguousarray(epx, dtype=np.float64)
+    dif = np.empty(2)
+    n = lib().plsvo_oracle_setup_sampling(_dp(spx), _dp(epx), float(length), patch_size, _dp(dif))
+    return int(n), dif
+
+
+def line_normal(sf, ef):
+    sf = np.ascontiguousarray(sf, dtype=np.float64)
+    ef = np.ascontiguousarray(ef, dtype=np.float64)
+    o = np.empty(3)
+    lib().plsvo_oracle_line_normal(_dp(sf), _dp(ef), _dp(o))
+    return o
+
+
+def tukey(x):
+    return float(lib().plsvo_oracle_tukey(C.c_float(x)))
+
+
+def mad_scale(errors):
+    e = np.ascontiguousarray(errors, dtype=np.float32).copy()
+    return float(lib().plsvo_oracle_mad_scale(e.ctypes.data_as(C.POINTER(C.c_float)), e.size))
+
+
+def median_f64(v):
+    v = np.ascontiguousarray(v, dtype=np.float64).copy()
+    return float(lib().plsvo_oracle_median_f64(_dp(v), v.size))

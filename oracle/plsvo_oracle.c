@@ -1,0 +1,864 @@
+/*
+ * plsvo_oracle.c -- CPU restatement of PL-SVO's sparse image alignment + pose optimisation.
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see plsvo_oracle.h for what that means and why).
+ *
+ * Typing follows the reference exactly: image interpolation, residuals and robust weights in
+ * float; geometry, Jacobians and all accumulators in double.  Build with -ffp-contract=off so the
+ * float expressions round like written C (the reference's build flags, CMakeLists.txt:25-36, do not
+ * pin contraction either way; see DESIGN.md "numerics").
+ *
+ * Every function cites the reference file:line it follows; "[ext]" marks semantics of a third-party
+ * dependency that is NOT under /root/reference and is restated from its published source.
+ */
+#include "plsvo_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ============================================================================================ */
+/* [ext] Sophus (non-templated) SO3 / SE3, storage: unit quaternion (x,y,z,w) + translation      */
+/* ============================================================================================ */
+
+#define SMALL_EPS 1e-10 /* [ext] sophus/so3.h */
+
+typedef struct { double x, y, z, w; } quat_t;
+typedef struct { quat_t q; double t[3]; } se3_t;
+
+static se3_t se3_load(const double T[7]) {
+  se3_t r; r.q.x = T[0]; r.q.y = T[1]; r.q.z = T[2]; r.q.w = T[3];
+  r.t[0] = T[4]; r.t[1] = T[5]; r.t[2] = T[6]; return r;
+}
+static void se3_store(const se3_t* s, double T[7]) {
+  T[0] = s->q.x; T[1] = s->q.y; T[2] = s->q.z; T[3] = s->q.w;
+  T[4] = s->t[0]; T[5] = s->t[1]; T[6] = s->t[2];
+}
+
+/* [ext] Eigen::Quaternion product */
+static quat_t quat_mul(quat_t a, quat_t b) {
+  quat_t r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  return r;
+}
+/* [ext] Eigen::Quaternion::normalize: coeffs /= sqrt(squaredNorm) */
+static quat_t quat_normalized(quat_t a) {
+  const double n = sqrt(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w);
+  quat_t r = { a.x / n, a.y / n, a.z / n, a.w / n };
+  return r;
+}
+/* [ext] Eigen::Quaternion::_transformVector:  uv = 2 * vec x v;  v + w*uv + vec x uv
+ * (SO3::operator*(Vector3d) in Sophus calls this) */
+static void quat_rotate(quat_t q, const double v[3], double out[3]) {
+  double uv[3];
+  uv[0] = q.y * v[2] - q.z * v[1];
+  uv[1] = q.z * v[0] - q.x * v[2];
+  uv[2] = q.x * v[1] - q.y * v[0];
+  uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+  out[0] = v[0] + q.w * uv[0] + (q.y * uv[2] - q.z * uv[1]);
+  out[1] = v[1] + q.w * uv[1] + (q.z * uv[0] - q.x * uv[2]);
+  out[2] = v[2] + q.w * uv[2] + (q.x * uv[1] - q.y * uv[0]);
+}
+/* [ext] Eigen::Quaternion::toRotationMatrix, row-major */
+static void quat_to_matrix(quat_t q, double R[9]) {
+  const double tx = 2.0 * q.x, ty = 2.0 * q.y, tz = 2.0 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+  R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+/* [ext] Sophus::SE3::operator*: t = t_A + R_A t_B; q = normalize(q_A q_B) */
+static se3_t se3_mul(const se3_t* A, const se3_t* B) {
+  se3_t r; double rt[3];
+  quat_rotate(A->q, B->t, rt);
+  r.t[0] = A->t[0] + rt[0]; r.t[1] = A->t[1] + rt[1]; r.t[2] = A->t[2] + rt[2];
+  r.q = quat_normalized(quat_mul(A->q, B->q));
+  return r;
+}
+/* [ext] Sophus::SE3::inverse: (q^-1, q^-1 * (-t)) */
+static se3_t se3_inv(const se3_t* A) {
+  se3_t r; double nt[3] = { A->t[0] * -1., A->t[1] * -1., A->t[2] * -1. };
+  r.q.x = -A->q.x; r.q.y = -A->q.y; r.q.z = -A->q.z; r.q.w = A->q.w;
+  quat_rotate(r.q, nt, r.t);
+  return r;
+}
+static void se3_act(const se3_t* T, const double p[3], double out[3]) {
+  quat_rotate(T->q, p, out);
+  out[0] += T->t[0]; out[1] += T->t[1]; out[2] += T->t[2];
+}
+/* [ext] Sophus::SE3::exp(Vector6d): tangent = (upsilon[0:3], omega[3:6]); SO3::expAndTheta */
+static se3_t se3_exp(const double u[6]) {
+  se3_t r;
+  const double ox = u[3], oy = u[4], oz = u[5];
+  const double theta = sqrt(ox * ox + oy * oy + oz * oz);
+  const double half_theta = 0.5 * theta;
+  double imag_factor;
+  const double real_factor = cos(half_theta);
+  if (theta < SMALL_EPS) {
+    const double theta_sq = theta * theta;
+    const double theta_po4 = theta_sq * theta_sq;
+    imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * theta_po4;
+  } else {
+    const double sin_half_theta = sin(half_theta);
+    imag_factor = sin_half_theta / theta;
+  }
+  quat_t q = { imag_factor * ox, imag_factor * oy, imag_factor * oz, real_factor };
+  r.q = quat_normalized(q); /* SO3(Quaterniond) ctor normalises */
+  /* V = I + (1-cos t)/t^2 Omega + (t - sin t)/t^3 Omega^2, or the rotation matrix when t is tiny */
+  double V[9];
+  if (theta < SMALL_EPS) {
+    quat_to_matrix(r.q, V);
+  } else {
+    const double O[9] = { 0, -oz, oy, oz, 0, -ox, -oy, ox, 0 };
+    double O2[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        O2[i * 3 + j] = O[i * 3 + 0] * O[0 * 3 + j] + O[i * 3 + 1] * O[1 * 3 + j] + O[i * 3 + 2] * O[2 * 3 + j];
+    const double theta_sq = theta * theta;
+    const double a = (1 - cos(theta)) / (theta_sq);
+    const double b = (theta - sin(theta)) / (theta_sq * theta);
+    for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * O[i] + b * O2[i];
+  }
+  for (int i = 0; i < 3; ++i) r.t[i] = V[i * 3 + 0] * u[0] + V[i * 3 + 1] * u[1] + V[i * 3 + 2] * u[2];
+  return r;
+}
+
+void plsvo_oracle_se3_exp(const double u[6], double T[7]) { se3_t r = se3_exp(u); se3_store(&r, T); }
+void plsvo_oracle_se3_mul(const double A[7], const double B[7], double C[7]) {
+  se3_t a = se3_load(A), b = se3_load(B), c = se3_mul(&a, &b); se3_store(&c, C);
+}
+void plsvo_oracle_se3_inv(const double A[7], double B[7]) { se3_t a = se3_load(A), b = se3_inv(&a); se3_store(&b, B); }
+void plsvo_oracle_se3_act(const double T[7], const double p[3], double out[3]) { se3_t t = se3_load(T); se3_act(&t, p, out); }
+void plsvo_oracle_se3_matrix(const double T[7], double R[9], double t[3]) {
+  se3_t s = se3_load(T); quat_to_matrix(s.q, R); t[0] = s.t[0]; t[1] = s.t[1]; t[2] = s.t[2];
+}
+
+/* ============================================================================================ */
+/* [ext] Eigen 3 dense pieces: LDLT with diagonal pivoting (ldlt().solve) and PartialPivLU inverse */
+/* ============================================================================================ */
+
+/* Eigen::LDLT<Matrix6d>::compute (unblocked, lower) followed by solve():
+ *   dst = P b;  L^-1;  D^-1 (entries with |d| <= 1/highest() give 0);  L^-T;  P^T.
+ * returns 0 always (Eigen reports nothing here); NaN/Inf propagate into x. */
+int plsvo_oracle_ldlt_solve6(const double H[36], const double b[6], double x[6]) {
+  enum { N = 6 };
+  double m[N][N]; int tr[N];
+  for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) m[i][j] = H[i * N + j];
+  for (int k = 0; k < N; ++k) {
+    /* largest |diagonal| in the remaining corner (first maximum wins) */
+    int big = k; double bigv = fabs(m[k][k]);
+    for (int i = k + 1; i < N; ++i) { const double v = fabs(m[i][i]); if (v > bigv) { bigv = v; big = i; } }
+    tr[k] = big;
+    if (k != big) {
+      const int s = N - big - 1;
+      for (int j = 0; j < k; ++j) { const double t = m[k][j]; m[k][j] = m[big][j]; m[big][j] = t; }
+      for (int i = 0; i < s; ++i) { const double t = m[big + 1 + i][k]; m[big + 1 + i][k] = m[big + 1 + i][big]; m[big + 1 + i][big] = t; }
+      { const double t = m[k][k]; m[k][k] = m[big][big]; m[big][big] = t; }
+      for (int i = k + 1; i < big; ++i) { const double t = m[i][k]; m[i][k] = m[big][i]; m[big][i] = t; }
+    }
+    const int rs = N - k - 1;
+    if (k > 0) {
+      double temp[N];
+      for (int j = 0; j < k; ++j) temp[j] = m[j][j] * m[k][j];
+      double acc = 0.0;
+      for (int j = 0; j < k; ++j) acc += m[k][j] * temp[j];
+      m[k][k] -= acc;
+      for (int i = k + 1; i < N; ++i) {
+        double a2 = 0.0;
+        for (int j = 0; j < k; ++j) a2 += m[i][j] * temp[j];
+        m[i][k] -= a2;
+      }
+    }
+    const double akk = m[k][k];
+    const int pivot_is_valid = fabs(akk) > 0.0;
+    if (k == 0 && !pivot_is_valid) { /* the whole diagonal is zero: nothing more to do */
+      for (int j = 0; j < N; ++j) tr[j] = j;
+      break;
+    }
+    if (rs > 0 && pivot_is_valid) for (int i = k + 1; i < N; ++i) m[i][k] /= akk;
+  }
+  double d[N];
+  for (int i = 0; i < N; ++i) d[i] = b[i];
+  for (int k = 0; k < N; ++k) { const double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
+  for (int i = 0; i < N; ++i) for (int j = 0; j < i; ++j) d[i] -= m[i][j] * d[j];
+  const double tolerance = 1.0 / 1.7976931348623157e308;
+  for (int i = 0; i < N; ++i) { if (fabs(m[i][i]) > tolerance) d[i] /= m[i][i]; else d[i] = 0.0; }
+  for (int i = N - 1; i >= 0; --i) for (int j = i + 1; j < N; ++j) d[i] -= m[j][i] * d[j];
+  for (int k = N - 1; k >= 0; --k) { const double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
+  for (int i = 0; i < N; ++i) x[i] = d[i];
+  return 0;
+}
+
+/* Eigen's inverse() of a fixed 6x6 goes through PartialPivLU: LU with row pivoting, solve for I */
+void plsvo_oracle_inv6(const double A[36], double Ainv[36]) {
+  enum { N = 6 };
+  double lu[N][N]; int perm[N];
+  for (int i = 0; i < N; ++i) { perm[i] = i; for (int j = 0; j < N; ++j) lu[i][j] = A[i * N + j]; }
+  for (int k = 0; k < N; ++k) {
+    int piv = k; double pv = fabs(lu[k][k]);
+    for (int i = k + 1; i < N; ++i) { const double v = fabs(lu[i][k]); if (v > pv) { pv = v; piv = i; } }
+    if (piv != k) {
+      for (int j = 0; j < N; ++j) { const double t = lu[k][j]; lu[k][j] = lu[piv][j]; lu[piv][j] = t; }
+      const int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    }
+    for (int i = k + 1; i < N; ++i) {
+      lu[i][k] /= lu[k][k];
+      for (int j = k + 1; j < N; ++j) lu[i][j] -= lu[i][k] * lu[k][j];
+    }
+  }
+  for (int c = 0; c < N; ++c) {
+    double y[N];
+    for (int i = 0; i < N; ++i) y[i] = (perm[i] == c) ? 1.0 : 0.0;
+    for (int i = 0; i < N; ++i) for (int j = 0; j < i; ++j) y[i] -= lu[i][j] * y[j];
+    for (int i = N - 1; i >= 0; --i) { for (int j = i + 1; j < N; ++j) y[i] -= lu[i][j] * y[j]; y[i] /= lu[i][i]; }
+    for (int i = 0; i < N; ++i) Ainv[i * N + c] = y[i];
+  }
+}
+
+/* ============================================================================================ */
+/* [ext] vikit_common: pinhole camera, math_utils, robust_cost, halfSample                        */
+/* ============================================================================================ */
+
+/* vk::PinholeCamera::world2cam (no distortion): project2d, then fx*u+cx */
+void plsvo_oracle_world2cam(const plsvo_pinhole* cam, const double xyz[3], double px[2]) {
+  const double u = xyz[0] / xyz[2], v = xyz[1] / xyz[2];
+  px[0] = cam->fx * u + cam->cx;
+  px[1] = cam->fy * v + cam->cy;
+}
+/* vk::PinholeCamera::cam2world (no distortion): normalised ((u-cx)/fx, (v-cy)/fy, 1) */
+void plsvo_oracle_cam2world(const plsvo_pinhole* cam, const double px[2], double f[3]) {
+  double x = (px[0] - cam->cx) / cam->fx, y = (px[1] - cam->cy) / cam->fy, z = 1.0;
+  const double n = sqrt(x * x + y * y + z * z);
+  f[0] = x / n; f[1] = y / n; f[2] = z / n;
+}
+/* vk::AbstractCamera::isInFrame(Vector2i obs, int boundary, int level) */
+static int cam_is_in_frame(const plsvo_pinhole* cam, int ox, int oy, int boundary, int level) {
+  return ox >= boundary && ox < cam->width / (1 << level) - boundary &&
+         oy >= boundary && oy < cam->height / (1 << level) - boundary;
+}
+
+static int cmp_f32(const void* a, const void* b) { const float x = *(const float*)a, y = *(const float*)b; return (x > y) - (x < y); }
+static int cmp_f64(const void* a, const void* b) { const double x = *(const double*)a, y = *(const double*)b; return (x > y) - (x < y); }
+/* vk::getMedian: nth_element at floor(n/2) -- value-equivalent to sorting and indexing */
+static float median_f32(float* v, uint64_t n) { qsort(v, n, sizeof(float), cmp_f32); return v[n / 2]; }
+double plsvo_oracle_median_f64(double* v, uint64_t n) { qsort(v, n, sizeof(double), cmp_f64); return v[n / 2]; }
+/* vk::robust_cost::MADScaleEstimator::compute = 1.48f * median */
+float plsvo_oracle_mad_scale(float* errors, uint64_t n) { return 1.48f * median_f32(errors, n); }
+/* vk::robust_cost::TukeyWeightFunction::value, b = 4.6851f */
+float plsvo_oracle_tukey(float x) {
+  const float b = 4.6851f; const float b_square = b * b;
+  const float x_square = x * x;
+  if (x_square <= b_square) { const float tmp = 1.0f - x_square / b_square; return tmp * tmp; }
+  return 0.0f;
+}
+static double norm_max6(const double v[6]) { double m = 0; for (int i = 0; i < 6; ++i) { const double a = fabs(v[i]); if (a > m) m = a; } return m; }
+
+void plsvo_oracle_halfsample(const uint8_t* in, int w, int h, int stride, uint8_t* out, int out_stride, int rounding) {
+  const int ow = w / 2, oh = h / 2;
+  for (int y = 0; y < oh; ++y) {
+    const uint8_t* r0 = in + (size_t)(2 * y) * stride; const uint8_t* r1 = r0 + stride;
+    for (int x = 0; x < ow; ++x) {
+      const int a = r0[2 * x], b = r0[2 * x + 1], c = r1[2 * x], d = r1[2 * x + 1];
+      if (rounding == 0) { /* SSE2 path: _mm_avg_epu8 of the rows, then _mm_avg_epu16 of neighbours */
+        const int ac = (a + c + 1) >> 1, bd = (b + d + 1) >> 1;
+        out[(size_t)y * out_stride + x] = (uint8_t)((ac + bd + 1) >> 1);
+      } else {
+        out[(size_t)y * out_stride + x] = (uint8_t)((a + b + c + d) / 4);
+      }
+    }
+  }
+}
+
+/* ============================================================================================ */
+/* reference-owned helpers                                                                       */
+/* ============================================================================================ */
+
+/* Frame::jacobian_xyz2uv  include/plsvo/frame.h:138-160 (row-major 2x6) */
+void plsvo_oracle_jacobian_xyz2uv(const double xyz[3], double J[12]) {
+  const double x = xyz[0], y = xyz[1];
+  const double z_inv = 1. / xyz[2];
+  const double z_inv_2 = z_inv * z_inv;
+  J[0] = -z_inv; J[1] = 0.0; J[2] = x * z_inv_2; J[3] = y * J[2]; J[4] = -(1.0 + x * J[2]); J[5] = y * z_inv;
+  J[6] = 0.0; J[7] = -z_inv; J[8] = y * z_inv_2; J[9] = 1.0 + y * J[8]; J[10] = -J[3]; J[11] = -x * z_inv;
+}
+
+/* LineFeat::setupSampling  src/feature.cpp:160-173 */
+uint64_t plsvo_oracle_setup_sampling(const double spx[2], const double epx[2], double length, uint64_t patch_size, double dif[2]) {
+  dif[0] = epx[0] - spx[0]; dif[1] = epx[1] - spx[1];
+  const double a0 = fabs(dif[0]), a1 = fabs(dif[1]);
+  const double tan_dir = (a0 < a1 ? a0 : a1) / (a0 > a1 ? a0 : a1);
+  const double sin_dir = tan_dir / sqrt(1.0 + tan_dir * tan_dir);
+  const double correction = 2.0 * sqrt(1.0 + sin_dir * sin_dir);
+  const double v = length / (2.0 * patch_size * correction);
+  return (uint64_t)(1.0 > v ? 1.0 : v); /* std::max(1.0, v); NaN (zero-length segment) gives 1.0 like std::max */
+}
+
+/* LineFeat ctor  src/feature.cpp:103-104: line = sf x ef, scaled so (l0,l1) is unit */
+void plsvo_oracle_line_normal(const double sf[3], const double ef[3], double line[3]) {
+  double l[3] = { sf[1] * ef[2] - sf[2] * ef[1], sf[2] * ef[0] - sf[0] * ef[2], sf[0] * ef[1] - sf[1] * ef[0] };
+  const double n = sqrt(l[0] * l[0] + l[1] * l[1]);
+  line[0] = l[0] / n; line[1] = l[1] / n; line[2] = l[2] / n;
+}
+
+/* src/sparse_img_align.cpp:229-230 (also :327-330, 422-423, 568-571): f * ||pos - ref_pos|| */
+void plsvo_oracle_scaled_bearing(const double f[3], const double pos[3], const double ref_pos[3], double out[3]) {
+  const double d0 = pos[0] - ref_pos[0], d1 = pos[1] - ref_pos[1], d2 = pos[2] - ref_pos[2];
+  const double depth = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+  out[0] = f[0] * depth; out[1] = f[1] * depth; out[2] = f[2] * depth;
+}
+
+/* Patch  include/plsvo/feature.h:107-147, src/feature.cpp:175-218 */
+typedef struct {
+  float u_ref, v_ref; int u_ref_i, v_ref_i;
+  float wTL, wTR, wBL, wBR;
+  const uint8_t* img; int cols, rows, stride;
+} patch_t;
+enum { P_SIZE = 4, P_HALF = 2, P_AREA = 16 };
+
+static void patch_init(patch_t* p, const plsvo_oracle_pyr* pyr, int level) {
+  p->img = pyr->img[level]; p->cols = pyr->width[level]; p->rows = pyr->height[level]; p->stride = pyr->stride[level];
+}
+static void patch_set_position(patch_t* p, double px, double py) { /* feature.cpp:189-197 */
+  p->u_ref = (float)px; p->v_ref = (float)py;
+  p->u_ref_i = (int)floorf(p->u_ref); p->v_ref_i = (int)floorf(p->v_ref);
+}
+static int patch_is_in_frame(const patch_t* p, int boundary) { /* feature.h:139-144 */
+  return !(p->u_ref_i < boundary || p->v_ref_i < boundary || p->u_ref_i >= p->cols - boundary || p->v_ref_i >= p->rows - boundary);
+}
+static void patch_interp_weights(patch_t* p) { /* feature.cpp:199-208: double arithmetic, float storage */
+  const float subpix_u_ref = p->u_ref - p->u_ref_i;
+  const float subpix_v_ref = p->v_ref - p->v_ref_i;
+  p->wTL = (1.0 - subpix_u_ref) * (1.0 - subpix_v_ref);
+  p->wTR = subpix_u_ref * (1.0 - subpix_v_ref);
+  p->wBL = (1.0 - subpix_u_ref) * subpix_v_ref;
+  p->wBR = subpix_u_ref * subpix_v_ref;
+}
+/* pointer to ROI row y: cv::Rect(u_i-2, v_i-2, 4, 4)  feature.cpp:210-218 */
+static const uint8_t* patch_row(const patch_t* p, int y) {
+  return p->img + (ptrdiff_t)(p->v_ref_i - P_HALF + y) * p->stride + (p->u_ref_i - P_HALF);
+}
+
+/* ============================================================================================ */
+/* SparseImgAlign  src/sparse_img_align.cpp                                                      */
+/* ============================================================================================ */
+
+typedef struct { /* SparseImgAlign::Cache  sparse_img_align.h:83-96 */
+  double* jacobian;   /* 6 x (n*16), column-major */
+  float* ref_patch;   /* n x 16 */
+  uint8_t* visible;   /* n */
+  size_t n;
+} cache_t;
+
+typedef struct {
+  const plsvo_align_in* in; const plsvo_oracle_pyr* ref; const plsvo_oracle_pyr* cur;
+  int level;
+  cache_t pt_cache, seg_cache;
+  size_t* patch_offset;
+  int have_ref_patch_cache;
+  uint8_t* seg_alive; /* LineFeat::feat3D != NULL */
+  /* [ext] vk::NLLSSolver<6,SE3> state */
+  double H[36], Jres[6], x[6];
+  double chi2; size_t n_meas; int iter, n_iter, stop, use_weights;
+  double scale_, scale_ls, scale_pt;
+} align_t;
+
+static void cache_alloc(cache_t* c, size_t n) {
+  c->n = n;
+  c->jacobian = (double*)calloc(6 * (n ? n : 1) * P_AREA, sizeof(double));
+  c->ref_patch = (float*)calloc((n ? n : 1) * P_AREA, sizeof(float));
+  c->visible = (uint8_t*)calloc(n ? n : 1, 1);
+}
+static void cache_free(cache_t* c) { free(c->jacobian); free(c->ref_patch); free(c->visible); }
+
+/* the 16-pixel inner loop shared by :243-264 and :354-375 */
+static void precompute_patch(const patch_t* patch, const double frame_jac[12], double focal_over_scale,
+                             float* cache_ptr, double* jac_cols) {
+  const int stride = patch->stride;
+  const float wTL = patch->wTL, wTR = patch->wTR, wBL = patch->wBL, wBR = patch->wBR;
+  int pixel_counter = 0;
+  for (int y = 0; y < P_SIZE; ++y) {
+    const uint8_t* img_ptr = patch_row(patch, y);
+    for (int x = 0; x < P_SIZE; ++x, ++img_ptr, ++cache_ptr, ++pixel_counter) {
+      *cache_ptr = wTL * img_ptr[0] + wTR * img_ptr[1] + wBL * img_ptr[stride] + wBR * img_ptr[stride + 1];
+      float dx = 0.5f * ((wTL * img_ptr[1] + wTR * img_ptr[2] + wBL * img_ptr[stride + 1] + wBR * img_ptr[stride + 2])
+                       - (wTL * img_ptr[-1] + wTR * img_ptr[0] + wBL * img_ptr[stride - 1] + wBR * img_ptr[stride]));
+      float dy = 0.5f * ((wTL * img_ptr[stride] + wTR * img_ptr[1 + stride] + wBL * img_ptr[stride * 2] + wBR * img_ptr[stride * 2 + 1])
+                       - (wTL * img_ptr[-stride] + wTR * img_ptr[1 - stride] + wBL * img_ptr[0] + wBR * img_ptr[1]));
+      double* col = jac_cols + 6 * pixel_counter;
+      for (int k = 0; k < 6; ++k) col[k] = (dx * frame_jac[k] + dy * frame_jac[6 + k]) * focal_over_scale;
+    }
+  }
+}
+
+/* precomputeGaussNewtonParamsPoints  :195-268 */
+static void precompute_points(align_t* a) {
+  const plsvo_align_in* in = a->in;
+  patch_t patch; patch_init(&patch, a->ref, a->level);
+  const float scale = 1.0f / (1 << a->level);
+  const double focal_length = fabs(in->cam.fx); /* errorMultiplier2() */
+  for (int i = 0; i < in->n_pts; ++i) {
+    /* feat3D == NULL entries are not part of the flattened input */
+    patch_set_position(&patch, in->pt_px[2 * i] * scale, in->pt_px[2 * i + 1] * scale);
+    if (!patch_is_in_frame(&patch, P_HALF + 1)) continue;
+    patch_interp_weights(&patch);
+    a->pt_cache.visible[i] = 1;
+    double frame_jac[12];
+    plsvo_oracle_jacobian_xyz2uv(&in->pt_xyz_ref[3 * i], frame_jac);
+    precompute_patch(&patch, frame_jac, focal_length / (1 << a->level),
+                     a->pt_cache.ref_patch + (size_t)P_AREA * i, a->pt_cache.jacobian + (size_t)6 * P_AREA * i);
+  }
+}
+
+/* precomputeGaussNewtonParamsSegments  :270-378 */
+static void precompute_segments(align_t* a) {
+  const plsvo_align_in* in = a->in;
+  patch_t patch; patch_init(&patch, a->ref, a->level);
+  const float scale = 1.0f / (1 << a->level);
+  const double focal_length = fabs(in->cam.fx);
+  size_t cache_idx = 0;
+  for (int s = 0; s < in->n_seg; ++s) {
+    a->patch_offset[s] = cache_idx;
+    if (!a->seg_alive[s]) continue;
+    const double* spx = &in->seg_spx[2 * s]; const double* epx = &in->seg_epx[2 * s];
+    /* (spx*scale).cast<int>() truncates toward zero */
+    if (!cam_is_in_frame(&in->cam, (int)(spx[0] * scale), (int)(spx[1] * scale), P_HALF + 1, a->level) ||
+        !cam_is_in_frame(&in->cam, (int)(epx[0] * scale), (int)(epx[1] * scale), P_HALF + 1, a->level))
+      continue;
+    a->seg_cache.visible[s] = 1;
+    double inc2d[2];
+    size_t N_samples = plsvo_oracle_setup_sampling(spx, epx, in->seg_len[s], P_SIZE, inc2d);
+    N_samples = 1 + (N_samples - 1) / (1 << a->level);
+    inc2d[0] = inc2d[0] * scale / (double)(N_samples - 1);
+    inc2d[1] = inc2d[1] * scale / (double)(N_samples - 1);
+    double px_ref[2] = { spx[0] * scale, spx[1] * scale };
+    const double* p_ref = &in->seg_p_ref[3 * s]; const double* q_ref = &in->seg_q_ref[3 * s];
+    double inc3d[3], xyz_ref[3];
+    for (int k = 0; k < 3; ++k) { inc3d[k] = (q_ref[k] - p_ref[k]) / (double)(N_samples - 1); xyz_ref[k] = p_ref[k]; }
+    for (size_t sample = 0; sample < N_samples; ++sample) {
+      patch_set_position(&patch, px_ref[0], px_ref[1]);
+      patch_interp_weights(&patch);
+      double frame_jac[12];
+      plsvo_oracle_jacobian_xyz2uv(xyz_ref, frame_jac);
+      precompute_patch(&patch, frame_jac, focal_length / (1 << a->level),
+                       a->seg_cache.ref_patch + cache_idx, a->seg_cache.jacobian + 6 * cache_idx);
+      cache_idx += P_AREA;
+      px_ref[0] += inc2d[0]; px_ref[1] += inc2d[1];
+      for (int k = 0; k < 3; ++k) xyz_ref[k] += inc3d[k];
+    }
+  }
+}
+
+/* computeGaussNewtonParamsPoints  :380-502  (linearize_system=true, compute_weight_scale=false, use_weights_=true) */
+static void compute_points(align_t* a, const se3_t* T, double H[36], double Jres[6], float* chi2) {
+  const plsvo_align_in* in = a->in;
+  patch_t patch; patch_init(&patch, a->cur, a->level);
+  const float scale = 1.0f / (1 << a->level);
+  *chi2 = 0.0;
+  memset(H, 0, 36 * sizeof(double)); memset(Jres, 0, 6 * sizeof(double));
+  for (int i = 0; i < in->n_pts; ++i) {
+    if (!a->pt_cache.visible[i]) continue;
+    double xyz_cur[3], uv[2];
+    se3_act(T, &in->pt_xyz_ref[3 * i], xyz_cur);
+    plsvo_oracle_world2cam(&in->cam, xyz_cur, uv);
+    patch_set_position(&patch, uv[0] * scale, uv[1] * scale);
+    if (!patch_is_in_frame(&patch, P_HALF)) continue;
+    patch_interp_weights(&patch);
+    size_t pixel_counter = 0;
+    const float* cache_ptr = a->pt_cache.ref_patch + (size_t)P_AREA * i;
+    const int stride = patch.stride;
+    for (int y = 0; y < P_SIZE; ++y) {
+      const uint8_t* img_ptr = patch_row(&patch, y);
+      for (int x = 0; x < P_SIZE; ++x, ++img_ptr, ++cache_ptr, ++pixel_counter) {
+        const float intensity_cur = patch.wTL * img_ptr[0] + patch.wTR * img_ptr[1] + patch.wBL * img_ptr[stride] + patch.wBR * img_ptr[stride + 1];
+        const float res = intensity_cur - (*cache_ptr);
+        float weight = 1.0;
+        weight = 1.0 / (1.0 + fabsf(res)); /* :479 (the scale_pt branch :470-475 is unreachable) */
+        *chi2 += res * res * weight;
+        a->n_meas++;
+        const double* J = a->pt_cache.jacobian + 6 * ((size_t)i * P_AREA + pixel_counter);
+        for (int r = 0; r < 6; ++r) {
+          for (int c = 0; c < 6; ++c) H[r * 6 + c] += J[r] * J[c] * weight;
+          Jres[r] -= J[r] * res * weight;
+        }
+      }
+    }
+  }
+}
+
+/* computeGaussNewtonParamsSegments  :504-695 */
+static void compute_segments(align_t* a, const se3_t* T, double H[36], double Jres[6], float* chi2) {
+  const plsvo_align_in* in = a->in;
+  patch_t patch; patch_init(&patch, a->cur, a->level);
+  const float scale = 1.0f / (1 << a->level);
+  *chi2 = 0.0;
+  memset(H, 0, 36 * sizeof(double)); memset(Jres, 0, 6 * sizeof(double));
+  float* ls_res = (float*)malloc(sizeof(float) * (a->seg_cache.n * P_AREA + P_AREA));
+  for (int s = 0; s < in->n_seg; ++s) {
+    if (!a->seg_alive[s]) continue;
+    if (!a->seg_cache.visible[s]) continue;
+    size_t cache_idx = a->patch_offset[s];
+    double inc2d[2];
+    size_t N_samples = plsvo_oracle_setup_sampling(&in->seg_spx[2 * s], &in->seg_epx[2 * s], in->seg_len[s], P_SIZE, inc2d);
+    N_samples = 1 + (N_samples - 1) / (1 << a->level);
+    const double* p_ref = &in->seg_p_ref[3 * s]; const double* q_ref = &in->seg_q_ref[3 * s];
+    double inc3d[3], xyz_ref[3];
+    for (int k = 0; k < 3; ++k) { inc3d[k] = (q_ref[k] - p_ref[k]) / (double)(N_samples - 1); xyz_ref[k] = p_ref[k]; }
+    double H_[36], Jres_[6];
+    memset(H_, 0, sizeof(H_)); memset(Jres_, 0, sizeof(Jres_));
+    size_t n_res = 0;
+    int good_line = 1;
+    for (size_t sample = 0; sample < N_samples; ++sample) {
+      double xyz_cur[3], uv[2];
+      se3_act(T, xyz_ref, xyz_cur);
+      plsvo_oracle_world2cam(&in->cam, xyz_cur, uv);
+      patch_set_position(&patch, uv[0] * scale, uv[1] * scale);
+      if (!patch_is_in_frame(&patch, P_HALF)) { good_line = 0; break; } /* :588-594 */
+      patch_interp_weights(&patch);
+      const float* cache_ptr = a->seg_cache.ref_patch + cache_idx;
+      const int stride = patch.stride;
+      for (int y = 0; y < P_SIZE; ++y) {
+        const uint8_t* img_ptr = patch_row(&patch, y);
+        for (int x = 0; x < P_SIZE; ++x, ++img_ptr, ++cache_ptr, ++cache_idx) {
+          const float intensity_cur = patch.wTL * img_ptr[0] + patch.wTR * img_ptr[1] + patch.wBL * img_ptr[stride] + patch.wBR * img_ptr[stride + 1];
+          const float res = intensity_cur - (*cache_ptr);
+          ls_res[n_res++] = res;
+          const double* J = a->seg_cache.jacobian + 6 * cache_idx;
+          for (int r = 0; r < 6; ++r) {
+            for (int c = 0; c < 6; ++c) H_[r * 6 + c] += J[r] * J[c];
+            Jres_[r] -= J[r] * res;
+          }
+        }
+      }
+      for (int k = 0; k < 3; ++k) xyz_ref[k] += inc3d[k];
+    }
+    float res_ = 0.0;
+    for (size_t k = 0; k < n_res; ++k) res_ += fabsf(ls_res[k]);
+    res_ = res_ / (double)N_samples;
+    if (good_line && res_ < 200.0) {
+      float weight = 1.0;
+      weight = 1.0 / (1.0 + res_); /* :675 */
+      for (int k = 0; k < 36; ++k) H[k] += H_[k] * weight / res_;
+      for (int k = 0; k < 6; ++k) Jres[k] += Jres_[k] * weight;
+      *chi2 += res_ * res_ * weight;
+      a->n_meas++;
+    } else {
+      a->seg_alive[s] = 0; /* it->feat3D = NULL  :687-688 */
+    }
+  }
+  free(ls_res);
+}
+
+/* computeResiduals  :112-193 */
+static double compute_residuals(align_t* a, const se3_t* T) {
+  if (!a->have_ref_patch_cache) { /* precomputeReferencePatches :104-110 */
+    precompute_points(a);
+    precompute_segments(a);
+    a->have_ref_patch_cache = 1;
+  }
+  a->use_weights = 1; /* :130-132 */
+  double pt_H[36], pt_Jres[6], seg_H[36], seg_Jres[6];
+  float pt_chi2 = 0.0, seg_chi2 = 0.0;
+  compute_points(a, T, pt_H, pt_Jres, &pt_chi2);
+  compute_segments(a, T, seg_H, seg_Jres, &seg_chi2);
+  for (int k = 0; k < 36; ++k) a->H[k] = pt_H[k] + seg_H[k];
+  for (int k = 0; k < 6; ++k) a->Jres[k] = pt_Jres[k] + seg_Jres[k];
+  float chi2 = pt_chi2 + seg_chi2;
+  if (a->iter == 0) { a->scale_ = 1.0; a->scale_ls = 1.0; a->scale_pt = 1.0; } /* :186-190, never read */
+  return chi2 / a->n_meas; /* float / size_t -> float division */
+}
+
+static void log_iter(plsvo_align_iterlog* log, int max_log, int* n_log, const align_t* a, int accepted,
+                     double new_chi2, const se3_t* model) {
+  if (!log || *n_log >= max_log) { if (n_log) ++*n_log; return; }
+  plsvo_align_iterlog* r = &log[*n_log];
+  r->level = a->level; r->iter = a->iter; r->accepted = accepted; r->stop = a->stop;
+  r->n_meas = a->n_meas; r->new_chi2 = new_chi2;
+  memcpy(r->H, a->H, sizeof(r->H)); memcpy(r->Jres, a->Jres, sizeof(r->Jres)); memcpy(r->x, a->x, sizeof(r->x));
+  se3_store(model, r->T_after);
+  ++*n_log;
+}
+
+/* [ext] vk::NLLSSolver<6,SE3>::optimize -> optimizeGaussNewton, with SparseImgAlign::solve :697-703
+ * and ::update :705-710 */
+static void optimize_gauss_newton(align_t* a, se3_t* model, int* iters_out, plsvo_align_iterlog* log, int max_log, int* n_log) {
+  if (a->use_weights) compute_residuals(a, model); /* weight-scale pass; result-idempotent here */
+  se3_t old_model = *model;
+  int iters = 0;
+  for (a->iter = 0; a->iter < a->n_iter; ++a->iter) {
+    memset(a->H, 0, sizeof(a->H)); memset(a->Jres, 0, sizeof(a->Jres));
+    a->n_meas = 0;
+    const double new_chi2 = compute_residuals(a, model);
+    ++iters;
+    plsvo_oracle_ldlt_solve6(a->H, a->Jres, a->x); /* solve() */
+    if (isnan(a->x[0])) a->stop = 1;
+    if ((a->iter > 0 && new_chi2 > a->chi2) || a->stop) {
+      *model = old_model; /* rollback */
+      log_iter(log, max_log, n_log, a, 0, new_chi2, model);
+      break;
+    }
+    double mx[6]; for (int k = 0; k < 6; ++k) mx[k] = -a->x[k];
+    const se3_t ex = se3_exp(mx);
+    const se3_t new_model = se3_mul(model, &ex); /* update(): T_old * exp(-x) */
+    old_model = *model;
+    *model = new_model;
+    a->chi2 = new_chi2;
+    log_iter(log, max_log, n_log, a, 1, new_chi2, model);
+    if (norm_max6(a->x) <= a->in->eps) break;
+  }
+  *iters_out = iters;
+}
+
+int plsvo_oracle_sparse_align(const plsvo_align_in* in, const plsvo_oracle_pyr* ref, const plsvo_oracle_pyr* cur,
+                              plsvo_align_out* out, plsvo_align_iterlog* log, int max_log, int* n_log) {
+  if (!in || !ref || !cur || !out) return PLSVO_E_INVALID;
+  if (in->max_level >= ref->n_levels || in->max_level >= cur->n_levels || in->min_level < 0 || in->max_level >= PLSVO_MAX_LEVELS)
+    return PLSVO_E_INVALID;
+  int dummy_n = 0; if (!n_log) n_log = &dummy_n; *n_log = 0;
+  align_t a; memset(&a, 0, sizeof(a));
+  a.in = in; a.ref = ref; a.cur = cur;
+  /* reset()  [ext] */
+  a.chi2 = 1e10; a.n_meas = 0; a.n_iter = in->n_iter; a.iter = 0; a.stop = 0; a.use_weights = 0;
+  uint8_t* alive_out = out->seg_alive_out;
+  memset(out, 0, sizeof(*out)); out->seg_alive_out = alive_out;
+  se3_t T = se3_load(in->T_cur_from_ref);
+  if (in->n_pts == 0 && in->n_seg == 0) { /* :58-62 */
+    se3_store(&T, out->T_cur_from_ref); out->chi2 = a.chi2; return 0;
+  }
+  /* :69-78 cache sizing */
+  float total_length = 0;
+  for (int s = 0; s < in->n_seg; ++s) total_length += in->seg_len[s];
+  const int max_num_seg_samples = (int)ceilf(total_length / P_SIZE);
+  cache_alloc(&a.pt_cache, (size_t)in->n_pts);
+  cache_alloc(&a.seg_cache, (size_t)(max_num_seg_samples > 0 ? max_num_seg_samples : 0));
+  free(a.seg_cache.visible); a.seg_cache.visible = (uint8_t*)calloc(in->n_seg ? in->n_seg : 1, 1);
+  a.patch_offset = (size_t*)calloc(in->n_seg ? in->n_seg : 1, sizeof(size_t));
+  a.seg_alive = (uint8_t*)malloc(in->n_seg ? in->n_seg : 1);
+  for (int s = 0; s < in->n_seg; ++s) a.seg_alive[s] = in->seg_alive_in ? (in->seg_alive_in[s] != 0) : 1;
+
+  for (a.level = in->max_level; a.level >= in->min_level; --a.level) { /* :82-91 */
+    memset(a.pt_cache.jacobian, 0, sizeof(double) * 6 * (a.pt_cache.n ? a.pt_cache.n : 1) * P_AREA);
+    memset(a.seg_cache.jacobian, 0, sizeof(double) * 6 * (a.seg_cache.n ? a.seg_cache.n : 1) * P_AREA);
+    a.have_ref_patch_cache = 0;
+    int iters = 0;
+    optimize_gauss_newton(&a, &T, &iters, log, max_log, n_log);
+    out->iters_per_level[a.level] = iters;
+  }
+  se3_store(&T, out->T_cur_from_ref);
+  out->n_meas = a.n_meas; out->n_tracked = a.n_meas / P_AREA;
+  memcpy(out->H, a.H, sizeof(out->H));
+  out->chi2 = a.chi2; out->status = a.stop ? 1 : 0;
+  if (out->seg_alive_out) memcpy(out->seg_alive_out, a.seg_alive, (size_t)in->n_seg);
+  cache_free(&a.pt_cache); cache_free(&a.seg_cache); free(a.patch_offset); free(a.seg_alive);
+  return 0;
+}
+
+/* ============================================================================================ */
+/* pose_optimizer::optimizeGaussNewton  src/pose_optimizer.cpp:38-260 (9-arg), :262-582 (10-arg)  */
+/* ============================================================================================ */
+
+static void project2d(const double v[3], double out[2]) { out[0] = v[0] / v[2]; out[1] = v[1] / v[2]; } /* [ext] vk::project2d */
+static double norm2(const double e[2]) { return sqrt(e[0] * e[0] + e[1] * e[1]); }
+static double sqnorm2(const double e[2]) { return e[0] * e[0] + e[1] * e[1]; }
+
+typedef struct {
+  const plsvo_poseopt_in* in;
+  uint8_t* pt_keep; uint8_t* seg_keep;
+  se3_t T, T_old; double chi2;
+  double A[36], b[6];
+  double* chi2_vec_init; size_t n_init;
+} popt_t;
+
+/* one pass of the GN loop body :103-195 (identical text at :339-431 and :469-563); returns 1 to continue */
+static int popt_gn_loop(popt_t* p, size_t n_iter, double scale_pt, double scale_ls, int phase, int* iters_out,
+                        plsvo_poseopt_iterlog* log, int max_log, int* n_log) {
+  const plsvo_poseopt_in* in = p->in;
+  int iters = 0;
+  for (size_t iter = 0; iter < n_iter; iter++) {
+    memset(p->b, 0, sizeof(p->b)); memset(p->A, 0, sizeof(p->A));
+    double new_chi2 = 0.0;
+    ++iters;
+    for (int i = 0; i < in->n_pts; ++i) {
+      if (!p->pt_keep[i]) continue;
+      double J[12], xyz_f[3], pf[2], pp[2], e[2];
+      se3_act(&p->T, &in->pt_pos[3 * i], xyz_f);
+      plsvo_oracle_jacobian_xyz2uv(xyz_f, J);
+      project2d(&in->pt_f[3 * i], pf); project2d(xyz_f, pp);
+      e[0] = pf[0] - pp[0]; e[1] = pf[1] - pp[1];
+      const double sqrt_inv_cov = 1.0 / (1 << in->pt_level[i]);
+      e[0] *= sqrt_inv_cov; e[1] *= sqrt_inv_cov;
+      if (iter == 0) p->chi2_vec_init[p->n_init++] = sqnorm2(e);
+      for (int k = 0; k < 12; ++k) J[k] *= sqrt_inv_cov;
+      const double weight = plsvo_oracle_tukey((float)(norm2(e) / scale_pt));
+      for (int r = 0; r < 6; ++r) {
+        for (int c = 0; c < 6; ++c) p->A[r * 6 + c] += (J[r] * J[c] + J[6 + r] * J[6 + c]) * weight;
+        p->b[r] -= (J[r] * e[0] + J[6 + r] * e[1]) * weight;
+      }
+      new_chi2 += sqnorm2(e) * weight;
+    }
+    for (int s = 0; s < in->n_seg; ++s) {
+      if (!p->seg_keep[s]) continue;
+      double J_s[12], J_e[12], J[12], xs[3], xe[3], e[2];
+      se3_act(&p->T, &in->seg_spos[3 * s], xs);
+      se3_act(&p->T, &in->seg_epos[3 * s], xe);
+      plsvo_oracle_jacobian_xyz2uv(xs, J_s);
+      plsvo_oracle_jacobian_xyz2uv(xe, J_e);
+      double sp[2], ep[2];
+      project2d(xs, sp); project2d(xe, ep);
+      const double* line = &in->seg_line[3 * s];
+      float ds = line[0] * sp[0] + line[1] * sp[1] + line[2] * 1.0;
+      float de = line[0] * ep[0] + line[1] * ep[1] + line[2] * 1.0;
+      e[0] = ds; e[1] = de;
+      const double sqrt_inv_cov = 1.0 / (1 << in->seg_level[s]);
+      e[0] *= sqrt_inv_cov; e[1] *= sqrt_inv_cov;
+      if (iter == 0) p->chi2_vec_init[p->n_init++] = sqnorm2(e);
+      const double k_s = sqrt_inv_cov * ds / norm2(e); /* the same factor for both rows; `de` unused (:156-157) */
+      for (int k = 0; k < 12; ++k) { J_s[k] *= k_s; J_e[k] *= k_s; }
+      for (int c = 0; c < 6; ++c) {
+        J[c] = line[0] * J_s[c] + line[1] * J_s[6 + c];
+        J[6 + c] = line[0] * J_e[c] + line[1] * J_e[6 + c];
+      }
+      const double weight = plsvo_oracle_tukey((float)(norm2(e) / scale_ls));
+      for (int r = 0; r < 6; ++r) {
+        for (int c = 0; c < 6; ++c) p->A[r * 6 + c] += (J[r] * J[c] + J[6 + r] * J[6 + c]) * weight;
+        p->b[r] -= (J[r] * e[0] + J[6 + r] * e[1]) * weight;
+      }
+      new_chi2 += sqnorm2(e) * weight;
+    }
+    double dT[6];
+    plsvo_oracle_ldlt_solve6(p->A, p->b, dT);
+    int accepted = 1;
+    if ((iter > 0 && new_chi2 > p->chi2) || isnan(dT[0])) {
+      p->T = p->T_old; /* roll-back */
+      accepted = 0;
+    } else {
+      const se3_t ex = se3_exp(dT);
+      const se3_t T_new = se3_mul(&ex, &p->T); /* SE3::exp(dT) * T */
+      p->T_old = p->T; p->T = T_new; p->chi2 = new_chi2;
+    }
+    if (log && *n_log < max_log) {
+      plsvo_poseopt_iterlog* r = &log[*n_log];
+      r->phase = phase; r->iter = (int)iter; r->accepted = accepted; r->reserved0 = 0; r->new_chi2 = new_chi2;
+      memcpy(r->A, p->A, sizeof(r->A)); memcpy(r->b, p->b, sizeof(r->b)); memcpy(r->dT, dT, sizeof(r->dT));
+      se3_store(&p->T, r->T_after);
+    }
+    ++*n_log;
+    if (!accepted) break;
+    if (norm_max6(dT) <= 0.0000000001 /* EPS, global.h:99 */) break;
+  }
+  *iters_out = iters;
+  return 0;
+}
+
+/* residual used by the scale pass (:61-87) and the cull pass (:205-240) for one segment */
+static void seg_endpoint_dists(const se3_t* T, const double* line, const double* spos, const double* epos, double* es, double* ee) {
+  double xs[3], xe[3], sp[2], ep[2];
+  se3_act(T, spos, xs); se3_act(T, epos, xe);
+  project2d(xs, sp); project2d(xe, ep);
+  *es = line[0] * sp[0] + line[1] * sp[1] + line[2] * 1.0;
+  *ee = line[0] * ep[0] + line[1] * ep[1] + line[2] * 1.0;
+}
+
+int plsvo_oracle_pose_optimize(const plsvo_poseopt_in* in, plsvo_poseopt_out* out, plsvo_poseopt_iterlog* log, int max_log, int* n_log) {
+  if (!in || !out) return PLSVO_E_INVALID;
+  int dummy_n = 0; if (!n_log) n_log = &dummy_n; *n_log = 0;
+  uint8_t* pk = out->pt_keep; uint8_t* sk = out->seg_keep;
+  memset(out, 0, sizeof(*out)); out->pt_keep = pk; out->seg_keep = sk;
+  const int np = in->n_pts, ns = in->n_seg;
+  popt_t p; memset(&p, 0, sizeof(p));
+  p.in = in;
+  p.pt_keep = (uint8_t*)malloc(np ? np : 1); p.seg_keep = (uint8_t*)malloc(ns ? ns : 1);
+  memset(p.pt_keep, 1, np ? np : 1); memset(p.seg_keep, 1, ns ? ns : 1);
+  p.T = se3_load(in->T_f_w); p.T_old = p.T; p.chi2 = 0.0;
+  p.chi2_vec_init = (double*)malloc(sizeof(double) * 2 * (size_t)(np + ns + 1));
+  double* chi2_vec_final = (double*)malloc(sizeof(double) * (size_t)(np + ns + 1));
+  float* errors = (float*)malloc(sizeof(float) * (size_t)(np + ns + 1));
+  float* errors_ls = (float*)malloc(sizeof(float) * (size_t)(ns + 1));
+  size_t n_err = 0, n_err_ls = 0, n_final = 0;
+  int rc = 0;
+
+  /* scale pass :57-95 */
+  for (int i = 0; i < np; ++i) {
+    double pf[2], pp[2], xyz[3], e[2];
+    project2d(&in->pt_f[3 * i], pf);
+    se3_act(&p.T, &in->pt_pos[3 * i], xyz); project2d(xyz, pp);
+    e[0] = pf[0] - pp[0]; e[1] = pf[1] - pp[1];
+    const double s = 1.0 / (1 << in->pt_level[i]);
+    e[0] *= s; e[1] *= s;
+    errors[n_err++] = (float)norm2(e);
+  }
+  /* :70 runs the estimator on the point errors even when there are none (undefined behaviour in the
+   * reference: getMedian asserts non-empty).  Documented deviation: zero points -> scale_pt = 1.0. */
+  double estimated_scale_pt = (n_err > 0) ? (double)plsvo_oracle_mad_scale(errors, n_err) : 1.0;
+  out->num_obs_pt = n_err;
+  for (int s = 0; s < ns; ++s) {
+    double es_d, ee_d;
+    seg_endpoint_dists(&p.T, &in->seg_line[3 * s], &in->seg_spos[3 * s], &in->seg_epos[3 * s], &es_d, &ee_d);
+    float es = es_d, ee = ee_d;
+    const float v = sqrtf(es * es + ee * ee);
+    errors[n_err++] = v; errors_ls[n_err_ls++] = v;
+  }
+  if (n_err == 0) { /* :88-89 early return, nothing else written */
+    out->status = 1; se3_store(&p.T, out->T_f_w);
+    if (out->pt_keep) memset(out->pt_keep, 1, np); if (out->seg_keep) memset(out->seg_keep, 1, ns);
+    goto done;
+  }
+  out->num_obs_ls = n_err_ls;
+  double estimated_scale_ls = 1.f;
+  if (n_err_ls > 0) estimated_scale_ls = plsvo_oracle_mad_scale(errors_ls, n_err_ls);
+  double estimated_scale = estimated_scale_pt;
+  const double scale_pt = estimated_scale_pt, scale_ls = estimated_scale_ls;
+
+  popt_gn_loop(&p, (size_t)in->n_iter, scale_pt, scale_ls, 0, &out->iters, log, max_log, n_log);
+
+  /* covariance :197-199 */
+  {
+    double Af[36];
+    const double f2 = pow(in->fx, 2);
+    for (int k = 0; k < 36; ++k) Af[k] = p.A[k] * f2;
+    plsvo_oracle_inv6(Af, out->cov);
+  }
+  /* cull :201-242 */
+  const double reproj_thresh_scaled_pt = in->reproj_thresh / in->fx;
+  const double reproj_thresh_scaled_ls = reproj_thresh_scaled_pt * estimated_scale_ls / estimated_scale_pt;
+  size_t n_deleted_refs_pt = 0, n_deleted_refs_ls = 0;
+  for (int i = 0; i < np; ++i) {
+    double pf[2], pp[2], xyz[3], e[2];
+    project2d(&in->pt_f[3 * i], pf);
+    se3_act(&p.T, &in->pt_pos[3 * i], xyz); project2d(xyz, pp);
+    e[0] = pf[0] - pp[0]; e[1] = pf[1] - pp[1];
+    const double s = 1.0 / (1 << in->pt_level[i]);
+    e[0] *= s; e[1] *= s;
+    chi2_vec_final[n_final++] = sqnorm2(e);
+    if (norm2(e) > reproj_thresh_scaled_pt) { p.pt_keep[i] = 0; ++n_deleted_refs_pt; }
+  }
+  for (int s = 0; s < ns; ++s) {
+    double e[2];
+    seg_endpoint_dists(&p.T, &in->seg_line[3 * s], &in->seg_spos[3 * s], &in->seg_epos[3 * s], &e[0], &e[1]);
+    const double c = 1.0 / (1 << in->seg_level[s]);
+    e[0] *= c; e[1] *= c;
+    chi2_vec_final[n_final++] = sqnorm2(e);
+    if (norm2(e) > reproj_thresh_scaled_ls) { p.seg_keep[s] = 0; ++n_deleted_refs_ls; }
+  }
+  /* refinement with inliers :469-563 (10-argument overload only); chi2 and T_old carry over */
+  if (in->n_iter_ref >= 0)
+    popt_gn_loop(&p, (size_t)in->n_iter_ref, scale_pt, scale_ls, 1, &out->iters_ref, log, max_log, n_log);
+
+  out->error_init = 0.0; out->error_final = 0.0;
+  if (p.n_init > 0) out->error_init = sqrt(plsvo_oracle_median_f64(p.chi2_vec_init, p.n_init)) * in->fx;
+  if (n_final > 0) out->error_final = sqrt(plsvo_oracle_median_f64(chi2_vec_final, n_final)) * in->fx;
+  estimated_scale *= in->fx;
+  out->estimated_scale = estimated_scale;
+  out->num_obs_pt -= n_deleted_refs_pt;
+  out->num_obs_ls -= n_deleted_refs_ls;
+  se3_store(&p.T, out->T_f_w);
+  if (out->pt_keep) memcpy(out->pt_keep, p.pt_keep, np);
+  if (out->seg_keep) memcpy(out->seg_keep, p.seg_keep, ns);
+done:
+  free(p.pt_keep); free(p.seg_keep); free(p.chi2_vec_init); free(chi2_vec_final); free(errors); free(errors_ls);
+  return rc;
+}

@@ -1,0 +1,183 @@
+"""ctypes mirror of include/plsvo_hip.h (struct layouts + helpers to fill them from numpy arrays).
+
+Used by the product binding (capi.py, loads libplsvo_hip.so) and, because the oracle shares the struct
+layouts, by the test-only oracle binding (oracle/binding.py).  Nothing here computes anything.
+"""
+import ctypes as C
+
+import numpy as np
+
+MAX_LEVELS = 8
+PATCH_AREA = 16
+
+c_double_p = C.POINTER(C.c_double)
+c_u8_p = C.POINTER(C.c_uint8)
+c_i32_p = C.POINTER(C.c_int32)
+
+# error codes (include/plsvo_hip.h)
+OK, E_INVALID, E_NODEVICE, E_HIP, E_CAPACITY, E_STATE, E_RCCL = 0, -1, -2, -3, -4, -5, -6
+
+# kernel families for plsvo_hip_kernel_time
+K_ALIGN_INIT, K_ALIGN_LEVEL, K_POSEOPT, K_HALFSAMPLE, K_COUNT = 0, 1, 2, 3, 4
+
+
+class Pinhole(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class AlignIn(C.Structure):
+    _fields_ = [("ref_slot", C.c_int32), ("cur_slot", C.c_int32), ("cam", Pinhole),
+                ("max_level", C.c_int32), ("min_level", C.c_int32), ("n_iter", C.c_int32),
+                ("reserved0", C.c_int32), ("eps", C.c_double), ("T_cur_from_ref", C.c_double * 7),
+                ("n_pts", C.c_int32), ("n_seg", C.c_int32),
+                ("pt_px", c_double_p), ("pt_xyz_ref", c_double_p),
+                ("seg_spx", c_double_p), ("seg_epx", c_double_p), ("seg_len", c_double_p),
+                ("seg_p_ref", c_double_p), ("seg_q_ref", c_double_p), ("seg_alive_in", c_u8_p)]
+
+
+class AlignOut(C.Structure):
+    _fields_ = [("T_cur_from_ref", C.c_double * 7), ("n_meas", C.c_uint64), ("n_tracked", C.c_uint64),
+                ("H", C.c_double * 36), ("chi2", C.c_double), ("seg_alive_out", c_u8_p),
+                ("iters_per_level", C.c_int32 * MAX_LEVELS), ("status", C.c_int32), ("reserved0", C.c_int32)]
+
+
+class AlignIterLog(C.Structure):
+    _fields_ = [("level", C.c_int32), ("iter", C.c_int32), ("accepted", C.c_int32), ("stop", C.c_int32),
+                ("n_meas", C.c_uint64), ("new_chi2", C.c_double), ("H", C.c_double * 36),
+                ("Jres", C.c_double * 6), ("x", C.c_double * 6), ("T_after", C.c_double * 7)]
+
+
+class PoseOptIn(C.Structure):
+    _fields_ = [("T_f_w", C.c_double * 7), ("fx", C.c_double), ("reproj_thresh", C.c_double),
+                ("n_iter", C.c_int32), ("n_iter_ref", C.c_int32), ("n_pts", C.c_int32), ("n_seg", C.c_int32),
+                ("pt_f", c_double_p), ("pt_pos", c_double_p), ("pt_level", c_i32_p),
+                ("seg_line", c_double_p), ("seg_spos", c_double_p), ("seg_epos", c_double_p),
+                ("seg_level", c_i32_p)]
+
+
+class PoseOptOut(C.Structure):
+    _fields_ = [("T_f_w", C.c_double * 7), ("cov", C.c_double * 36), ("estimated_scale", C.c_double),
+                ("error_init", C.c_double), ("error_final", C.c_double), ("num_obs_pt", C.c_uint64),
+                ("num_obs_ls", C.c_uint64), ("pt_keep", c_u8_p), ("seg_keep", c_u8_p), ("iters", C.c_int32),
+                ("iters_ref", C.c_int32), ("status", C.c_int32), ("reserved0", C.c_int32)]
+
+
+class PoseOptIterLog(C.Structure):
+    _fields_ = [("phase", C.c_int32), ("iter", C.c_int32), ("accepted", C.c_int32), ("reserved0", C.c_int32),
+                ("new_chi2", C.c_double), ("A", C.c_double * 36), ("b", C.c_double * 6), ("dT", C.c_double * 6),
+                ("T_after", C.c_double * 7)]
+
+
+def _f64(a, n=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if n is not None and a.size != n:
+        raise ValueError(f"expected {n} doubles, got {a.size}")
+    return a
+
+
+def _ptr(a, typ):
+    return a.ctypes.data_as(typ) if a.size else C.cast(None, typ)
+
+
+class AlignJob:
+    """Owns the numpy buffers behind one plsvo_align_in (keeps them alive) and exposes .c (the struct)."""
+
+    def __init__(self, cam, max_level, min_level, n_iter, eps, T_cur_from_ref, pt_px, pt_xyz_ref,
+                 seg_spx, seg_epx, seg_len, seg_p_ref, seg_q_ref, seg_alive_in=None, ref_slot=0, cur_slot=1):
+        self.pt_px = _f64(pt_px).reshape(-1, 2)
+        n_pts = self.pt_px.shape[0]
+        self.pt_xyz_ref = _f64(pt_xyz_ref, 3 * n_pts).reshape(-1, 3)
+        self.seg_spx = _f64(seg_spx).reshape(-1, 2)
+        n_seg = self.seg_spx.shape[0]
+        self.seg_epx = _f64(seg_epx, 2 * n_seg).reshape(-1, 2)
+        self.seg_len = _f64(seg_len, n_seg).reshape(-1)
+        self.seg_p_ref = _f64(seg_p_ref, 3 * n_seg).reshape(-1, 3)
+        self.seg_q_ref = _f64(seg_q_ref, 3 * n_seg).reshape(-1, 3)
+        self.seg_alive_in = None if seg_alive_in is None else np.ascontiguousarray(seg_alive_in, dtype=np.uint8)
+        c = AlignIn()
+        c.ref_slot, c.cur_slot = ref_slot, cur_slot
+        c.cam = cam if isinstance(cam, Pinhole) else Pinhole(*cam)
+        c.max_level, c.min_level, c.n_iter, c.eps = max_level, min_level, n_iter, eps
+        c.T_cur_from_ref[:] = list(_f64(T_cur_from_ref, 7))
+        c.n_pts, c.n_seg = n_pts, n_seg
+        c.pt_px = _ptr(self.pt_px, c_double_p)
+        c.pt_xyz_ref = _ptr(self.pt_xyz_ref, c_double_p)
+        c.seg_spx = _ptr(self.seg_spx, c_double_p)
+        c.seg_epx = _ptr(self.seg_epx, c_double_p)
+        c.seg_len = _ptr(self.seg_len, c_double_p)
+        c.seg_p_ref = _ptr(self.seg_p_ref, c_double_p)
+        c.seg_q_ref = _ptr(self.seg_q_ref, c_double_p)
+        c.seg_alive_in = (C.cast(None, c_u8_p) if self.seg_alive_in is None
+                          else self.seg_alive_in.ctypes.data_as(c_u8_p))
+        self.c = c
+        self.n_pts, self.n_seg = n_pts, n_seg
+
+
+class PoseOptJob:
+    def __init__(self, T_f_w, fx, reproj_thresh, n_iter, pt_f, pt_pos, pt_level, seg_line, seg_spos, seg_epos,
+                 seg_level, n_iter_ref=-1):
+        self.pt_f = _f64(pt_f).reshape(-1, 3)
+        n_pts = self.pt_f.shape[0]
+        self.pt_pos = _f64(pt_pos, 3 * n_pts).reshape(-1, 3)
+        self.pt_level = np.ascontiguousarray(pt_level, dtype=np.int32).reshape(-1)
+        self.seg_line = _f64(seg_line).reshape(-1, 3)
+        n_seg = self.seg_line.shape[0]
+        self.seg_spos = _f64(seg_spos, 3 * n_seg).reshape(-1, 3)
+        self.seg_epos = _f64(seg_epos, 3 * n_seg).reshape(-1, 3)
+        self.seg_level = np.ascontiguousarray(seg_level, dtype=np.int32).reshape(-1)
+        c = PoseOptIn()
+        c.T_f_w[:] = list(_f64(T_f_w, 7))
+        c.fx, c.reproj_thresh, c.n_iter, c.n_iter_ref = fx, reproj_thresh, n_iter, n_iter_ref
+        c.n_pts, c.n_seg = n_pts, n_seg
+        c.pt_f = _ptr(self.pt_f, c_double_p)
+        c.pt_pos = _ptr(self.pt_pos, c_double_p)
+        c.pt_level = _ptr(self.pt_level, c_i32_p)
+        c.seg_line = _ptr(self.seg_line, c_double_p)
+        c.seg_spos = _ptr(self.seg_spos, c_double_p)
+        c.seg_epos = _ptr(self.seg_epos, c_double_p)
+        c.seg_level = _ptr(self.seg_level, c_i32_p)
+        self.c = c
+        self.n_pts, self.n_seg = n_pts, n_seg
+
+
+class AlignResult:
+    """Plain-python view of a plsvo_align_out."""
+
+    def __init__(self, out, seg_alive):
+        self.T = np.array(out.T_cur_from_ref[:], dtype=np.float64)
+        self.n_meas = int(out.n_meas)
+        self.n_tracked = int(out.n_tracked)
+        self.H = np.array(out.H[:], dtype=np.float64).reshape(6, 6)
+        self.chi2 = float(out.chi2)
+        self.iters_per_level = list(out.iters_per_level[:])
+        self.status = int(out.status)
+        self.seg_alive = seg_alive
+
+
+class PoseOptResult:
+    def __init__(self, out, pt_keep, seg_keep):
+        self.T = np.array(out.T_f_w[:], dtype=np.float64)
+        self.cov = np.array(out.cov[:], dtype=np.float64).reshape(6, 6)
+        self.estimated_scale = float(out.estimated_scale)
+        self.error_init = float(out.error_init)
+        self.error_final = float(out.error_final)
+        self.num_obs_pt = int(out.num_obs_pt)
+        self.num_obs_ls = int(out.num_obs_ls)
+        self.iters = int(out.iters)
+        self.iters_ref = int(out.iters_ref)
+        self.status = int(out.status)
+        self.pt_keep = pt_keep
+        self.seg_keep = seg_keep
+
+
+def align_log_to_dicts(arr, n):
+    return [dict(level=r.level, iter=r.iter, accepted=r.accepted, stop=r.stop, n_meas=int(r.n_meas),
+                 new_chi2=float(r.new_chi2), H=np.array(r.H[:]).reshape(6, 6), Jres=np.array(r.Jres[:]),
+                 x=np.array(r.x[:]), T_after=np.array(r.T_after[:])) for r in arr[:n]]
+
+
+def poseopt_log_to_dicts(arr, n):
+    return [dict(phase=r.phase, iter=r.iter, accepted=r.accepted, new_chi2=float(r.new_chi2),
+                 A=np.array(r.A[:]).reshape(6, 6), b=np.array(r.b[:]), dT=np.array(r.dT[:]),
+                 T_after=np.array(r.T_after[:])) for r in arr[:n]]

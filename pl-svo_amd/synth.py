@@ -1,0 +1,306 @@
+"""Deterministic synthetic inputs for the hot path: textured-plane frame pairs with
+point and line-segment features for sparse image alignment, and noisy/outlier-contaminated
+point/line observations for pose optimisation.
+
+Per-stream parameters come from numpy's default_rng(seed) on the host (seed = 1234 + stream index by
+convention); the images are rendered analytically (ray-plane intersection + sum-of-sinusoids texture)
+with torch on whatever device is asked for, so a whole batch of streams can be rendered in HBM.
+This is input generation only -- no part of the hot path lives here.
+"""
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+# ------------------------------------------------------------------------------------------------
+# tiny SE3 helpers (numpy, float64).  Pose = [qx qy qz qw tx ty tz], tangent = (upsilon, omega)
+# ------------------------------------------------------------------------------------------------
+
+
+def quat_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by + ay * bw + az * bx - ax * bz,
+                     aw * bz + az * bw + ax * by - ay * bx,
+                     aw * bw - ax * bx - ay * by - az * bz])
+
+
+def quat_to_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def se3_exp(u):
+    u = np.asarray(u, dtype=np.float64)
+    ups, om = u[:3], u[3:]
+    th = np.linalg.norm(om)
+    if th < 1e-10:
+        q = np.array([0.5 * om[0], 0.5 * om[1], 0.5 * om[2], 1.0])
+        V = np.eye(3)
+    else:
+        q = np.concatenate([math.sin(0.5 * th) / th * om, [math.cos(0.5 * th)]])
+        O = np.array([[0, -om[2], om[1]], [om[2], 0, -om[0]], [-om[1], om[0], 0]])
+        V = np.eye(3) + (1 - math.cos(th)) / th ** 2 * O + (th - math.sin(th)) / th ** 3 * (O @ O)
+    q = q / np.linalg.norm(q)
+    return np.concatenate([q, V @ ups])
+
+
+def se3_mul(A, B):
+    q = quat_mul(A[:4], B[:4])
+    q = q / np.linalg.norm(q)
+    return np.concatenate([q, A[4:] + quat_to_R(A[:4]) @ B[4:]])
+
+
+def se3_inv(A):
+    q = np.array([-A[0], -A[1], -A[2], A[3]])
+    return np.concatenate([q, -(quat_to_R(q) @ A[4:])])
+
+
+def se3_act(T, p):
+    return (quat_to_R(T[:4]) @ np.asarray(p).T).T + T[4:]
+
+
+def se3_log_angle_dist(A, B):
+    """(rotation angle [rad], translation distance) between two poses."""
+    D = se3_mul(se3_inv(A), B)
+    ang = 2.0 * math.atan2(np.linalg.norm(D[:3]), abs(D[3]))
+    return ang, float(np.linalg.norm(D[4:]))
+
+
+# ------------------------------------------------------------------------------------------------
+# alignment streams
+# ------------------------------------------------------------------------------------------------
+
+N_SIN_MAIN = 24
+N_SIN_FINE = 24
+
+
+@dataclass
+class AlignStream:
+    seed: int
+    W: int
+    H: int
+    cam: tuple                 # (fx, fy, cx, cy, W, H)
+    plane_n: np.ndarray        # plane normal in the ref camera frame
+    plane_d: float             # n . X = d
+    e1: np.ndarray
+    e2: np.ndarray
+    tex: np.ndarray            # [K,4] = kx, ky, phase, amplitude (plane metric units)
+    tex_norm: float
+    T_true: np.ndarray         # cur_from_ref
+    T_ref_w: np.ndarray        # ref frame's T_f_w
+    T_cur_w_init: np.ndarray   # cur frame's initial T_f_w (= ref's, frame_handler_mono.cpp:266)
+    T_init: np.ndarray         # cur_init * ref^-1 (identity up to rounding)
+    # reference-frame features, as the reference's Frame/Feature/Point/LineSeg objects would hold them
+    pt_px: np.ndarray = field(default=None)
+    pt_f: np.ndarray = field(default=None)
+    pt_pos_w: np.ndarray = field(default=None)
+    seg_spx: np.ndarray = field(default=None)
+    seg_epx: np.ndarray = field(default=None)
+    seg_sf: np.ndarray = field(default=None)
+    seg_ef: np.ndarray = field(default=None)
+    seg_spos_w: np.ndarray = field(default=None)
+    seg_epos_w: np.ndarray = field(default=None)
+    # flattened for the C ABI (include/plsvo_hip.h, plsvo_align_in)
+    ref_pos: np.ndarray = field(default=None)
+    pt_xyz_ref: np.ndarray = field(default=None)
+    seg_len: np.ndarray = field(default=None)
+    seg_p_ref: np.ndarray = field(default=None)
+    seg_q_ref: np.ndarray = field(default=None)
+
+
+def _bearing(cam, px):
+    fx, fy, cx, cy = cam[:4]
+    r = np.stack([(px[:, 0] - cx) / fx, (px[:, 1] - cy) / fy, np.ones(len(px))], axis=1)
+    return r / np.linalg.norm(r, axis=1, keepdims=True), r
+
+
+def _on_plane(n, d, rays):
+    """intersection of rays (through the origin) with n.X = d"""
+    s = d / (rays @ n)
+    return rays * s[:, None]
+
+
+def make_align_stream(seed, W=640, H=480, n_pts=200, n_seg=80, max_level=3, motion_scale=0.5,
+                      tex_lam=(16.0, 320.0)):
+    rng = np.random.default_rng(seed)
+    fx = fy = 0.65 * W
+    cam = (fx, fy, W / 2.0, H / 2.0, W, H)
+    d0 = rng.uniform(2.0, 6.0)
+    tilt = math.radians(rng.uniform(0.0, 15.0))
+    az = rng.uniform(0.0, 2 * math.pi)
+    n = np.array([math.sin(tilt) * math.cos(az), math.sin(tilt) * math.sin(az), math.cos(tilt)])
+    d = n[2] * d0
+    e1 = np.array([1.0, 0.0, 0.0]) - n * n[0]
+    e1 /= np.linalg.norm(e1)
+    e2 = np.cross(n, e1)
+    # texture: sinusoids with wavelength given in level-0 pixels at depth d0
+    m_per_px = d0 / fx
+    # 1/f-like amplitude spectrum (amplitude ~ wavelength), like natural images: smooth at the coarse
+    # pyramid levels, detailed at the fine ones
+    lam_px = np.concatenate([np.exp(rng.uniform(math.log(tex_lam[0]), math.log(tex_lam[1]), N_SIN_MAIN)),
+                             np.exp(rng.uniform(math.log(4.0), math.log(tex_lam[0]), N_SIN_FINE))])
+    lam = lam_px * m_per_px
+    ang = rng.uniform(0.0, 2 * math.pi, lam.size)
+    amp = rng.uniform(0.5, 1.0, lam.size) * lam_px / tex_lam[1]
+    tex = np.stack([2 * math.pi / lam * np.cos(ang), 2 * math.pi / lam * np.sin(ang),
+                    rng.uniform(0.0, 2 * math.pi, lam.size), amp], axis=1)
+    tex_norm = math.sqrt(0.5 * float(np.sum(amp ** 2)))
+    xi = np.concatenate([rng.uniform(-0.03, 0.03, 3) * d0, rng.uniform(-0.01, 0.01, 3)]) * motion_scale
+    T_true = se3_exp(xi)
+    T_ref_w = se3_exp(np.concatenate([rng.uniform(-1.0, 1.0, 3), rng.uniform(-0.3, 0.3, 3)]))
+    T_w_ref = se3_inv(T_ref_w)
+    T_cur_w_init = T_ref_w.copy()
+    T_init = se3_mul(T_cur_w_init, T_w_ref)
+
+    margin = 4.0 * (1 << max_level)
+    pt_px = np.stack([rng.uniform(margin, W - margin, n_pts), rng.uniform(margin, H - margin, n_pts)], axis=1)
+    lmin, lmax = 0.15 * W * H / (W + H), 0.35 * W
+    spx = np.zeros((n_seg, 2))
+    epx = np.zeros((n_seg, 2))
+    k = 0
+    while k < n_seg:
+        s = np.array([rng.uniform(margin, W - margin), rng.uniform(margin, H - margin)])
+        L = rng.uniform(lmin, lmax)
+        a = rng.uniform(0.0, math.pi)
+        e = s + L * np.array([math.cos(a), math.sin(a)])
+        if margin <= e[0] < W - margin and margin <= e[1] < H - margin:
+            spx[k], epx[k] = s, e
+            k += 1
+
+    st = AlignStream(seed=seed, W=W, H=H, cam=cam, plane_n=n, plane_d=d, e1=e1, e2=e2, tex=tex, tex_norm=tex_norm,
+                     T_true=T_true, T_ref_w=T_ref_w, T_cur_w_init=T_cur_w_init, T_init=T_init)
+    ref_pos = T_w_ref[4:].copy()  # Frame::pos() = T_f_w^-1 translation (frame.h:131)
+    st.ref_pos = ref_pos
+
+    def lift(px):
+        f, rays = _bearing(cam, px)
+        X = _on_plane(n, d, rays)
+        pos_w = se3_act(T_w_ref, X)
+        depth = np.linalg.norm(pos_w - ref_pos, axis=1)
+        return f, pos_w, f * depth[:, None]
+
+    st.pt_px = pt_px
+    st.pt_f, st.pt_pos_w, st.pt_xyz_ref = lift(pt_px) if n_pts else (np.zeros((0, 3)),) * 3
+    st.seg_spx, st.seg_epx = spx, epx
+    if n_seg:
+        st.seg_sf, st.seg_spos_w, st.seg_p_ref = lift(spx)
+        st.seg_ef, st.seg_epos_w, st.seg_q_ref = lift(epx)
+    else:
+        z = np.zeros((0, 3))
+        st.seg_sf = st.seg_spos_w = st.seg_p_ref = st.seg_ef = st.seg_epos_w = st.seg_q_ref = z
+    st.seg_len = np.linalg.norm(epx - spx, axis=1)
+    return st
+
+
+def render_streams(streams, device="cpu", noise_sigma=2.0, chunk=64):
+    """Render the (ref, cur) level-0 images of a list of AlignStream -> uint8 tensor [B, 2, H, W] on `device`."""
+    B = len(streams)
+    W, H = streams[0].W, streams[0].H
+    dev = torch.device(device)
+    out = torch.empty((B, 2, H, W), dtype=torch.uint8, device=dev)
+    fx, fy, cx, cy = streams[0].cam[:4]
+    u = torch.arange(W, dtype=torch.float64, device=dev)
+    v = torch.arange(H, dtype=torch.float64, device=dev)
+    rays = torch.stack([((u - cx) / fx)[None, :].expand(H, W), ((v - cy) / fy)[:, None].expand(H, W),
+                        torch.ones((H, W), dtype=torch.float64, device=dev)], dim=-1)  # [H,W,3]
+    for c0 in range(0, B, chunk):
+        sub = streams[c0:c0 + chunk]
+        b = len(sub)
+        t64 = lambda a: torch.as_tensor(np.stack(a), dtype=torch.float64, device=dev)
+        n = t64([s.plane_n for s in sub])
+        d = t64([np.array(s.plane_d) for s in sub])
+        e1 = t64([s.e1 for s in sub])
+        e2 = t64([s.e2 for s in sub])
+        tex = t64([s.tex for s in sub])          # [b,K,4]
+        tnorm = t64([np.array(s.tex_norm) for s in sub])
+        gen = torch.Generator(device=dev)
+        for which in (0, 1):
+            if which == 0:
+                o = torch.zeros((b, 3), dtype=torch.float64, device=dev)
+                dirs = rays[None].expand(b, H, W, 3)
+            else:
+                R = t64([quat_to_R(s.T_true[:4]) for s in sub])      # cur_from_ref
+                t = t64([s.T_true[4:] for s in sub])
+                o = -torch.einsum("bji,bj->bi", R, t)                  # -R^T t
+                dirs = torch.einsum("bji,hwj->bhwi", R, rays)          # R^T r
+            nd = torch.einsum("bhwi,bi->bhw", dirs, n)
+            s_ = (d - torch.einsum("bi,bi->b", n, o))[:, None, None] / nd
+            X = o[:, None, None, :] + s_[..., None] * dirs
+            a = torch.einsum("bhwi,bi->bhw", X, e1)
+            bb = torch.einsum("bhwi,bi->bhw", X, e2)
+            acc = torch.zeros_like(a)
+            for k in range(tex.shape[1]):
+                acc += tex[:, k, 3][:, None, None] * torch.sin(tex[:, k, 0][:, None, None] * a +
+                                                               tex[:, k, 1][:, None, None] * bb +
+                                                               tex[:, k, 2][:, None, None])
+            img = 128.0 + 45.0 * acc / tnorm[:, None, None]
+            img = img.clamp(16.0, 240.0)
+            if noise_sigma > 0:
+                gen.manual_seed(int(sub[0].seed) * 2 + which + 977)
+                img = img + noise_sigma * torch.randn(img.shape, dtype=torch.float64, device=dev, generator=gen)
+            out[c0:c0 + b, which] = img.round().clamp(0, 255).to(torch.uint8)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# pose-optimisation frames
+# ------------------------------------------------------------------------------------------------
+
+@dataclass
+class PoseOptFrame:
+    seed: int
+    fx: float
+    T_true: np.ndarray
+    T_init: np.ndarray
+    pt_f: np.ndarray
+    pt_pos: np.ndarray
+    pt_level: np.ndarray
+    pt_outlier: np.ndarray
+    seg_line: np.ndarray
+    seg_spos: np.ndarray
+    seg_epos: np.ndarray
+    seg_level: np.ndarray
+    seg_outlier: np.ndarray
+
+
+def make_poseopt_frame(seed, n_pts=500, n_seg=200, W=640, H=480, noise_px=1.0, outlier_frac=0.10,
+                       outlier_px=20.0, pert_t=0.02, pert_r=0.01):
+    rng = np.random.default_rng(seed + 500000)
+    fx = fy = 0.65 * W
+    cx, cy = W / 2.0, H / 2.0
+    T_true = se3_exp(np.concatenate([rng.uniform(-1.0, 1.0, 3), rng.uniform(-0.3, 0.3, 3)]))   # T_f_w
+    T_w_f = se3_inv(T_true)
+
+    def sample_obs(k):
+        px = np.stack([rng.uniform(8, W - 8, k), rng.uniform(8, H - 8, k)], axis=1)
+        depth = rng.uniform(2.0, 10.0, k)
+        rays = np.stack([(px[:, 0] - cx) / fx, (px[:, 1] - cy) / fy, np.ones(k)], axis=1)
+        X_f = rays * depth[:, None]
+        pos_w = se3_act(T_w_f, X_f)
+        out = rng.uniform(size=k) < outlier_frac
+        noise = rng.normal(0.0, noise_px, (k, 2))
+        dirs = rng.uniform(0, 2 * math.pi, k)
+        noise[out] += outlier_px * np.stack([np.cos(dirs[out]), np.sin(dirs[out])], axis=1)
+        px_obs = px + noise
+        r = np.stack([(px_obs[:, 0] - cx) / fx, (px_obs[:, 1] - cy) / fy, np.ones(k)], axis=1)
+        f = r / np.linalg.norm(r, axis=1, keepdims=True)
+        return f, pos_w, out
+
+    pt_f, pt_pos, pt_out = sample_obs(n_pts)
+    sf, spos, so = sample_obs(n_seg)
+    ef, epos, eo = sample_obs(n_seg)
+    line = np.cross(sf, ef)
+    line = line / np.sqrt(line[:, 0:1] ** 2 + line[:, 1:2] ** 2) if n_seg else np.zeros((0, 3))
+    pert = np.concatenate([rng.normal(0, 1, 3), rng.normal(0, 1, 3)])
+    pert[:3] *= pert_t / max(np.linalg.norm(pert[:3]), 1e-12)
+    pert[3:] *= pert_r / max(np.linalg.norm(pert[3:]), 1e-12)
+    T_init = se3_mul(se3_exp(pert), T_true)
+    return PoseOptFrame(seed=seed, fx=fx, T_true=T_true, T_init=T_init, pt_f=pt_f, pt_pos=pt_pos,
+                        pt_level=rng.integers(0, 3, n_pts).astype(np.int32), pt_outlier=pt_out,
+                        seg_line=line, seg_spos=spos, seg_epos=epos,
+                        seg_level=rng.integers(0, 3, n_seg).astype(np.int32), seg_outlier=(so | eo))
