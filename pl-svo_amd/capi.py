@@ -1,0 +1,277 @@
+"""ctypes binding of the product library libplsvo_hip.so (C ABI: include/plsvo_hip.h).
+
+There is NO CPU fallback here: loading fails loudly if the HIP extension is missing, and Context()
+raises if no gfx950 device can be used.  Nothing in this module imports or calls the CPU oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplsvo_hip.so")
+
+# every symbol include/plsvo_hip.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "plsvo_hip_create", "plsvo_hip_destroy", "plsvo_hip_last_error", "plsvo_hip_stream", "plsvo_hip_synchronize",
+    "plsvo_hip_config_pyramids", "plsvo_hip_upload_pyramid", "plsvo_hip_build_pyramid", "plsvo_hip_build_pyramids_dev",
+    "plsvo_hip_download_level",
+    "plsvo_sparse_align", "plsvo_sparse_align_batch", "plsvo_align_stage", "plsvo_align_run", "plsvo_align_fetch",
+    "plsvo_align_set_trace", "plsvo_align_fetch_trace", "plsvo_align_poses_dev", "plsvo_align_work",
+    "plsvo_pose_optimize", "plsvo_pose_optimize_batch", "plsvo_poseopt_stage", "plsvo_poseopt_run", "plsvo_poseopt_fetch",
+    "plsvo_poseopt_set_trace", "plsvo_poseopt_fetch_trace", "plsvo_poseopt_poses_dev", "plsvo_poseopt_work",
+    "plsvo_gather_poses",
+    "plsvo_hip_set_profiling", "plsvo_hip_kernel_time", "plsvo_hip_reset_profiling",
+    "plsvo_hip_version", "plsvo_hip_device_info",
+]
+
+
+class PlsvoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"plsvo_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libplsvo_hip.so (built in-tree by __graft_entry__.build()).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not found: build it with `make -C pl-svo_amd/csrc` "
+                          f"(or __graft_entry__.build()); plsvo_hip has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    ctxp = C.c_void_p
+    vp = C.c_void_p
+    sig = {
+        "plsvo_hip_create": (C.c_int, [C.c_int, vp, C.POINTER(ctxp)]),
+        "plsvo_hip_destroy": (None, [ctxp]),
+        "plsvo_hip_last_error": (C.c_char_p, [ctxp]),
+        "plsvo_hip_stream": (vp, [ctxp]),
+        "plsvo_hip_synchronize": (C.c_int, [ctxp]),
+        "plsvo_hip_config_pyramids": (C.c_int, [ctxp, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "plsvo_hip_upload_pyramid": (C.c_int, [ctxp, C.c_int, C.c_int, C.POINTER(abi.c_u8_p), abi.c_i32_p, abi.c_i32_p, abi.c_i32_p]),
+        "plsvo_hip_build_pyramid": (C.c_int, [ctxp, C.c_int, abi.c_u8_p, C.c_int, C.c_int]),
+        "plsvo_hip_build_pyramids_dev": (C.c_int, [ctxp, C.c_int, C.c_int, vp, C.c_int, C.c_size_t, C.c_int]),
+        "plsvo_hip_download_level": (C.c_int, [ctxp, C.c_int, C.c_int, abi.c_u8_p]),
+        "plsvo_sparse_align": (C.c_int, [ctxp, C.POINTER(abi.AlignIn), C.POINTER(abi.AlignOut)]),
+        "plsvo_sparse_align_batch": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.AlignIn), C.POINTER(abi.AlignOut)]),
+        "plsvo_align_stage": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.AlignIn)]),
+        "plsvo_align_run": (C.c_int, [ctxp]),
+        "plsvo_align_fetch": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.AlignOut)]),
+        "plsvo_align_set_trace": (C.c_int, [ctxp, C.c_int]),
+        "plsvo_align_fetch_trace": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.AlignIterLog), C.c_int, C.POINTER(C.c_int)]),
+        "plsvo_align_poses_dev": (vp, [ctxp]),
+        "plsvo_align_work": (C.c_int, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "plsvo_pose_optimize": (C.c_int, [ctxp, C.POINTER(abi.PoseOptIn), C.POINTER(abi.PoseOptOut)]),
+        "plsvo_pose_optimize_batch": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.PoseOptIn), C.POINTER(abi.PoseOptOut)]),
+        "plsvo_poseopt_stage": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.PoseOptIn)]),
+        "plsvo_poseopt_run": (C.c_int, [ctxp]),
+        "plsvo_poseopt_fetch": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.PoseOptOut)]),
+        "plsvo_poseopt_set_trace": (C.c_int, [ctxp, C.c_int]),
+        "plsvo_poseopt_fetch_trace": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.PoseOptIterLog), C.c_int, C.POINTER(C.c_int)]),
+        "plsvo_poseopt_poses_dev": (vp, [ctxp]),
+        "plsvo_poseopt_work": (C.c_int, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "plsvo_gather_poses": (C.c_int, [ctxp, vp, vp, C.c_int, vp]),
+        "plsvo_hip_set_profiling": (C.c_int, [ctxp, C.c_int]),
+        "plsvo_hip_kernel_time": (C.c_int, [ctxp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+        "plsvo_hip_reset_profiling": (C.c_int, [ctxp]),
+        "plsvo_hip_version": (C.c_char_p, []),
+        "plsvo_hip_device_info": (C.c_int, [ctxp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+class Context:
+    """One plsvo_ctx: a device + stream + HBM buffers.  Mirrors the C ABI one-to-one."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.plsvo_hip_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != 0:
+            raise PlsvoError(rc, (self.L.plsvo_hip_last_error(None) or b"").decode())
+        self.h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.plsvo_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PlsvoError(rc, (self.L.plsvo_hip_last_error(self.h) or b"").decode())
+
+    # ---- info / timing ----
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu = C.c_int(0)
+        mem = C.c_size_t(0)
+        self._chk(self.L.plsvo_hip_device_info(self.h, name, 256, C.byref(cu), C.byref(mem)))
+        return name.value.decode(), cu.value, mem.value
+
+    def stream(self):
+        return self.L.plsvo_hip_stream(self.h)
+
+    def synchronize(self):
+        self._chk(self.L.plsvo_hip_synchronize(self.h))
+
+    def set_profiling(self, on):
+        self._chk(self.L.plsvo_hip_set_profiling(self.h, 1 if on else 0))
+
+    def reset_profiling(self):
+        self._chk(self.L.plsvo_hip_reset_profiling(self.h))
+
+    def kernel_time(self, k):
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        self._chk(self.L.plsvo_hip_kernel_time(self.h, k, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- pyramids ----
+    def config_pyramids(self, n_slots, width, height, n_levels):
+        self._chk(self.L.plsvo_hip_config_pyramids(self.h, n_slots, width, height, n_levels))
+        self.n_levels = n_levels
+        self.width, self.height = width, height
+
+    def upload_pyramid(self, slot, levels):
+        keep = [np.ascontiguousarray(l, dtype=np.uint8) for l in levels]
+        n = len(keep)
+        ptrs = (abi.c_u8_p * n)(*[l.ctypes.data_as(abi.c_u8_p) for l in keep])
+        w = (C.c_int32 * n)(*[l.shape[1] for l in keep])
+        h = (C.c_int32 * n)(*[l.shape[0] for l in keep])
+        s = (C.c_int32 * n)(*[l.strides[0] for l in keep])
+        self._chk(self.L.plsvo_hip_upload_pyramid(self.h, slot, n, ptrs, w, h, s))
+
+    def build_pyramid(self, slot, img0, rounding=0):
+        img0 = np.ascontiguousarray(img0, dtype=np.uint8)
+        self._chk(self.L.plsvo_hip_build_pyramid(self.h, slot, img0.ctypes.data_as(abi.c_u8_p), img0.strides[0], rounding))
+
+    def build_pyramids_dev(self, first_slot, n, d_ptr, stride_bytes, image_pitch_bytes, rounding=0):
+        self._chk(self.L.plsvo_hip_build_pyramids_dev(self.h, first_slot, n, C.c_void_p(d_ptr), stride_bytes,
+                                                      image_pitch_bytes, rounding))
+
+    def download_level(self, slot, level):
+        w, h = self.width >> level, self.height >> level
+        out = np.empty((h, w), dtype=np.uint8)
+        self._chk(self.L.plsvo_hip_download_level(self.h, slot, level, out.ctypes.data_as(abi.c_u8_p)))
+        return out
+
+    def download_pyramid(self, slot):
+        return [self.download_level(slot, l) for l in range(self.n_levels)]
+
+    # ---- sparse image alignment ----
+    def align_set_trace(self, max_records):
+        self._chk(self.L.plsvo_align_set_trace(self.h, max_records))
+        self._align_trace = max_records
+
+    def align_stage(self, jobs):
+        arr = (abi.AlignIn * len(jobs))(*[j.c for j in jobs])
+        self._chk(self.L.plsvo_align_stage(self.h, len(jobs), arr))
+        self._align_jobs = jobs
+
+    def align_run(self):
+        self._chk(self.L.plsvo_align_run(self.h))
+
+    def align_fetch(self):
+        jobs = self._align_jobs
+        n = len(jobs)
+        outs = (abi.AlignOut * n)()
+        alive = [np.ones(max(j.n_seg, 1), dtype=np.uint8) for j in jobs]
+        for o, a in zip(outs, alive):
+            o.seg_alive_out = a.ctypes.data_as(abi.c_u8_p)
+        self._chk(self.L.plsvo_align_fetch(self.h, n, outs))
+        return [abi.AlignResult(o, a[:j.n_seg].copy()) for o, a, j in zip(outs, alive, jobs)]
+
+    def align_fetch_trace(self, job):
+        cap = getattr(self, "_align_trace", 0)
+        log = (abi.AlignIterLog * max(cap, 1))()
+        n = C.c_int(0)
+        self._chk(self.L.plsvo_align_fetch_trace(self.h, job, log, cap, C.byref(n)))
+        return abi.align_log_to_dicts(log, n.value)
+
+    def sparse_align_batch(self, jobs):
+        self.align_stage(jobs)
+        self.align_run()
+        return self.align_fetch()
+
+    def sparse_align(self, job):
+        return self.sparse_align_batch([job])[0]
+
+    def align_work(self):
+        a = C.c_uint64(0)
+        b = C.c_uint64(0)
+        self._chk(self.L.plsvo_align_work(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def align_poses_dev(self):
+        return self.L.plsvo_align_poses_dev(self.h)
+
+    # ---- pose optimisation ----
+    def poseopt_set_trace(self, max_records):
+        self._chk(self.L.plsvo_poseopt_set_trace(self.h, max_records))
+        self._pose_trace = max_records
+
+    def poseopt_stage(self, jobs):
+        arr = (abi.PoseOptIn * len(jobs))(*[j.c for j in jobs])
+        self._chk(self.L.plsvo_poseopt_stage(self.h, len(jobs), arr))
+        self._pose_jobs = jobs
+
+    def poseopt_run(self):
+        self._chk(self.L.plsvo_poseopt_run(self.h))
+
+    def poseopt_fetch(self):
+        jobs = self._pose_jobs
+        n = len(jobs)
+        outs = (abi.PoseOptOut * n)()
+        pk = [np.ones(max(j.n_pts, 1), dtype=np.uint8) for j in jobs]
+        sk = [np.ones(max(j.n_seg, 1), dtype=np.uint8) for j in jobs]
+        for o, a, b in zip(outs, pk, sk):
+            o.pt_keep = a.ctypes.data_as(abi.c_u8_p)
+            o.seg_keep = b.ctypes.data_as(abi.c_u8_p)
+        self._chk(self.L.plsvo_poseopt_fetch(self.h, n, outs))
+        return [abi.PoseOptResult(o, a[:j.n_pts].copy(), b[:j.n_seg].copy()) for o, a, b, j in zip(outs, pk, sk, jobs)]
+
+    def poseopt_fetch_trace(self, job):
+        cap = getattr(self, "_pose_trace", 0)
+        log = (abi.PoseOptIterLog * max(cap, 1))()
+        n = C.c_int(0)
+        self._chk(self.L.plsvo_poseopt_fetch_trace(self.h, job, log, cap, C.byref(n)))
+        return abi.poseopt_log_to_dicts(log, n.value)
+
+    def pose_optimize_batch(self, jobs):
+        self.poseopt_stage(jobs)
+        self.poseopt_run()
+        return self.poseopt_fetch()
+
+    def pose_optimize(self, job):
+        return self.pose_optimize_batch([job])[0]
+
+    def poseopt_work(self):
+        a = C.c_uint64(0)
+        b = C.c_uint64(0)
+        self._chk(self.L.plsvo_poseopt_work(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def poseopt_poses_dev(self):
+        return self.L.plsvo_poseopt_poses_dev(self.h)
+
+    def gather_poses(self, rccl_comm, d_local, n_local, d_all):
+        self._chk(self.L.plsvo_gather_poses(self.h, C.c_void_p(rccl_comm), C.c_void_p(d_local), n_local, C.c_void_p(d_all)))

@@ -1,0 +1,718 @@
+// plsvo_capi.hip -- implementation of the C ABI declared in include/plsvo_hip.h.
+// Host side only: context, HBM buffers, staging of flattened features, kernel launches, result fetch,
+// hipEvent timing, RCCL gather.  All device work is enqueued on the ctx stream; nothing here computes
+// any part of the hot path on the CPU (there is no fallback).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/plsvo_hip.h"
+#include "plsvo_dev.hpp"
+#include "plsvo_math.hpp"
+
+namespace plsvo_hip {
+// kernels (align_kernels.hip, poseopt_kernels.hip, pyramid_kernels.hip)
+size_t align_level_lds_bytes(int threads, int cap, int img_bytes_or_0);
+hipError_t launch_align_level(const AlignBatchDev& b, int level, int cap, int threads, bool lds_img, size_t lds, hipStream_t stream);
+hipError_t launch_align_init(const AlignBatchDev& b, hipStream_t stream);
+hipError_t launch_align_finish(const AlignBatchDev& b, double* d_poses, hipStream_t stream);
+hipError_t launch_pose_opt(const PoseBatchDev& b, hipStream_t stream);
+hipError_t launch_pose_finish(const PoseBatchDev& b, double* d_poses, hipStream_t stream);
+hipError_t launch_halfsample(const uint8_t* src, size_t src_pitch, int in_w, int in_h, int in_stride, uint8_t* dst,
+                             size_t dst_pitch, int n_slots, int rounding, hipStream_t stream);
+hipError_t launch_copy_level0(const uint8_t* src, size_t src_pitch, int w, int h, int stride, uint8_t* dst, size_t dst_pitch,
+                              int n_slots, hipStream_t stream);
+}  // namespace plsvo_hip
+
+using namespace plsvo_hip;
+
+static thread_local std::string g_create_error;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+    size_t want = std::max(bytes, (size_t)256);
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct EventPair { hipEvent_t a, b; };
+
+}  // namespace
+
+struct plsvo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  int cu_count = 0;
+  size_t lds_per_block = 65536;
+
+  // pyramids
+  DevBuf pyr_slab;
+  PyrDesc pyr{};
+  DevBuf pyr_upload;  // staging for level-0 uploads
+
+  // alignment batch
+  int a_n = 0;
+  bool a_staged = false;
+  std::vector<AlignJobDev> a_jobs;
+  std::vector<int> a_nseg_off;  // per job seg offset (host copy)
+  int a_total_seg = 0;
+  int a_gmax = -1, a_gmin = 99;
+  int a_cap[PLSVO_MAX_LEVELS]{};
+  int a_trace_cap = 0;
+  DevBuf a_d_jobs, a_d_state, a_d_T0, a_d_ptpx, a_d_ptxyz, a_d_spx, a_d_epx, a_d_len, a_d_p, a_d_q, a_d_alive_in, a_d_alive;
+  DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_cdx, a_d_cdy, a_d_partial, a_d_log, a_d_poses;
+  AlignBatchDev a_b{};
+
+  // pose-opt batch
+  int p_n = 0;
+  bool p_staged = false;
+  std::vector<PoseJobDev> p_jobs;
+  int p_total_pt = 0, p_total_seg = 0;
+  int p_trace_cap = 0;
+  DevBuf p_d_jobs, p_d_state, p_d_f, p_d_pos, p_d_plevel, p_d_line, p_d_spos, p_d_epos, p_d_slevel, p_d_ptkeep, p_d_segkeep;
+  DevBuf p_d_s32, p_d_s64, p_d_log, p_d_poses;
+  PoseBatchDev p_b{};
+
+  // profiling
+  bool profiling = false;
+  std::vector<EventPair> ev[PLSVO_K_COUNT];
+  std::vector<EventPair> ev_pool;
+  double ev_ms[PLSVO_K_COUNT]{};
+  int64_t ev_launches[PLSVO_K_COUNT]{};
+};
+
+#define CTX_CHECK(ctx) do { if (!(ctx)) return PLSVO_E_INVALID; } while (0)
+#define HIP_TRY(ctx, expr)                                                                      \
+  do {                                                                                          \
+    hipError_t e__ = (expr);                                                                    \
+    if (e__ != hipSuccess) {                                                                    \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                          \
+      return PLSVO_E_HIP;                                                                       \
+    }                                                                                           \
+  } while (0)
+static int fail(plsvo_ctx* ctx, int code, const std::string& msg) { ctx->err = msg; return code; }
+
+// ---- profiling helpers ----------------------------------------------------------------------
+static void prof_begin(plsvo_ctx* c, int k, EventPair* ep) {
+  if (!c->profiling) return;
+  if (!c->ev_pool.empty()) { *ep = c->ev_pool.back(); c->ev_pool.pop_back(); }
+  else { (void)hipEventCreate(&ep->a); (void)hipEventCreate(&ep->b); }
+  (void)hipEventRecord(ep->a, c->stream);
+  (void)k;
+}
+static void prof_end(plsvo_ctx* c, int k, EventPair* ep) {
+  if (!c->profiling) return;
+  (void)hipEventRecord(ep->b, c->stream);
+  c->ev[k].push_back(*ep);
+}
+static void prof_collect(plsvo_ctx* c) {
+  for (int k = 0; k < PLSVO_K_COUNT; ++k) {
+    for (auto& ep : c->ev[k]) {
+      float ms = 0.f;
+      if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+        c->ev_ms[k] += (double)ms; c->ev_launches[k] += 1;
+      }
+      c->ev_pool.push_back(ep);
+    }
+    c->ev[k].clear();
+  }
+}
+
+// ---- context ---------------------------------------------------------------------------------
+extern "C" const char* plsvo_hip_version(void) { return "plsvo_hip 0.1 (gfx950)"; }
+
+extern "C" int plsvo_hip_create(int device_id, void* stream, plsvo_ctx** out) {
+  if (!out) return PLSVO_E_INVALID;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_error = std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "count=0") +
+                     "); plsvo_hip has no CPU fallback";
+    return PLSVO_E_NODEVICE;
+  }
+  if (device_id < 0 || device_id >= n) { g_create_error = "device_id out of range"; return PLSVO_E_INVALID; }
+  if ((e = hipSetDevice(device_id)) != hipSuccess) { g_create_error = hipGetErrorString(e); return PLSVO_E_HIP; }
+  plsvo_ctx* c = new plsvo_ctx();
+  c->device = device_id;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+    c->cu_count = prop.multiProcessorCount;
+    c->lds_per_block = prop.sharedMemPerBlock;
+    int optin = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && optin > 0)
+      c->lds_per_block = std::max(c->lds_per_block, (size_t)optin);
+  }
+  if (stream) { c->stream = reinterpret_cast<hipStream_t>(stream); c->own_stream = false; }
+  else {
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+      g_create_error = hipGetErrorString(e); delete c; return PLSVO_E_HIP;
+    }
+    c->own_stream = true;
+  }
+  if (const char* s = getenv("PLSVO_LDS_LIMIT")) c->lds_per_block = (size_t)atol(s);
+  *out = c;
+  return PLSVO_OK;
+}
+
+extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  prof_collect(c);
+  for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+  DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_upload, &c->a_d_jobs, &c->a_d_state, &c->a_d_T0, &c->a_d_ptpx, &c->a_d_ptxyz, &c->a_d_spx,
+                     &c->a_d_epx, &c->a_d_len, &c->a_d_p, &c->a_d_q, &c->a_d_alive_in, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv,
+                     &c->a_d_cref, &c->a_d_cdx, &c->a_d_cdy, &c->a_d_partial, &c->a_d_log, &c->a_d_poses, &c->p_d_jobs, &c->p_d_state,
+                     &c->p_d_f, &c->p_d_pos, &c->p_d_plevel, &c->p_d_line, &c->p_d_spos, &c->p_d_epos, &c->p_d_slevel,
+                     &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64, &c->p_d_log, &c->p_d_poses };
+  for (DevBuf* b : bufs) b->release();
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" const char* plsvo_hip_last_error(const plsvo_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+extern "C" void* plsvo_hip_stream(plsvo_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) : nullptr; }
+extern "C" int plsvo_hip_synchronize(plsvo_ctx* c) { CTX_CHECK(c); HIP_TRY(c, hipStreamSynchronize(c->stream)); return PLSVO_OK; }
+
+extern "C" int plsvo_hip_device_info(plsvo_ctx* c, char* name, int name_len, int* cu_count, size_t* hbm_bytes) {
+  CTX_CHECK(c);
+  hipDeviceProp_t prop;
+  HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+  if (name && name_len > 0) { snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName); }
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+  return PLSVO_OK;
+}
+
+// ---- pyramids ----------------------------------------------------------------------------------
+extern "C" int plsvo_hip_config_pyramids(plsvo_ctx* c, int n_slots, int width, int height, int n_levels) {
+  CTX_CHECK(c);
+  if (n_slots <= 0 || width <= 0 || height <= 0 || n_levels <= 0 || n_levels > PLSVO_MAX_LEVELS) return fail(c, PLSVO_E_INVALID, "config_pyramids: bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  PyrDesc d{};
+  size_t off = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    d.w[l] = width >> l; d.h[l] = height >> l;
+    if (d.w[l] <= 0 || d.h[l] <= 0) return fail(c, PLSVO_E_INVALID, "config_pyramids: too many levels for this image size");
+    d.off[l] = (unsigned int)off;
+    off += (((size_t)d.w[l] * d.h[l] + 64) + 255) & ~(size_t)255;  // >= 64 bytes of slack after every level (gather over-read)
+  }
+  d.slot_bytes = off; d.n_slots = n_slots; d.n_levels = n_levels;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, c->pyr_slab.ensure((size_t)n_slots * off + 256));
+  HIP_TRY(c, hipMemsetAsync(c->pyr_slab.p, 0, (size_t)n_slots * off + 256, c->stream));
+  d.base = c->pyr_slab.as<uint8_t>();
+  c->pyr = d;
+  c->a_staged = false;
+  return PLSVO_OK;
+}
+
+static int check_slot(plsvo_ctx* c, int slot) {
+  if (!c->pyr.base) return fail(c, PLSVO_E_STATE, "pyramids not configured");
+  if (slot < 0 || slot >= c->pyr.n_slots) return fail(c, PLSVO_E_CAPACITY, "pyramid slot out of range");
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_hip_upload_pyramid(plsvo_ctx* c, int slot, int n_levels, const uint8_t* const* level_ptr, const int* width,
+                                        const int* height, const int* stride_bytes) {
+  CTX_CHECK(c);
+  int rc = check_slot(c, slot); if (rc) return rc;
+  if (!level_ptr || !width || !height || !stride_bytes || n_levels > c->pyr.n_levels) return fail(c, PLSVO_E_INVALID, "upload_pyramid: bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  for (int l = 0; l < n_levels; ++l) {
+    if (width[l] != c->pyr.w[l] || height[l] != c->pyr.h[l]) return fail(c, PLSVO_E_INVALID, "upload_pyramid: level size does not match the configured pyramid");
+    uint8_t* dst = c->pyr_slab.as<uint8_t>() + (size_t)slot * c->pyr.slot_bytes + c->pyr.off[l];
+    HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)width[l], level_ptr[l], (size_t)stride_bytes[l], (size_t)width[l], (size_t)height[l],
+                                hipMemcpyHostToDevice, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the host buffers may be released by the caller
+  return PLSVO_OK;
+}
+
+static int build_levels(plsvo_ctx* c, int first_slot, int n, int rounding) {
+  uint8_t* base = c->pyr_slab.as<uint8_t>() + (size_t)first_slot * c->pyr.slot_bytes;
+  for (int l = 1; l < c->pyr.n_levels; ++l) {
+    EventPair ep{}; prof_begin(c, PLSVO_K_HALFSAMPLE, &ep);
+    HIP_TRY(c, launch_halfsample(base + c->pyr.off[l - 1], c->pyr.slot_bytes, c->pyr.w[l - 1], c->pyr.h[l - 1], c->pyr.w[l - 1],
+                                 base + c->pyr.off[l], c->pyr.slot_bytes, n, rounding, c->stream));
+    prof_end(c, PLSVO_K_HALFSAMPLE, &ep);
+  }
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_hip_build_pyramid(plsvo_ctx* c, int slot, const uint8_t* level0, int stride_bytes, int rounding) {
+  CTX_CHECK(c);
+  int rc = check_slot(c, slot); if (rc) return rc;
+  if (!level0 || stride_bytes < c->pyr.w[0]) return fail(c, PLSVO_E_INVALID, "build_pyramid: bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint8_t* dst = c->pyr_slab.as<uint8_t>() + (size_t)slot * c->pyr.slot_bytes + c->pyr.off[0];
+  HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)c->pyr.w[0], level0, (size_t)stride_bytes, (size_t)c->pyr.w[0], (size_t)c->pyr.h[0],
+                              hipMemcpyHostToDevice, c->stream));
+  rc = build_levels(c, slot, 1, rounding); if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_hip_build_pyramids_dev(plsvo_ctx* c, int first_slot, int n, const void* d_level0, int stride_bytes,
+                                            size_t image_pitch_bytes, int rounding) {
+  CTX_CHECK(c);
+  if (n <= 0 || !d_level0) return fail(c, PLSVO_E_INVALID, "build_pyramids_dev: bad arguments");
+  int rc = check_slot(c, first_slot); if (rc) return rc;
+  rc = check_slot(c, first_slot + n - 1); if (rc) return rc;
+  if (stride_bytes < c->pyr.w[0]) return fail(c, PLSVO_E_INVALID, "build_pyramids_dev: stride smaller than width");
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint8_t* base = c->pyr_slab.as<uint8_t>() + (size_t)first_slot * c->pyr.slot_bytes;
+  HIP_TRY(c, launch_copy_level0(reinterpret_cast<const uint8_t*>(d_level0), image_pitch_bytes, c->pyr.w[0], c->pyr.h[0], stride_bytes,
+                                base + c->pyr.off[0], c->pyr.slot_bytes, n, c->stream));
+  return build_levels(c, first_slot, n, rounding);
+}
+
+extern "C" int plsvo_hip_download_level(plsvo_ctx* c, int slot, int level, uint8_t* out) {
+  CTX_CHECK(c);
+  int rc = check_slot(c, slot); if (rc) return rc;
+  if (level < 0 || level >= c->pyr.n_levels || !out) return fail(c, PLSVO_E_INVALID, "download_level: bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint8_t* src = c->pyr_slab.as<uint8_t>() + (size_t)slot * c->pyr.slot_bytes + c->pyr.off[level];
+  HIP_TRY(c, hipMemcpyAsync(out, src, (size_t)c->pyr.w[level] * c->pyr.h[level], hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PLSVO_OK;
+}
+
+// ---- alignment -----------------------------------------------------------------------------------
+template <typename T>
+static int upload(plsvo_ctx* c, DevBuf& buf, const std::vector<T>& v) {
+  HIP_TRY(c, buf.ensure(std::max(v.size(), (size_t)1) * sizeof(T)));
+  if (!v.empty()) HIP_TRY(c, hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) {
+  CTX_CHECK(c);
+  if (n <= 0 || !in) return fail(c, PLSVO_E_INVALID, "align_stage: bad arguments");
+  if (!c->pyr.base) return fail(c, PLSVO_E_STATE, "align_stage: pyramids not configured");
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->a_staged = false;
+  std::vector<AlignJobDev> jobs((size_t)n);
+  std::vector<double> T0((size_t)n * 7), ptpx, ptxyz, spx, epx, len, sp, sq;
+  std::vector<uint8_t> alive;
+  int gmax = -1, gmin = 99;
+  int caps[PLSVO_MAX_LEVELS] = { 0 };
+  size_t patch_total = 0;
+  for (int j = 0; j < n; ++j) {
+    const plsvo_align_in& a = in[j];
+    if (a.n_pts < 0 || a.n_seg < 0 || a.max_level < a.min_level || a.min_level < 0 || a.max_level >= c->pyr.n_levels || a.n_iter < 0)
+      return fail(c, PLSVO_E_INVALID, "align_stage: bad job parameters (levels must exist in the configured pyramid)");
+    if (a.ref_slot < 0 || a.ref_slot >= c->pyr.n_slots || a.cur_slot < 0 || a.cur_slot >= c->pyr.n_slots)
+      return fail(c, PLSVO_E_CAPACITY, "align_stage: pyramid slot out of range");
+    if (a.cam.width != c->pyr.w[0] || a.cam.height != c->pyr.h[0])
+      return fail(c, PLSVO_E_INVALID, "align_stage: camera size does not match the configured pyramid");
+    if ((a.n_pts > 0 && (!a.pt_px || !a.pt_xyz_ref)) || (a.n_seg > 0 && (!a.seg_spx || !a.seg_epx || !a.seg_len || !a.seg_p_ref || !a.seg_q_ref)))
+      return fail(c, PLSVO_E_INVALID, "align_stage: null feature array");
+    AlignJobDev& J = jobs[(size_t)j];
+    J.ref_slot = a.ref_slot; J.cur_slot = a.cur_slot;
+    J.fx = a.cam.fx; J.fy = a.cam.fy; J.cx = a.cam.cx; J.cy = a.cam.cy; J.width = a.cam.width; J.height = a.cam.height;
+    J.max_level = a.max_level; J.min_level = a.min_level; J.n_iter = a.n_iter; J.eps = a.eps;
+    J.skip = (a.n_pts == 0 && a.n_seg == 0) ? 1 : 0;
+    J.pt_off = (int)(ptpx.size() / 2); J.n_pts = a.n_pts; J.seg_off = (int)len.size(); J.n_seg = a.n_seg;
+    for (int k = 0; k < 7; ++k) T0[(size_t)j * 7 + k] = a.T_cur_from_ref[k];
+    ptpx.insert(ptpx.end(), a.pt_px, a.pt_px + 2 * (size_t)a.n_pts);
+    ptxyz.insert(ptxyz.end(), a.pt_xyz_ref, a.pt_xyz_ref + 3 * (size_t)a.n_pts);
+    spx.insert(spx.end(), a.seg_spx, a.seg_spx + 2 * (size_t)a.n_seg);
+    epx.insert(epx.end(), a.seg_epx, a.seg_epx + 2 * (size_t)a.n_seg);
+    len.insert(len.end(), a.seg_len, a.seg_len + (size_t)a.n_seg);
+    sp.insert(sp.end(), a.seg_p_ref, a.seg_p_ref + 3 * (size_t)a.n_seg);
+    sq.insert(sq.end(), a.seg_q_ref, a.seg_q_ref + 3 * (size_t)a.n_seg);
+    for (int s = 0; s < a.n_seg; ++s) alive.push_back(a.seg_alive_in ? (a.seg_alive_in[s] ? 1 : 0) : 1);
+    // patch capacity per level: every point + every sample of every segment (upper bound; the kernel
+    // recomputes the same count on the device and checks it against this bound)
+    int ub_min = 0;
+    for (int l = a.max_level; l >= a.min_level; --l) {
+      long long ub = a.n_pts;
+      for (int s = 0; s < a.n_seg; ++s)
+        ub += seg_num_samples(a.seg_spx[2 * s], a.seg_spx[2 * s + 1], a.seg_epx[2 * s], a.seg_epx[2 * s + 1], a.seg_len[s], l);
+      if (ub > (1 << 20) - 8) return fail(c, PLSVO_E_CAPACITY, "align_stage: more than 2^20 patches in one job");
+      const int ub4 = (int)((ub + 3) & ~3LL);
+      if (!J.skip) caps[l] = std::max(caps[l], ub4);
+      ub_min = std::max(ub_min, ub4);
+    }
+    J.patch_off = (int)patch_total; J.patch_cap = ub_min;
+    patch_total += (size_t)ub_min;
+    if (patch_total > (size_t)0x7fffffff / 16) return fail(c, PLSVO_E_CAPACITY, "align_stage: batch too large (patch index overflow)");
+    if (!J.skip) { gmax = std::max(gmax, a.max_level); gmin = std::min(gmin, a.min_level); }
+  }
+  int rc;
+  if ((rc = upload(c, c->a_d_jobs, jobs))) return rc;
+  if ((rc = upload(c, c->a_d_T0, T0))) return rc;
+  if ((rc = upload(c, c->a_d_ptpx, ptpx))) return rc;
+  if ((rc = upload(c, c->a_d_ptxyz, ptxyz))) return rc;
+  if ((rc = upload(c, c->a_d_spx, spx))) return rc;
+  if ((rc = upload(c, c->a_d_epx, epx))) return rc;
+  if ((rc = upload(c, c->a_d_len, len))) return rc;
+  if ((rc = upload(c, c->a_d_p, sp))) return rc;
+  if ((rc = upload(c, c->a_d_q, sq))) return rc;
+  if ((rc = upload(c, c->a_d_alive_in, alive))) return rc;
+  HIP_TRY(c, c->a_d_alive.ensure(std::max(alive.size(), (size_t)1)));
+  HIP_TRY(c, c->a_d_state.ensure((size_t)n * sizeof(AlignStateDev)));
+  HIP_TRY(c, c->a_d_poses.ensure((size_t)n * 7 * sizeof(double)));
+  const size_t pt = std::max(patch_total, (size_t)4);
+  HIP_TRY(c, c->a_d_pxyz.ensure(pt * 3 * sizeof(double)));
+  HIP_TRY(c, c->a_d_puv.ensure(pt * 2 * sizeof(float)));
+  HIP_TRY(c, c->a_d_cref.ensure(pt * 16 * sizeof(float)));
+  HIP_TRY(c, c->a_d_cdx.ensure(pt * 16 * sizeof(float)));
+  HIP_TRY(c, c->a_d_cdy.ensure(pt * 16 * sizeof(float)));
+  HIP_TRY(c, c->a_d_partial.ensure(pt * 6 * sizeof(double)));
+  if (c->a_trace_cap > 0) HIP_TRY(c, c->a_d_log.ensure((size_t)n * c->a_trace_cap * sizeof(plsvo_align_iterlog)));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
+
+  AlignBatchDev& b = c->a_b;
+  b.jobs = c->a_d_jobs.as<AlignJobDev>(); b.state = c->a_d_state.as<AlignStateDev>(); b.T0 = c->a_d_T0.as<double>();
+  b.pt_px = c->a_d_ptpx.as<double>(); b.pt_xyz = c->a_d_ptxyz.as<double>();
+  b.seg_spx = c->a_d_spx.as<double>(); b.seg_epx = c->a_d_epx.as<double>(); b.seg_len = c->a_d_len.as<double>();
+  b.seg_p = c->a_d_p.as<double>(); b.seg_q = c->a_d_q.as<double>();
+  b.seg_alive_in = c->a_d_alive_in.as<uint8_t>(); b.seg_alive = c->a_d_alive.as<uint8_t>();
+  b.patch_xyz = c->a_d_pxyz.as<double>(); b.patch_uvref = c->a_d_puv.as<float>();
+  b.cache_ref = c->a_d_cref.as<float>(); b.cache_dx = c->a_d_cdx.as<float>(); b.cache_dy = c->a_d_cdy.as<float>();
+  b.partial = c->a_d_partial.as<double>();
+  b.pyr = c->pyr;
+  b.log = c->a_trace_cap > 0 ? c->a_d_log.as<plsvo_align_iterlog>() : nullptr;
+  b.log_cap = c->a_trace_cap;
+  b.n_jobs = n;
+  c->a_jobs.swap(jobs);
+  c->a_n = n; c->a_total_seg = (int)alive.size(); c->a_gmax = gmax; c->a_gmin = gmin;
+  for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) c->a_cap[l] = caps[l];
+  c->a_staged = true;
+  return PLSVO_OK;
+}
+
+// choose workgroup size / LDS mode for one level launch
+static void pick_level_config(plsvo_ctx* c, int level, int cap, int* threads, bool* lds_img, size_t* lds) {
+  const int img_bytes = c->pyr.w[level] * c->pyr.h[level];
+  int forced_t = 0;
+  if (const char* s = getenv("PLSVO_ALIGN_THREADS")) forced_t = atoi(s);
+  bool allow_lds = true;
+  if (const char* s = getenv("PLSVO_ALIGN_NO_LDS_IMG")) allow_lds = atoi(s) == 0;
+  const size_t limit = c->lds_per_block;
+  // LDS need with the image staged (tables are the same for every workgroup size up to the reduce scratch)
+  const size_t need_img = align_level_lds_bytes(1024, cap, img_bytes);
+  *lds_img = allow_lds && need_img <= limit;
+  int t;
+  if (*lds_img) {
+    // aim at ~16 waves per CU: workgroups per CU limited by LDS (160 KiB), size the workgroup to fill the rest
+    const size_t per_cu = 160 * 1024;
+    int wgs = (int)std::min<size_t>(8, per_cu / need_img);
+    if (wgs < 1) wgs = 1;
+    const int want = 1024 / wgs;
+    t = want <= 256 ? 256 : (want <= 512 ? 512 : 1024);
+  } else {
+    t = 256;
+  }
+  if (forced_t == 256 || forced_t == 512 || forced_t == 1024) t = forced_t;
+  *threads = t;
+  *lds = align_level_lds_bytes(t, cap, *lds_img ? img_bytes : 0);
+}
+
+extern "C" int plsvo_align_run(plsvo_ctx* c) {
+  CTX_CHECK(c);
+  if (!c->a_staged) return fail(c, PLSVO_E_STATE, "align_run: no staged batch");
+  HIP_TRY(c, hipSetDevice(c->device));
+  {
+    EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_INIT, &ep);
+    HIP_TRY(c, launch_align_init(c->a_b, c->stream));
+    prof_end(c, PLSVO_K_ALIGN_INIT, &ep);
+  }
+  for (int level = c->a_gmax; level >= c->a_gmin && level >= 0; --level) {
+    const int cap = std::max(c->a_cap[level], 4);
+    int threads; bool lds_img; size_t lds;
+    pick_level_config(c, level, cap, &threads, &lds_img, &lds);
+    if (lds > c->lds_per_block) return fail(c, PLSVO_E_CAPACITY, "align_run: patch tables do not fit in LDS (too many features in one job)");
+    EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
+    HIP_TRY(c, launch_align_level(c->a_b, level, cap, threads, lds_img, lds, c->stream));
+    prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
+  }
+  HIP_TRY(c, launch_align_finish(c->a_b, c->a_d_poses.as<double>(), c->stream));
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_align_fetch(plsvo_ctx* c, int n, plsvo_align_out* out) {
+  CTX_CHECK(c);
+  if (!c->a_staged) return fail(c, PLSVO_E_STATE, "align_fetch: no staged batch");
+  if (n != c->a_n || !out) return fail(c, PLSVO_E_INVALID, "align_fetch: n does not match the staged batch");
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<AlignStateDev> st((size_t)n);
+  std::vector<uint8_t> alive((size_t)std::max(c->a_total_seg, 1));
+  HIP_TRY(c, hipMemcpyAsync(st.data(), c->a_d_state.p, (size_t)n * sizeof(AlignStateDev), hipMemcpyDeviceToHost, c->stream));
+  if (c->a_total_seg > 0) HIP_TRY(c, hipMemcpyAsync(alive.data(), c->a_d_alive.p, (size_t)c->a_total_seg, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int dev_err = 0;
+  for (int j = 0; j < n; ++j) {
+    const AlignStateDev& s = st[(size_t)j];
+    plsvo_align_out& o = out[j];
+    uint8_t* alive_out = o.seg_alive_out;
+    memset(&o, 0, sizeof(o));
+    o.seg_alive_out = alive_out;
+    for (int k = 0; k < 7; ++k) o.T_cur_from_ref[k] = s.T[k];
+    o.n_meas = s.n_meas; o.n_tracked = s.n_meas / PLSVO_PATCH_AREA;
+    for (int k = 0; k < 36; ++k) o.H[k] = s.H[k];
+    o.chi2 = s.chi2;
+    for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) o.iters_per_level[l] = s.iters[l];
+    o.status = s.stop ? 1 : 0;
+    if (alive_out && c->a_jobs[(size_t)j].n_seg > 0)
+      memcpy(alive_out, alive.data() + c->a_jobs[(size_t)j].seg_off, (size_t)c->a_jobs[(size_t)j].n_seg);
+    if (s.error) dev_err = s.error;
+  }
+  if (dev_err) return fail(c, PLSVO_E_CAPACITY, "align: device-side capacity check failed (code " + std::to_string(dev_err) + ")");
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_sparse_align_batch(plsvo_ctx* c, int n, const plsvo_align_in* in, plsvo_align_out* out) {
+  int rc = plsvo_align_stage(c, n, in); if (rc) return rc;
+  rc = plsvo_align_run(c); if (rc) return rc;
+  return plsvo_align_fetch(c, n, out);
+}
+extern "C" int plsvo_sparse_align(plsvo_ctx* c, const plsvo_align_in* in, plsvo_align_out* out) {
+  return plsvo_sparse_align_batch(c, 1, in, out);
+}
+
+extern "C" int plsvo_align_set_trace(plsvo_ctx* c, int max_records_per_job) {
+  CTX_CHECK(c);
+  if (max_records_per_job < 0) return fail(c, PLSVO_E_INVALID, "set_trace: negative capacity");
+  c->a_trace_cap = max_records_per_job;
+  c->a_staged = false;  // the trace buffer is sized at stage time
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_align_fetch_trace(plsvo_ctx* c, int job, plsvo_align_iterlog* out, int max_records, int* n_records) {
+  CTX_CHECK(c);
+  if (!c->a_staged || c->a_trace_cap <= 0) return fail(c, PLSVO_E_STATE, "fetch_trace: tracing not enabled for the staged batch");
+  if (job < 0 || job >= c->a_n || !out || !n_records) return fail(c, PLSVO_E_INVALID, "fetch_trace: bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  AlignStateDev s;
+  HIP_TRY(c, hipMemcpyAsync(&s, c->a_d_state.as<AlignStateDev>() + job, sizeof(s), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const int have = std::min(s.log_count, c->a_trace_cap);
+  const int nrec = std::min(have, max_records);
+  if (nrec > 0) {
+    HIP_TRY(c, hipMemcpyAsync(out, c->a_d_log.as<plsvo_align_iterlog>() + (size_t)job * c->a_trace_cap, (size_t)nrec * sizeof(plsvo_align_iterlog),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  *n_records = nrec;
+  return PLSVO_OK;
+}
+
+extern "C" const double* plsvo_align_poses_dev(plsvo_ctx* c) { return (c && c->a_staged) ? c->a_d_poses.as<double>() : nullptr; }
+
+extern "C" int plsvo_align_work(plsvo_ctx* c, uint64_t* patch_levels, uint64_t* patch_iters) {
+  CTX_CHECK(c);
+  if (!c->a_staged) return fail(c, PLSVO_E_STATE, "align_work: no staged batch");
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<AlignStateDev> st((size_t)c->a_n);
+  HIP_TRY(c, hipMemcpyAsync(st.data(), c->a_d_state.p, (size_t)c->a_n * sizeof(AlignStateDev), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  uint64_t pl = 0, pi = 0;
+  for (auto& s : st) { pl += s.patch_levels; pi += s.patch_iters; }
+  if (patch_levels) *patch_levels = pl;
+  if (patch_iters) *patch_iters = pi;
+  return PLSVO_OK;
+}
+
+// ---- pose optimisation ---------------------------------------------------------------------------
+extern "C" int plsvo_poseopt_stage(plsvo_ctx* c, int n, const plsvo_poseopt_in* in) {
+  CTX_CHECK(c);
+  if (n <= 0 || !in) return fail(c, PLSVO_E_INVALID, "poseopt_stage: bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->p_staged = false;
+  std::vector<PoseJobDev> jobs((size_t)n);
+  std::vector<double> f, pos, line, spos, epos;
+  std::vector<int> plev, slev;
+  for (int j = 0; j < n; ++j) {
+    const plsvo_poseopt_in& a = in[j];
+    if (a.n_pts < 0 || a.n_seg < 0 || a.n_iter < 0) return fail(c, PLSVO_E_INVALID, "poseopt_stage: bad job parameters");
+    if ((a.n_pts > 0 && (!a.pt_f || !a.pt_pos || !a.pt_level)) || (a.n_seg > 0 && (!a.seg_line || !a.seg_spos || !a.seg_epos || !a.seg_level)))
+      return fail(c, PLSVO_E_INVALID, "poseopt_stage: null feature array");
+    PoseJobDev& J = jobs[(size_t)j];
+    for (int k = 0; k < 7; ++k) J.T0[k] = a.T_f_w[k];
+    J.fx = a.fx; J.reproj_thresh = a.reproj_thresh; J.n_iter = a.n_iter; J.n_iter_ref = a.n_iter_ref;
+    J.pt_off = (int)plev.size(); J.n_pts = a.n_pts; J.seg_off = (int)slev.size(); J.n_seg = a.n_seg;
+    f.insert(f.end(), a.pt_f, a.pt_f + 3 * (size_t)a.n_pts);
+    pos.insert(pos.end(), a.pt_pos, a.pt_pos + 3 * (size_t)a.n_pts);
+    plev.insert(plev.end(), a.pt_level, a.pt_level + (size_t)a.n_pts);
+    line.insert(line.end(), a.seg_line, a.seg_line + 3 * (size_t)a.n_seg);
+    spos.insert(spos.end(), a.seg_spos, a.seg_spos + 3 * (size_t)a.n_seg);
+    epos.insert(epos.end(), a.seg_epos, a.seg_epos + 3 * (size_t)a.n_seg);
+    slev.insert(slev.end(), a.seg_level, a.seg_level + (size_t)a.n_seg);
+    for (int i = 0; i < a.n_pts; ++i) if (a.pt_level[i] < 0 || a.pt_level[i] > 30) return fail(c, PLSVO_E_INVALID, "poseopt_stage: feature level out of range");
+    for (int i = 0; i < a.n_seg; ++i) if (a.seg_level[i] < 0 || a.seg_level[i] > 30) return fail(c, PLSVO_E_INVALID, "poseopt_stage: feature level out of range");
+  }
+  int rc;
+  if ((rc = upload(c, c->p_d_jobs, jobs))) return rc;
+  if ((rc = upload(c, c->p_d_f, f))) return rc;
+  if ((rc = upload(c, c->p_d_pos, pos))) return rc;
+  if ((rc = upload(c, c->p_d_plevel, plev))) return rc;
+  if ((rc = upload(c, c->p_d_line, line))) return rc;
+  if ((rc = upload(c, c->p_d_spos, spos))) return rc;
+  if ((rc = upload(c, c->p_d_epos, epos))) return rc;
+  if ((rc = upload(c, c->p_d_slevel, slev))) return rc;
+  const size_t npt = plev.size(), nsg = slev.size(), nft = std::max(npt + nsg, (size_t)1);
+  HIP_TRY(c, c->p_d_ptkeep.ensure(std::max(npt, (size_t)1)));
+  HIP_TRY(c, c->p_d_segkeep.ensure(std::max(nsg, (size_t)1)));
+  HIP_TRY(c, c->p_d_s32.ensure(nft * sizeof(float)));
+  HIP_TRY(c, c->p_d_s64.ensure(nft * 3 * sizeof(double)));
+  HIP_TRY(c, c->p_d_state.ensure((size_t)n * sizeof(PoseStateDev)));
+  HIP_TRY(c, c->p_d_poses.ensure((size_t)n * 7 * sizeof(double)));
+  if (c->p_trace_cap > 0) HIP_TRY(c, c->p_d_log.ensure((size_t)n * c->p_trace_cap * sizeof(plsvo_poseopt_iterlog)));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  PoseBatchDev& b = c->p_b;
+  b.jobs = c->p_d_jobs.as<PoseJobDev>(); b.state = c->p_d_state.as<PoseStateDev>();
+  b.pt_f = c->p_d_f.as<double>(); b.pt_pos = c->p_d_pos.as<double>(); b.pt_level = c->p_d_plevel.as<int>();
+  b.seg_line = c->p_d_line.as<double>(); b.seg_spos = c->p_d_spos.as<double>(); b.seg_epos = c->p_d_epos.as<double>();
+  b.seg_level = c->p_d_slevel.as<int>();
+  b.pt_keep = c->p_d_ptkeep.as<uint8_t>(); b.seg_keep = c->p_d_segkeep.as<uint8_t>();
+  b.scratch_f32 = c->p_d_s32.as<float>(); b.scratch_f64 = c->p_d_s64.as<double>();
+  b.log = c->p_trace_cap > 0 ? c->p_d_log.as<plsvo_poseopt_iterlog>() : nullptr;
+  b.log_cap = c->p_trace_cap; b.n_jobs = n;
+  c->p_jobs.swap(jobs);
+  c->p_n = n; c->p_total_pt = (int)npt; c->p_total_seg = (int)nsg;
+  c->p_staged = true;
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_poseopt_run(plsvo_ctx* c) {
+  CTX_CHECK(c);
+  if (!c->p_staged) return fail(c, PLSVO_E_STATE, "poseopt_run: no staged batch");
+  HIP_TRY(c, hipSetDevice(c->device));
+  EventPair ep{}; prof_begin(c, PLSVO_K_POSEOPT, &ep);
+  HIP_TRY(c, launch_pose_opt(c->p_b, c->stream));
+  prof_end(c, PLSVO_K_POSEOPT, &ep);
+  HIP_TRY(c, launch_pose_finish(c->p_b, c->p_d_poses.as<double>(), c->stream));
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_poseopt_fetch(plsvo_ctx* c, int n, plsvo_poseopt_out* out) {
+  CTX_CHECK(c);
+  if (!c->p_staged) return fail(c, PLSVO_E_STATE, "poseopt_fetch: no staged batch");
+  if (n != c->p_n || !out) return fail(c, PLSVO_E_INVALID, "poseopt_fetch: n does not match the staged batch");
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<PoseStateDev> st((size_t)n);
+  std::vector<uint8_t> pk((size_t)std::max(c->p_total_pt, 1)), sk((size_t)std::max(c->p_total_seg, 1));
+  HIP_TRY(c, hipMemcpyAsync(st.data(), c->p_d_state.p, (size_t)n * sizeof(PoseStateDev), hipMemcpyDeviceToHost, c->stream));
+  if (c->p_total_pt > 0) HIP_TRY(c, hipMemcpyAsync(pk.data(), c->p_d_ptkeep.p, (size_t)c->p_total_pt, hipMemcpyDeviceToHost, c->stream));
+  if (c->p_total_seg > 0) HIP_TRY(c, hipMemcpyAsync(sk.data(), c->p_d_segkeep.p, (size_t)c->p_total_seg, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int j = 0; j < n; ++j) {
+    const PoseStateDev& s = st[(size_t)j];
+    const PoseJobDev& J = c->p_jobs[(size_t)j];
+    plsvo_poseopt_out& o = out[j];
+    uint8_t* pko = o.pt_keep; uint8_t* sko = o.seg_keep;
+    memset(&o, 0, sizeof(o));
+    o.pt_keep = pko; o.seg_keep = sko;
+    for (int k = 0; k < 7; ++k) o.T_f_w[k] = s.T[k];
+    for (int k = 0; k < 36; ++k) o.cov[k] = s.cov[k];
+    o.estimated_scale = s.estimated_scale; o.error_init = s.error_init; o.error_final = s.error_final;
+    o.num_obs_pt = s.num_obs_pt; o.num_obs_ls = s.num_obs_ls;
+    o.iters = s.iters; o.iters_ref = s.iters_ref; o.status = s.status;
+    if (pko && J.n_pts > 0) memcpy(pko, pk.data() + J.pt_off, (size_t)J.n_pts);
+    if (sko && J.n_seg > 0) memcpy(sko, sk.data() + J.seg_off, (size_t)J.n_seg);
+  }
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_pose_optimize_batch(plsvo_ctx* c, int n, const plsvo_poseopt_in* in, plsvo_poseopt_out* out) {
+  int rc = plsvo_poseopt_stage(c, n, in); if (rc) return rc;
+  rc = plsvo_poseopt_run(c); if (rc) return rc;
+  return plsvo_poseopt_fetch(c, n, out);
+}
+extern "C" int plsvo_pose_optimize(plsvo_ctx* c, const plsvo_poseopt_in* in, plsvo_poseopt_out* out) {
+  return plsvo_pose_optimize_batch(c, 1, in, out);
+}
+
+extern "C" int plsvo_poseopt_set_trace(plsvo_ctx* c, int max_records_per_job) {
+  CTX_CHECK(c);
+  if (max_records_per_job < 0) return fail(c, PLSVO_E_INVALID, "set_trace: negative capacity");
+  c->p_trace_cap = max_records_per_job;
+  c->p_staged = false;
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_poseopt_fetch_trace(plsvo_ctx* c, int job, plsvo_poseopt_iterlog* out, int max_records, int* n_records) {
+  CTX_CHECK(c);
+  if (!c->p_staged || c->p_trace_cap <= 0) return fail(c, PLSVO_E_STATE, "fetch_trace: tracing not enabled for the staged batch");
+  if (job < 0 || job >= c->p_n || !out || !n_records) return fail(c, PLSVO_E_INVALID, "fetch_trace: bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  PoseStateDev s;
+  HIP_TRY(c, hipMemcpyAsync(&s, c->p_d_state.as<PoseStateDev>() + job, sizeof(s), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const int nrec = std::min(std::min(s.log_count, c->p_trace_cap), max_records);
+  if (nrec > 0) {
+    HIP_TRY(c, hipMemcpyAsync(out, c->p_d_log.as<plsvo_poseopt_iterlog>() + (size_t)job * c->p_trace_cap, (size_t)nrec * sizeof(plsvo_poseopt_iterlog),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  *n_records = nrec;
+  return PLSVO_OK;
+}
+
+extern "C" const double* plsvo_poseopt_poses_dev(plsvo_ctx* c) { return (c && c->p_staged) ? c->p_d_poses.as<double>() : nullptr; }
+
+extern "C" int plsvo_poseopt_work(plsvo_ctx* c, uint64_t* pt_iters, uint64_t* seg_iters) {
+  CTX_CHECK(c);
+  if (!c->p_staged) return fail(c, PLSVO_E_STATE, "poseopt_work: no staged batch");
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<PoseStateDev> st((size_t)c->p_n);
+  HIP_TRY(c, hipMemcpyAsync(st.data(), c->p_d_state.p, (size_t)c->p_n * sizeof(PoseStateDev), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  uint64_t a = 0, b2 = 0;
+  for (auto& s : st) { a += s.pt_iters; b2 += s.seg_iters; }
+  if (pt_iters) *pt_iters = a;
+  if (seg_iters) *seg_iters = b2;
+  return PLSVO_OK;
+}
+
+// ---- multi-GPU gather ------------------------------------------------------------------------------
+extern "C" int plsvo_gather_poses(plsvo_ctx* c, void* rccl_comm, const double* d_local, int n_local, double* d_all) {
+  CTX_CHECK(c);
+  if (!rccl_comm || !d_local || !d_all || n_local <= 0) return fail(c, PLSVO_E_INVALID, "gather_poses: bad arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  ncclResult_t r = ncclAllGather(d_local, d_all, (size_t)n_local * 7, ncclDouble, reinterpret_cast<ncclComm_t>(rccl_comm), c->stream);
+  if (r != ncclSuccess) return fail(c, PLSVO_E_RCCL, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+  return PLSVO_OK;
+}
+
+// ---- timing ------------------------------------------------------------------------------------------
+extern "C" int plsvo_hip_set_profiling(plsvo_ctx* c, int enable) { CTX_CHECK(c); c->profiling = enable != 0; return PLSVO_OK; }
+extern "C" int plsvo_hip_kernel_time(plsvo_ctx* c, int k, double* total_ms, int64_t* launches) {
+  CTX_CHECK(c);
+  if (k < 0 || k >= PLSVO_K_COUNT) return fail(c, PLSVO_E_INVALID, "kernel_time: bad kernel family");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  prof_collect(c);
+  if (total_ms) *total_ms = c->ev_ms[k];
+  if (launches) *launches = c->ev_launches[k];
+  return PLSVO_OK;
+}
+extern "C" int plsvo_hip_reset_profiling(plsvo_ctx* c) {
+  CTX_CHECK(c);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  prof_collect(c);
+  for (int k = 0; k < PLSVO_K_COUNT; ++k) { c->ev_ms[k] = 0.0; c->ev_launches[k] = 0; }
+  return PLSVO_OK;
+}

@@ -1,0 +1,111 @@
+// plsvo_dev.hpp -- device-side data layout (HBM) shared by the kernels and the C-ABI host code.
+//
+// Layout principles (MI355X-first):
+//   * every batch is a set of flat SoA arrays; a job is an (offset, count) pair into them -- no pointers
+//     chased on the device, fully coalesced feature reads;
+//   * pyramids live in one slab: slot s, level l at base + s*slot_bytes + off[l], rows tight
+//     (stride == level width), each level 256-byte aligned, so staging a level into LDS is one
+//     linear 16-byte-per-lane copy;
+//   * per-level alignment cache (reference-patch intensity + image gradient, 3 floats per pixel, and the
+//     per-patch 3-D point) is written once per level and re-read every Gauss-Newton iteration by the
+//     same lanes in the same order (coalesced float4).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/plsvo_hip.h"
+
+namespace plsvo_hip {
+
+struct PyrDesc {
+  const uint8_t* base;
+  unsigned long long slot_bytes;
+  int n_slots, n_levels;
+  int w[PLSVO_MAX_LEVELS], h[PLSVO_MAX_LEVELS];
+  unsigned int off[PLSVO_MAX_LEVELS];
+};
+
+struct AlignJobDev {
+  int ref_slot, cur_slot;
+  double fx, fy, cx, cy;
+  int width, height;
+  int max_level, min_level, n_iter, skip;   // skip: no features at all (src/sparse_img_align.cpp:58-62)
+  double eps;
+  int pt_off, n_pts, seg_off, n_seg;        // into the batch feature arrays
+  int patch_off, patch_cap;                 // into the batch patch-cache arrays
+};
+
+struct AlignStateDev {
+  double T[7];                 // current model T_cur_from_ref
+  double chi2;                 // solver chi2_
+  unsigned long long n_meas;   // n_meas_ of the last computeResiduals
+  double H[36];                // H_ of the last computeResiduals
+  int stop;                    // solver stop_
+  int log_count;
+  int iters[PLSVO_MAX_LEVELS];
+  unsigned long long patch_levels, patch_iters;  // work counters
+  int error;                   // device-side capacity/consistency error
+  int reserved0;
+};
+
+struct AlignBatchDev {
+  const AlignJobDev* jobs;
+  AlignStateDev* state;
+  const double* T0;            // 7 per job
+  const double* pt_px;         // 2 per point
+  const double* pt_xyz;        // 3 per point
+  const double* seg_spx;       // 2 per segment
+  const double* seg_epx;
+  const double* seg_len;       // 1
+  const double* seg_p;         // 3
+  const double* seg_q;         // 3
+  const uint8_t* seg_alive_in; // 1 (may be null)
+  uint8_t* seg_alive;          // 1, working copy / result
+  // per-level patch cache (capacity = sum over jobs of patch_cap)
+  double* patch_xyz;           // 3 per patch: 3-D point in the ref frame
+  float* patch_uvref;          // 2 per patch: ref pixel position at the level (float, as Patch::setPosition)
+  float* cache_ref;            // 16 per patch: interpolated reference intensity
+  float* cache_dx;             // 16 per patch
+  float* cache_dy;             // 16 per patch
+  double* partial;             // 6 per patch: per-iteration patch sums A,B,C,D,E,chi2
+  PyrDesc pyr;
+  plsvo_align_iterlog* log;    // log_cap per job, or null
+  int log_cap;
+  int n_jobs;
+};
+
+struct PoseJobDev {
+  double T0[7];
+  double fx, reproj_thresh;
+  int n_iter, n_iter_ref;
+  int pt_off, n_pts, seg_off, n_seg;
+};
+
+struct PoseStateDev {
+  double T[7];
+  double cov[36];
+  double estimated_scale, error_init, error_final;
+  unsigned long long num_obs_pt, num_obs_ls;
+  int iters, iters_ref, status, log_count;
+  unsigned long long pt_iters, seg_iters;   // work counters
+};
+
+struct PoseBatchDev {
+  const PoseJobDev* jobs;
+  PoseStateDev* state;
+  const double* pt_f;          // 3 per point
+  const double* pt_pos;        // 3
+  const int* pt_level;
+  const double* seg_line;      // 3 per segment
+  const double* seg_spos;
+  const double* seg_epos;
+  const int* seg_level;
+  uint8_t* pt_keep;
+  uint8_t* seg_keep;
+  float* scratch_f32;          // per feature, for the float medians (errors)
+  double* scratch_f64;         // 3 per feature: chi2_vec_init (2x) and chi2_vec_final
+  plsvo_poseopt_iterlog* log;
+  int log_cap;
+  int n_jobs;
+};
+
+}  // namespace plsvo_hip

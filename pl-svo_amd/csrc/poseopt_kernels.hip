@@ -1,0 +1,370 @@
+// poseopt_kernels.hip -- motion-only pose optimisation on gfx950: one workgroup per frame, the scale
+// pass, all Gauss-Newton iterations, the covariance, the outlier cull and the medians run in ONE launch.
+//
+// Replaces (reference file:line):
+//   plsvo::pose_optimizer::optimizeGaussNewton, 9-argument   src/pose_optimizer.cpp:38-260
+//   plsvo::pose_optimizer::optimizeGaussNewton, 10-argument  src/pose_optimizer.cpp:262-582
+//   [ext] vk::robust_cost::MADScaleEstimator / TukeyWeightFunction, vk::getMedian, Eigen ldlt()/inverse()
+//
+// Work per call is tiny (hundreds of features x ~100 flops x <=10 iterations): this kernel is
+// latency-bound by construction; it exists so that a batch of frames is one launch and the pose never
+// leaves the device between the alignment and the optimisation.  One lane per feature, lane-private
+// 6x6 (upper) + 6x1 accumulators in double, fixed-shape DPP/LDS reduction, one lane solves.
+// Medians (vk::getMedian = element floor(n/2) of the sorted vector) are exact: block-wide radix
+// select over the IEEE bit patterns (all values are non-negative), 11 bits per pass.
+#include <hip/hip_runtime.h>
+
+#include "plsvo_dev.hpp"
+#include "plsvo_math.hpp"
+#include "plsvo_wave.hpp"
+
+namespace plsvo_hip {
+
+#define PO_T 256
+#define PO_RED 32
+#define PO_BINS 2048
+
+// k-th smallest (0-based) of n non-negative IEEE values given as unsigned bit patterns of BITS bits.
+// get(i) returns the pattern of element i (invalid elements must return all-ones).
+template <int BITS, typename U, typename GET>
+__device__ U block_radix_select(GET get, int n, int k, int* s_hist, int* s_sel) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  U prefix = 0, mask = 0;
+  int shift = BITS;
+  while (shift > 0) {
+    const int bits = shift >= 11 ? 11 : shift;
+    shift -= bits;
+    const int nb = 1 << bits;
+    for (int i = tid; i < PO_BINS; i += PO_T) s_hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += PO_T) {
+      const U v = get(i);
+      if ((v & mask) == prefix) atomicAdd(&s_hist[(int)((v >> shift) & (U)(nb - 1))], 1);
+    }
+    __syncthreads();
+    // block scan over the bins: each thread owns PO_BINS/PO_T consecutive bins
+    constexpr int PER = PO_BINS / PO_T;
+    int loc[PER]; int local = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { loc[j] = s_hist[tid * PER + j]; local += loc[j]; }
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+    if (lane == 63) s_sel[4 + wave] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += s_sel[4 + w];
+    int cum = wave_off + incl - local;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      if (k >= cum && k < cum + loc[j]) { s_sel[0] = tid * PER + j; s_sel[1] = k - cum; }
+      cum += loc[j];
+    }
+    __syncthreads();
+    prefix |= ((U)s_sel[0]) << shift;
+    mask |= ((U)(nb - 1)) << shift;
+    k = s_sel[1];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+// LDS roles: s_red PO_RED*(PO_T/64) doubles; s_pose 0..8 R, 9..11 t, 12..18 model, 19..25 T_old, 26 chi2;
+// s_ctl[0] break flag
+
+// one GN loop (src/pose_optimizer.cpp:103-195 and the identical text at :469-563)
+__device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseStateDev* st, int job_id, double* s_red,
+                             double* s_pose, int* s_ctl, int n_iter, int phase, double scale_pt, double scale_ls,
+                             double* init_vec, double* s_tot) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int np = job.n_pts, ns = job.n_seg, nf = np + ns;
+  for (int iter = 0; iter < n_iter; ++iter) {
+    double aH[21], aB[6], aChi = 0.0;
+#pragma unroll
+    for (int k = 0; k < 21; ++k) aH[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) aB[k] = 0.0;
+    int cpt = 0, cls = 0;
+    const double R0 = s_pose[0], R1 = s_pose[1], R2 = s_pose[2], R3 = s_pose[3], R4 = s_pose[4], R5 = s_pose[5],
+                 R6 = s_pose[6], R7 = s_pose[7], R8 = s_pose[8], t0 = s_pose[9], t1 = s_pose[10], t2 = s_pose[11];
+    for (int f = tid; f < nf; f += PO_T) {
+      double J[12], e0, e1, weight;
+      if (f < np) {
+        const int i = job.pt_off + f;
+        if (!b.pt_keep[i]) continue;
+        const double x = b.pt_pos[3 * i], y = b.pt_pos[3 * i + 1], z = b.pt_pos[3 * i + 2];
+        const double xyz[3] = { R0 * x + R1 * y + R2 * z + t0, R3 * x + R4 * y + R5 * z + t1, R6 * x + R7 * y + R8 * z + t2 };
+        jacobian_xyz2uv(xyz, J);
+        const double fz = b.pt_f[3 * i + 2];
+        e0 = b.pt_f[3 * i] / fz - xyz[0] / xyz[2];
+        e1 = b.pt_f[3 * i + 1] / fz - xyz[1] / xyz[2];
+        const double sic = 1.0 / (double)(1 << b.pt_level[i]);
+        e0 *= sic; e1 *= sic;
+        if (iter == 0) init_vec[f] = e0 * e0 + e1 * e1;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) J[k] *= sic;
+        weight = (double)tukey_weight((float)(sqrt(e0 * e0 + e1 * e1) / scale_pt));
+        ++cpt;
+      } else {
+        const int s = job.seg_off + (f - np);
+        if (!b.seg_keep[s]) continue;
+        double Js[12], Je[12];
+        const double sx = b.seg_spos[3 * s], sy = b.seg_spos[3 * s + 1], sz = b.seg_spos[3 * s + 2];
+        const double ex = b.seg_epos[3 * s], ey = b.seg_epos[3 * s + 1], ez = b.seg_epos[3 * s + 2];
+        const double xs[3] = { R0 * sx + R1 * sy + R2 * sz + t0, R3 * sx + R4 * sy + R5 * sz + t1, R6 * sx + R7 * sy + R8 * sz + t2 };
+        const double xe[3] = { R0 * ex + R1 * ey + R2 * ez + t0, R3 * ex + R4 * ey + R5 * ez + t1, R6 * ex + R7 * ey + R8 * ez + t2 };
+        jacobian_xyz2uv(xs, Js);
+        jacobian_xyz2uv(xe, Je);
+        const double l0 = b.seg_line[3 * s], l1 = b.seg_line[3 * s + 1], l2 = b.seg_line[3 * s + 2];
+        const float ds = (float)(l0 * (xs[0] / xs[2]) + l1 * (xs[1] / xs[2]) + l2 * 1.0);
+        const float de = (float)(l0 * (xe[0] / xe[2]) + l1 * (xe[1] / xe[2]) + l2 * 1.0);
+        const double sic = 1.0 / (double)(1 << b.seg_level[s]);
+        e0 = (double)ds * sic; e1 = (double)de * sic;
+        if (iter == 0) init_vec[f] = e0 * e0 + e1 * e1;
+        const double en = sqrt(e0 * e0 + e1 * e1);
+        const double ks = sic * (double)ds / en;  // same factor for both rows (:156-157)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          J[c] = l0 * (Js[c] * ks) + l1 * (Js[6 + c] * ks);
+          J[6 + c] = l0 * (Je[c] * ks) + l1 * (Je[6 + c] * ks);
+        }
+        weight = (double)tukey_weight((float)(en / scale_ls));
+        ++cls;
+      }
+      int k = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int jj = i; jj < 6; ++jj) { aH[k] += (J[i] * J[jj] + J[6 + i] * J[6 + jj]) * weight; ++k; }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) aB[i] -= (J[i] * e0 + J[6 + i] * e1) * weight;
+      aChi += (e0 * e0 + e1 * e1) * weight;
+    }
+    {
+      double* dst = s_red + PO_RED * wave;
+#pragma unroll
+      for (int k = 0; k < 21; ++k) { const double v = wave_sum_to_lane63(aH[k]); if (lane == 63) dst[k] = v; }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { const double v = wave_sum_to_lane63(aB[k]); if (lane == 63) dst[21 + k] = v; }
+      { const double v = wave_sum_to_lane63(aChi); if (lane == 63) dst[27] = v; }
+      { const double v = wave_sum_to_lane63((double)cpt); if (lane == 63) dst[28] = v; }
+      { const double v = wave_sum_to_lane63((double)cls); if (lane == 63) dst[29] = v; }
+    }
+    __syncthreads();
+    if (tid < 30) { double v = 0.0; for (int w = 0; w < PO_T / 64; ++w) v += s_red[PO_RED * w + tid]; s_tot[tid] = v; }
+    __syncthreads();
+    if (wave == 0) {
+      double dT[6];
+      wave_solve6(s_tot, dT);                                                // A.ldlt().solve(b) :170
+      if (lane == 0) {
+        s_pose[27] += s_tot[28]; s_pose[28] += s_tot[29];
+        s_ctl[1 + phase] += 1;
+        const double new_chi2 = s_tot[27];
+        SE3d model = se3_load(s_pose + 12);
+        int accepted = 1, brk = 0;
+        if ((iter > 0 && new_chi2 > s_pose[26]) || isnan(dT[0])) {          // :173-180
+          model = se3_load(s_pose + 19); accepted = 0; brk = 1;
+        } else {
+          const SE3d Tn = se3_mul(se3_exp(dT), model);                       // :183 left update
+          se3_store(model, s_pose + 19);
+          model = Tn; s_pose[26] = new_chi2;
+          if (norm_max6(dT) <= 0.0000000001) brk = 1;                        // EPS, global.h:99
+        }
+        se3_store(model, s_pose + 12);
+        quat_to_matrix(model.q, s_pose); s_pose[9] = model.t[0]; s_pose[10] = model.t[1]; s_pose[11] = model.t[2];
+        s_ctl[0] = brk;
+        if (b.log) {
+          const int lc = st->log_count;
+          if (lc < b.log_cap) {
+            plsvo_poseopt_iterlog* r = b.log + (size_t)job_id * b.log_cap + lc;
+            r->phase = phase; r->iter = iter; r->accepted = accepted; r->reserved0 = 0; r->new_chi2 = new_chi2;
+            for (int i = 0; i < 6; ++i) for (int jj = 0; jj < 6; ++jj) r->A[i * 6 + jj] = s_tot[sym6_index(i, jj)];
+            for (int k = 0; k < 6; ++k) { r->b[k] = s_tot[21 + k]; r->dT[k] = dT[k]; }
+            se3_store(model, r->T_after);
+          }
+          st->log_count = lc + 1;
+        }
+      }
+    }
+    __syncthreads();
+    if (s_ctl[0]) break;
+  }
+}
+
+__global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b) {
+  const int job_id = blockIdx.x;
+  const PoseJobDev job = b.jobs[job_id];
+  PoseStateDev* st = b.state + job_id;
+  const int tid = threadIdx.x;
+  const int np = job.n_pts, ns = job.n_seg, nf = np + ns;
+
+  __shared__ double s_red[PO_RED * (PO_T / 64)];
+  __shared__ double s_pose[32];   // 27: point-iterations, 28: line-iterations
+  __shared__ double s_tot[32];
+  __shared__ int s_ctl[32];
+  __shared__ int s_hist[PO_BINS];
+  __shared__ int s_sel[16];
+
+  // scratch: floats [0,np) point errors, [np, np+ns) line errors; doubles [0,nf) init (first loop),
+  // [nf,2nf) init (refinement), [2nf,3nf) final
+  const size_t fbase = (size_t)job.pt_off + (size_t)job.seg_off;
+  float* errs = b.scratch_f32 + fbase;
+  double* vec = b.scratch_f64 + 3 * fbase;
+
+  if (tid == 0) {
+    SE3d m = se3_load(job.T0);
+    se3_store(m, s_pose + 12); se3_store(m, s_pose + 19); s_pose[26] = 0.0; s_pose[27] = 0.0; s_pose[28] = 0.0;
+    for (int k = 0; k < 32; ++k) s_tot[k] = 0.0;
+    quat_to_matrix(m.q, s_pose); s_pose[9] = m.t[0]; s_pose[10] = m.t[1]; s_pose[11] = m.t[2];
+    s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0;
+    st->log_count = 0; st->status = 0; st->iters = 0; st->iters_ref = 0; st->pt_iters = 0; st->seg_iters = 0;
+    st->num_obs_pt = 0; st->num_obs_ls = 0; st->estimated_scale = 0; st->error_init = 0; st->error_final = 0;
+    for (int k = 0; k < 36; ++k) st->cov[k] = 0.0;
+    for (int k = 0; k < 7; ++k) st->T[k] = job.T0[k];
+  }
+  for (int i = tid; i < np; i += PO_T) b.pt_keep[job.pt_off + i] = 1;
+  for (int s = tid; s < ns; s += PO_T) b.seg_keep[job.seg_off + s] = 1;
+  __syncthreads();
+  if (nf == 0) { if (tid == 0) st->status = 1; return; }                      // errors.empty() :88-89
+
+  // ---- scale pass :57-95 ----
+  {
+    const double R0 = s_pose[0], R1 = s_pose[1], R2 = s_pose[2], R3 = s_pose[3], R4 = s_pose[4], R5 = s_pose[5],
+                 R6 = s_pose[6], R7 = s_pose[7], R8 = s_pose[8], t0 = s_pose[9], t1 = s_pose[10], t2 = s_pose[11];
+    for (int f = tid; f < nf; f += PO_T) {
+      if (f < np) {
+        const int i = job.pt_off + f;
+        const double x = b.pt_pos[3 * i], y = b.pt_pos[3 * i + 1], z = b.pt_pos[3 * i + 2];
+        const double xc = R0 * x + R1 * y + R2 * z + t0, yc = R3 * x + R4 * y + R5 * z + t1, zc = R6 * x + R7 * y + R8 * z + t2;
+        const double fz = b.pt_f[3 * i + 2];
+        double e0 = b.pt_f[3 * i] / fz - xc / zc, e1 = b.pt_f[3 * i + 1] / fz - yc / zc;
+        const double sic = 1.0 / (double)(1 << b.pt_level[i]);
+        e0 *= sic; e1 *= sic;
+        errs[f] = (float)sqrt(e0 * e0 + e1 * e1);
+      } else {
+        const int s = job.seg_off + (f - np);
+        const double sx = b.seg_spos[3 * s], sy = b.seg_spos[3 * s + 1], sz = b.seg_spos[3 * s + 2];
+        const double ex = b.seg_epos[3 * s], ey = b.seg_epos[3 * s + 1], ez = b.seg_epos[3 * s + 2];
+        const double xs0 = R0 * sx + R1 * sy + R2 * sz + t0, xs1 = R3 * sx + R4 * sy + R5 * sz + t1, xs2 = R6 * sx + R7 * sy + R8 * sz + t2;
+        const double xe0 = R0 * ex + R1 * ey + R2 * ez + t0, xe1 = R3 * ex + R4 * ey + R5 * ez + t1, xe2 = R6 * ex + R7 * ey + R8 * ez + t2;
+        const double l0 = b.seg_line[3 * s], l1 = b.seg_line[3 * s + 1], l2 = b.seg_line[3 * s + 2];
+        const float es = (float)(l0 * (xs0 / xs2) + l1 * (xs1 / xs2) + l2 * 1.0);   // not scaled by the level (:84-87)
+        const float ee = (float)(l0 * (xe0 / xe2) + l1 * (xe1 / xe2) + l2 * 1.0);
+        errs[f] = sqrtf(__fadd_rn(__fmul_rn(es, es), __fmul_rn(ee, ee)));
+      }
+    }
+  }
+  __syncthreads();
+  // MAD scale = 1.48f * median (float).  Zero points: the reference is undefined (:70); we define 1.0.
+  double scale_pt = 1.0, scale_ls = 1.0;
+  if (np > 0) {
+    const uint32_t bits = block_radix_select<32, uint32_t>([&](int i) { return (uint32_t)__float_as_uint(errs[i]); }, np, np / 2, s_hist, s_sel);
+    scale_pt = (double)__fmul_rn(1.48f, __uint_as_float(bits));
+  }
+  if (ns > 0) {
+    const uint32_t bits = block_radix_select<32, uint32_t>([&](int i) { return (uint32_t)__float_as_uint(errs[np + i]); }, ns, ns / 2, s_hist, s_sel);
+    scale_ls = (double)__fmul_rn(1.48f, __uint_as_float(bits));
+  }
+
+  // ---- first GN loop ----
+  if (job.n_iter <= 0) for (int f = tid; f < nf; f += PO_T) vec[f] = __longlong_as_double(0x7ff0000000000000LL);
+  popt_gn_loop(b, job, st, job_id, s_red, s_pose, s_ctl, job.n_iter, 0, scale_pt, scale_ls, vec, s_tot);
+
+  // ---- covariance :197-199 (from the last assembled A, even if that iteration was rolled back) ----
+  if (tid == 0) {
+    double Af[36];
+    const double f2 = job.fx * job.fx;
+    for (int i = 0; i < 6; ++i) for (int jj = 0; jj < 6; ++jj) Af[i * 6 + jj] = s_tot[sym6_index(i, jj)] * f2;
+    inv6(Af, st->cov);
+  }
+
+  // ---- cull :201-242 ----
+  const double thr_pt = job.reproj_thresh / job.fx;
+  const double thr_ls = thr_pt * scale_ls / scale_pt;
+  int del_pt = 0, del_ls = 0;
+  {
+    const double R0 = s_pose[0], R1 = s_pose[1], R2 = s_pose[2], R3 = s_pose[3], R4 = s_pose[4], R5 = s_pose[5],
+                 R6 = s_pose[6], R7 = s_pose[7], R8 = s_pose[8], t0 = s_pose[9], t1 = s_pose[10], t2 = s_pose[11];
+    for (int f = tid; f < nf; f += PO_T) {
+      double e0, e1;
+      if (f < np) {
+        const int i = job.pt_off + f;
+        const double x = b.pt_pos[3 * i], y = b.pt_pos[3 * i + 1], z = b.pt_pos[3 * i + 2];
+        const double xc = R0 * x + R1 * y + R2 * z + t0, yc = R3 * x + R4 * y + R5 * z + t1, zc = R6 * x + R7 * y + R8 * z + t2;
+        const double fz = b.pt_f[3 * i + 2];
+        e0 = b.pt_f[3 * i] / fz - xc / zc; e1 = b.pt_f[3 * i + 1] / fz - yc / zc;
+        const double sic = 1.0 / (double)(1 << b.pt_level[i]);
+        e0 *= sic; e1 *= sic;
+        if (sqrt(e0 * e0 + e1 * e1) > thr_pt) { b.pt_keep[i] = 0; ++del_pt; }
+      } else {
+        const int s = job.seg_off + (f - np);
+        const double sx = b.seg_spos[3 * s], sy = b.seg_spos[3 * s + 1], sz = b.seg_spos[3 * s + 2];
+        const double ex = b.seg_epos[3 * s], ey = b.seg_epos[3 * s + 1], ez = b.seg_epos[3 * s + 2];
+        const double xs0 = R0 * sx + R1 * sy + R2 * sz + t0, xs1 = R3 * sx + R4 * sy + R5 * sz + t1, xs2 = R6 * sx + R7 * sy + R8 * sz + t2;
+        const double xe0 = R0 * ex + R1 * ey + R2 * ez + t0, xe1 = R3 * ex + R4 * ey + R5 * ez + t1, xe2 = R6 * ex + R7 * ey + R8 * ez + t2;
+        const double l0 = b.seg_line[3 * s], l1 = b.seg_line[3 * s + 1], l2 = b.seg_line[3 * s + 2];
+        const double sic = 1.0 / (double)(1 << b.seg_level[s]);
+        e0 = (l0 * (xs0 / xs2) + l1 * (xs1 / xs2) + l2 * 1.0) * sic;     // doubles here, no float truncation (:229)
+        e1 = (l0 * (xe0 / xe2) + l1 * (xe1 / xe2) + l2 * 1.0) * sic;
+        if (sqrt(e0 * e0 + e1 * e1) > thr_ls) { b.seg_keep[s] = 0; ++del_ls; }
+      }
+      vec[2 * nf + f] = e0 * e0 + e1 * e1;
+      vec[nf + f] = __longlong_as_double(0x7ff0000000000000LL);  // +inf sentinel for the refinement's init entries
+    }
+  }
+  // deleted counts -> thread 0
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    const double a = wave_sum_to_lane63((double)del_pt), c = wave_sum_to_lane63((double)del_ls);
+    __syncthreads();
+    if (lane == 63) { s_red[PO_RED * wave] = a; s_red[PO_RED * wave + 1] = c; }
+    __syncthreads();
+  }
+  int n_del_pt = 0, n_del_ls = 0;
+  for (int w = 0; w < PO_T / 64; ++w) { n_del_pt += (int)(s_red[PO_RED * w] + 0.5); n_del_ls += (int)(s_red[PO_RED * w + 1] + 0.5); }
+  __syncthreads();
+
+  // ---- refinement with inliers :469-563 (10-argument overload) ----
+  int n_init = job.n_iter > 0 ? nf : 0;
+  if (job.n_iter_ref >= 0) {
+    popt_gn_loop(b, job, st, job_id, s_red, s_pose, s_ctl, job.n_iter_ref, 1, scale_pt, scale_ls, vec + nf, s_tot);
+    if (job.n_iter_ref > 0) n_init += nf - n_del_pt - n_del_ls;
+  }
+  __syncthreads();
+
+  // ---- medians :244-249 ----
+  unsigned long long mi = 0;
+  if (n_init > 0)
+    mi = block_radix_select<64, unsigned long long>(
+        [&](int i) { return (unsigned long long)__double_as_longlong(vec[i]); }, 2 * nf, n_init / 2, s_hist, s_sel);
+  const unsigned long long mf = block_radix_select<64, unsigned long long>(
+      [&](int i) { return (unsigned long long)__double_as_longlong(vec[2 * nf + i]); }, nf, nf / 2, s_hist, s_sel);
+  if (tid == 0) {
+    for (int k = 0; k < 7; ++k) st->T[k] = s_pose[12 + k];
+    st->error_init = sqrt(__longlong_as_double((long long)mi)) * job.fx;
+    st->error_final = sqrt(__longlong_as_double((long long)mf)) * job.fx;
+    st->estimated_scale = scale_pt * job.fx;
+    st->num_obs_pt = (unsigned long long)(np - n_del_pt);
+    st->num_obs_ls = (unsigned long long)(ns - n_del_ls);
+    st->iters = s_ctl[1]; st->iters_ref = s_ctl[2];
+    st->pt_iters = (unsigned long long)(s_pose[27] + 0.5); st->seg_iters = (unsigned long long)(s_pose[28] + 0.5);
+  }
+}
+
+__global__ void pose_finish_kernel(PoseBatchDev b, double* poses) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= b.n_jobs) return;
+  for (int k = 0; k < 7; ++k) poses[7 * j + k] = b.state[j].T[k];
+}
+
+hipError_t launch_pose_finish(const PoseBatchDev& b, double* d_poses, hipStream_t stream) {
+  hipLaunchKernelGGL(pose_finish_kernel, dim3((b.n_jobs + 63) / 64), dim3(64), 0, stream, b, d_poses);
+  return hipGetLastError();
+}
+
+hipError_t launch_pose_opt(const PoseBatchDev& b, hipStream_t stream) {
+  hipLaunchKernelGGL(pose_opt_kernel, dim3(b.n_jobs), dim3(PO_T), 0, stream, b);
+  return hipGetLastError();
+}
+
+}  // namespace plsvo_hip
