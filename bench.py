@@ -1,0 +1,194 @@
+"""bench.py -- sparse-align + pose-opt frames/sec on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of B independent synthetic streams resident in HBM:
+  plsvo::SparseImgAlign::run (3 pyramid levels, <=30 GN iterations each) followed by
+  plsvo::pose_optimizer::optimizeGaussNewton (<=10 iterations), per stream, through the C ABI.
+Workload = BASELINE.json configs[1]: 640x480, 200 points + 80 line segments, 4-image pyramid
+(alignment levels 3..1).  Per-GPU batch is fixed as N grows ("weak" scaling); streams are independent, so
+ranks exchange nothing on the data path -- the only collective is the RCCL all-gather of the per-stream
+result poses (7 doubles each), once per step.
+
+  python bench.py --gpus 1 --steps K --warmup W            (single process)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_PATCH_LEVEL = 497     # precompute, per patch-level
+BYTES_PER_PATCH_ITER = 485      # residual/Jacobian, per patch-iteration
+W, H = 640, 480
+N_PTS, N_SEG = 200, 80
+N_PYR, MAX_LEVEL, MIN_LEVEL = 4, 3, 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PLSVO_BENCH_BATCH", "2048")), help="streams per GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    P = importlib.import_module("pl-svo_amd")
+    capi, synth, abi = P.capi, P.synth, P.abi
+    B = args.batch
+
+    # every launch goes on torch's current stream, so torch.cuda.synchronize()/events/RCCL see it
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ctx = capi.Context(local_rank, stream=stream)
+
+    # ---- synthetic inputs, generated in HBM (untimed) ----
+    seed0 = 1234 + rank * B
+    streams = [synth.make_align_stream(seed0 + i, W, H, N_PTS, N_SEG, max_level=MAX_LEVEL) for i in range(B)]
+    ctx.config_pyramids(2 * B, W, H, N_PYR)
+    chunk = 256
+    for c0 in range(0, B, chunk):
+        sub = streams[c0:c0 + chunk]
+        imgs = synth.render_streams(sub, device=dev)                      # [b, 2, H, W] u8 in HBM
+        ctx.build_pyramids_dev(2 * c0, 2 * len(sub), imgs.data_ptr(), W, W * H, 0)   # device half-sampler
+        ctx.synchronize()
+        del imgs
+    align_jobs = [P.align_job_from_stream(s, MAX_LEVEL, MIN_LEVEL, ref_slot=2 * i, cur_slot=2 * i + 1) for i, s in enumerate(streams)]
+    pose_frames = [synth.make_poseopt_frame(seed0 + i, N_PTS, N_SEG, W, H) for i in range(B)]
+    pose_jobs = [P.poseopt_job_from_frame(f) for f in pose_frames]
+    ctx.align_stage(align_jobs)      # features + job descriptors -> HBM; the timed region only launches kernels
+    ctx.poseopt_stage(pose_jobs)
+    ctx.synchronize()
+
+    gathered = None
+    local_poses = None
+    if world > 1:
+        local_poses = torch.empty((B, 7), dtype=torch.float64, device=dev)
+        gathered = torch.empty((world * B, 7), dtype=torch.float64, device=dev)
+
+    def step():
+        ctx.align_run()
+        ctx.poseopt_run()
+        if world > 1:
+            ctx.poseopt_copy_poses(local_poses.data_ptr())        # final per-stream poses, device to device
+            dist.all_gather_into_tensor(gathered, local_poses)   # RCCL over xGMI: the only collective
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+
+    ctx.set_profiling(True)
+    ctx.reset_profiling()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    ctx.set_profiling(False)
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (align_level_kernel), from live hipEvent timings ----
+    lvl_ms, lvl_launches = ctx.kernel_time(abi.K_ALIGN_LEVEL)
+    pose_ms, pose_launches = ctx.kernel_time(abi.K_POSEOPT)
+    patch_levels, patch_iters = ctx.align_work()       # counted on the device, per run of the staged batch
+    alg_bytes_per_step = patch_levels * BYTES_PER_PATCH_LEVEL + patch_iters * BYTES_PER_PATCH_ITER
+    launches_per_step = max(lvl_launches // max(args.steps, 1), 1)
+    avg_launch_ms = lvl_ms / max(lvl_launches, 1)
+    achieved = (alg_bytes_per_step / launches_per_step) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("align_level_kernel_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    res = ctx.align_fetch()
+    pres = ctx.poseopt_fetch()
+    result = None
+    if rank == 0:
+        frames = world * B * args.steps
+        value = frames / elapsed
+        errs = np.array([synth.se3_log_angle_dist(r.T, s.T_true) for r, s in zip(res[:64], streams[:64])])
+        result = {
+            "metric": "sparse-align+pose-opt frames/sec, 640x480, ~200 pts+80 lines",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 640x480, 200 points + 80 line segments, 4-image pyramid (levels 3..1), "
+                                   "sparse_img_align (<=30 GN it/level) + pose_optimizer (<=10 it, Tukey/MAD)",
+                       "streams_per_gpu": B, "global_batch": world * B,
+                       "parallelism": f"streams sharded x{world}, RCCL all-gather of poses" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "kernel": "align_level_kernel", "avg_launch_ms": round(avg_launch_ms, 4),
+                         "launches": int(lvl_launches), "algorithmic_bytes_per_launch": int(alg_bytes_per_step // launches_per_step),
+                         "patch_levels_per_step": int(patch_levels), "patch_iters_per_step": int(patch_iters)},
+            "kernel_ms_per_step": {"align_level": round(lvl_ms / args.steps, 4), "pose_opt": round(pose_ms / args.steps, 4)},
+            "accuracy_vs_truth": {"median_rot_rad": float(np.median(errs[:, 0])), "median_trans_m": float(np.median(errs[:, 1]))},
+        }
+        # ---- CPU baseline: the oracle (single thread) on a bounded sample of the same streams ----
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import binding as ob
+            ob.build()
+            n_s = min(B, 64)
+            pyrs = [(ctx.download_pyramid(2 * i), ctx.download_pyramid(2 * i + 1)) for i in range(n_s)]
+            for i in range(min(4, n_s)):   # warm-up, and a parity spot check of the timed batch against the oracle
+                ro, _ = ob.sparse_align(align_jobs[i], pyrs[i][0], pyrs[i][1])
+                ang, dist_ = synth.se3_log_angle_dist(ro.T, res[i].T)
+                po, _ = ob.pose_optimize(pose_jobs[i])
+                ang2, dist2 = synth.se3_log_angle_dist(po.T, pres[i].T)
+                assert ang < 1e-4 and ang2 < 1e-4, "bench batch disagrees with the oracle"
+            done, tc0 = 0, time.perf_counter()
+            while time.perf_counter() - tc0 < args.cpu_seconds:
+                i = done % n_s
+                ob.sparse_align(align_jobs[i], pyrs[i][0], pyrs[i][1])
+                ob.pose_optimize(pose_jobs[i])
+                done += 1
+            tc = time.perf_counter() - tc0
+            result["cpu_baseline"] = {"value": round(done / tc, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                                      "sample": f"{done} frames (cycling over the first {n_s} streams of the timed batch) in {tc:.1f} s, "
+                                                f"oracle/libplsvo_oracle.so single thread, python ctypes call overhead included"}
+            result["speedup_vs_cpu_1core"] = round(value / (done / tc), 1)
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

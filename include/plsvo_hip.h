@@ -170,6 +170,8 @@ int plsvo_align_fetch_trace(plsvo_ctx* ctx, int job, plsvo_align_iterlog* out, i
 
 /* device pointer to the staged batch's result poses, n*7 doubles (for a device-side gather) */
 const double* plsvo_align_poses_dev(plsvo_ctx* ctx);
+/* enqueue a device-to-device copy of those n*7 doubles into caller-owned HBM (e.g. a torch tensor) */
+int plsvo_align_copy_poses(plsvo_ctx* ctx, double* d_dst);
 
 /* work counters of the last plsvo_align_run (for the roofline accounting):
  *   patch_levels = sum over jobs and levels of patches precomputed (497 B each)
@@ -235,6 +237,7 @@ int plsvo_poseopt_set_trace(plsvo_ctx* ctx, int max_records_per_job);
 int plsvo_poseopt_fetch_trace(plsvo_ctx* ctx, int job, plsvo_poseopt_iterlog* out, int max_records,
                               int* n_records);
 const double* plsvo_poseopt_poses_dev(plsvo_ctx* ctx);
+int plsvo_poseopt_copy_poses(plsvo_ctx* ctx, double* d_dst);
 /* feature-iterations of the last run: points (24 B each) and lines (40 B each), SURVEY 8d */
 int plsvo_poseopt_work(plsvo_ctx* ctx, uint64_t* pt_iters, uint64_t* seg_iters);
 

@@ -19,9 +19,9 @@ SYMBOLS = [
     "plsvo_hip_config_pyramids", "plsvo_hip_upload_pyramid", "plsvo_hip_build_pyramid", "plsvo_hip_build_pyramids_dev",
     "plsvo_hip_download_level",
     "plsvo_sparse_align", "plsvo_sparse_align_batch", "plsvo_align_stage", "plsvo_align_run", "plsvo_align_fetch",
-    "plsvo_align_set_trace", "plsvo_align_fetch_trace", "plsvo_align_poses_dev", "plsvo_align_work",
+    "plsvo_align_set_trace", "plsvo_align_fetch_trace", "plsvo_align_poses_dev", "plsvo_align_copy_poses", "plsvo_align_work",
     "plsvo_pose_optimize", "plsvo_pose_optimize_batch", "plsvo_poseopt_stage", "plsvo_poseopt_run", "plsvo_poseopt_fetch",
-    "plsvo_poseopt_set_trace", "plsvo_poseopt_fetch_trace", "plsvo_poseopt_poses_dev", "plsvo_poseopt_work",
+    "plsvo_poseopt_set_trace", "plsvo_poseopt_fetch_trace", "plsvo_poseopt_poses_dev", "plsvo_poseopt_copy_poses", "plsvo_poseopt_work",
     "plsvo_gather_poses",
     "plsvo_hip_set_profiling", "plsvo_hip_kernel_time", "plsvo_hip_reset_profiling",
     "plsvo_hip_version", "plsvo_hip_device_info",
@@ -67,6 +67,8 @@ def lib():
         "plsvo_align_set_trace": (C.c_int, [ctxp, C.c_int]),
         "plsvo_align_fetch_trace": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.AlignIterLog), C.c_int, C.POINTER(C.c_int)]),
         "plsvo_align_poses_dev": (vp, [ctxp]),
+        "plsvo_align_copy_poses": (C.c_int, [ctxp, vp]),
+        "plsvo_poseopt_copy_poses": (C.c_int, [ctxp, vp]),
         "plsvo_align_work": (C.c_int, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "plsvo_pose_optimize": (C.c_int, [ctxp, C.POINTER(abi.PoseOptIn), C.POINTER(abi.PoseOptOut)]),
         "plsvo_pose_optimize_batch": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.PoseOptIn), C.POINTER(abi.PoseOptOut)]),
@@ -223,6 +225,12 @@ class Context:
 
     def align_poses_dev(self):
         return self.L.plsvo_align_poses_dev(self.h)
+
+    def align_copy_poses(self, d_dst):
+        self._chk(self.L.plsvo_align_copy_poses(self.h, C.c_void_p(d_dst)))
+
+    def poseopt_copy_poses(self, d_dst):
+        self._chk(self.L.plsvo_poseopt_copy_poses(self.h, C.c_void_p(d_dst)))
 
     # ---- pose optimisation ----
     def poseopt_set_trace(self, max_records):

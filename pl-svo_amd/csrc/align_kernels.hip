@@ -67,6 +67,21 @@ __device__ __forceinline__ float bilinear(float wTL, float wTR, float wBL, float
   return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(wTL, a), __fmul_rn(wTR, b)), __fmul_rn(wBL, c)), __fmul_rn(wBR, d));
 }
 
+// (float)(1.0 / (1.0 + (double)a)) for a float a >= 0 -- the reference's robust weight
+// (src/sparse_img_align.cpp:479) -- without a double division: 1 + a is split exactly into s_hi + s_lo
+// (two-sum), y0 = rcp(s_hi), the exact residual e = 1 - s_hi*y0 comes from one fma, and
+// y0 + y0*(e - s_lo*y0) is the quotient to ~1e-14 relative before the final rounding, i.e. the correctly
+// rounded float except when the quotient sits within ~1e-7 ulp of a rounding boundary.
+__device__ __forceinline__ float robust_weight(float a) {
+  const float s_hi = __fadd_rn(1.0f, a);
+  const float bv = __fsub_rn(s_hi, 1.0f);
+  const float s_lo = __fadd_rn(__fsub_rn(1.0f, __fsub_rn(s_hi, bv)), __fsub_rn(a, bv));  // exact: (1 + a) - s_hi
+  const float y0 = __builtin_amdgcn_rcpf(s_hi);
+  const float e = __fmaf_rn(-s_hi, y0, 1.0f);
+  const float c = __fmaf_rn(-s_lo, y0, e);
+  return __fmaf_rn(y0, c, y0);
+}
+
 // Patch::setPosition + computeInterpWeights (src/feature.cpp:189-208): position as float, weights
 // computed in double and stored as float
 struct PatchW { int ui, vi; float wTL, wTR, wBL, wBR; };
@@ -352,7 +367,7 @@ __global__ __launch_bounds__(T) void align_level_kernel(AlignBatchDev b, int lev
             const float res = __fsub_rn(cur, pr[x]);
             const float ares = fabsf(res);
             // points: w = 1/(1+|r|) (:479); line pixels are accumulated unweighted (:627-629)
-            const float w = is_point ? __builtin_amdgcn_rcpf(__fadd_rn(1.0f, ares)) : 1.0f;
+            const float w = is_point ? robust_weight(ares) : 1.0f;
             const double wd = (double)w, rd = (double)res, dx = (double)pxp[x], dy = (double)pyp[x];
             const double wdx = wd * dx, wdy = wd * dy;
             sA += wdx * dx; sB += wdx * dy; sC += wdy * dy;

@@ -521,6 +521,14 @@ extern "C" int plsvo_align_fetch_trace(plsvo_ctx* c, int job, plsvo_align_iterlo
 
 extern "C" const double* plsvo_align_poses_dev(plsvo_ctx* c) { return (c && c->a_staged) ? c->a_d_poses.as<double>() : nullptr; }
 
+extern "C" int plsvo_align_copy_poses(plsvo_ctx* c, double* d_dst) {
+  CTX_CHECK(c);
+  if (!c->a_staged || !d_dst) return fail(c, PLSVO_E_STATE, "align_copy_poses: no staged batch / null destination");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(d_dst, c->a_d_poses.p, (size_t)c->a_n * 7 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return PLSVO_OK;
+}
+
 extern "C" int plsvo_align_work(plsvo_ctx* c, uint64_t* patch_levels, uint64_t* patch_iters) {
   CTX_CHECK(c);
   if (!c->a_staged) return fail(c, PLSVO_E_STATE, "align_work: no staged batch");
@@ -672,6 +680,14 @@ extern "C" int plsvo_poseopt_fetch_trace(plsvo_ctx* c, int job, plsvo_poseopt_it
 }
 
 extern "C" const double* plsvo_poseopt_poses_dev(plsvo_ctx* c) { return (c && c->p_staged) ? c->p_d_poses.as<double>() : nullptr; }
+
+extern "C" int plsvo_poseopt_copy_poses(plsvo_ctx* c, double* d_dst) {
+  CTX_CHECK(c);
+  if (!c->p_staged || !d_dst) return fail(c, PLSVO_E_STATE, "poseopt_copy_poses: no staged batch / null destination");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(d_dst, c->p_d_poses.p, (size_t)c->p_n * 7 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return PLSVO_OK;
+}
 
 extern "C" int plsvo_poseopt_work(plsvo_ctx* c, uint64_t* pt_iters, uint64_t* seg_iters) {
   CTX_CHECK(c);
