@@ -1,0 +1,27 @@
+"""Summarise a rocprofv3 rocpd database (…_results.db) into a small CSV for profiles/.
+usage: python tools/rocpd_summary.py <results.db> <out.csv> "<command line that was profiled>" """
+import sqlite3
+import sys
+
+
+def main(db, out, cmd):
+    c = sqlite3.connect(db)
+    lines = [f"# rocprofv3 --kernel-trace --stats -- {cmd}",
+             "# extracted from the rocpd database (view `kernels`); durations in microseconds", "",
+             "## per-kernel totals (plsvo kernels only; torch kernels in the same process generate the synthetic inputs)",
+             "name,calls,total_us,avg_us,min_us,max_us"]
+    q = ("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+         "where name like '%plsvo%' group by name order by sum(duration) desc")
+    for r in c.execute(q):
+        lines.append(f"\"{r[0]}\",{r[1]},{r[2] / 1e3:.1f},{r[3] / 1e3:.1f},{r[4] / 1e3:.1f},{r[5] / 1e3:.1f}")
+    lines += ["", "## every align_level_kernel / pose_opt_kernel dispatch, in launch order",
+              "name,grid_x,workgroup_x,lds_bytes,arch_vgpr,accum_vgpr,sgpr,scratch,duration_us"]
+    q = ("select name, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size, duration "
+         "from kernels where name like '%align_level%' or name like '%pose_opt%' order by start")
+    for r in c.execute(q):
+        lines.append(f"\"{r[0]}\",{r[1]},{r[2]},{r[3]},{r[4]},{r[5]},{r[6]},{r[7]},{r[8] / 1e3:.1f}")
+    open(out, "w").write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")
