@@ -295,7 +295,7 @@ uint64_t plsvo_oracle_setup_sampling(const double spx[2], const double epx[2], d
   const double sin_dir = tan_dir / sqrt(1.0 + tan_dir * tan_dir);
   const double correction = 2.0 * sqrt(1.0 + sin_dir * sin_dir);
   const double v = length / (2.0 * patch_size * correction);
-  return (uint64_t)(1.0 > v ? 1.0 : v); /* std::max(1.0, v); NaN (zero-length segment) gives 1.0 like std::max */
+  return (uint64_t)((1.0 < v) ? v : 1.0); /* std::max(1.0, v) = (1.0 < v) ? v : 1.0; NaN (zero-length segment) gives 1.0 */
 }
 
 /* LineFeat ctor  src/feature.cpp:103-104: line = sf x ef, scaled so (l0,l1) is unit */

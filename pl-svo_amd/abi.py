@@ -1,7 +1,7 @@
 """ctypes mirror of include/plsvo_hip.h (struct layouts + helpers to fill them from numpy arrays).
 
-Used by the product binding (capi.py, loads libplsvo_hip.so) and, because the oracle shares the struct
-layouts, by the test-only oracle binding (oracle/binding.py).  Nothing here computes anything.
+Used by the product binding (capi.py, loads libplsvo_hip.so); the test-only CPU checker shares these
+struct layouts and imports this module from its own directory.  Nothing here computes anything.
 """
 import ctypes as C
 

@@ -217,7 +217,7 @@ PLSVO_HD int seg_num_samples(double sx, double sy, double ex, double ey, double 
   const double sin_dir = tan_dir / sqrt(1.0 + tan_dir * tan_dir);
   const double correction = 2.0 * sqrt(1.0 + sin_dir * sin_dir);
   const double v = length / (2.0 * 4 * correction);
-  const long long n0 = (long long)(1.0 > v ? 1.0 : v);
+  const long long n0 = (long long)((1.0 < v) ? v : 1.0);  // std::max(1.0, v); NaN -> 1
   return (int)(1 + (n0 - 1) / (1 << level));
 }
 

@@ -1,0 +1,140 @@
+"""CPU unit tests of the oracle's building blocks: analytic known answers for every piece of arithmetic the
+hot path relies on (tier "Unit").  These pin the restated third-party semantics
+(Sophus SE3, Eigen LDLT / inverse, vikit robust cost and camera)."""
+import math
+
+import numpy as np
+import pytest
+
+
+def test_se3_exp_small_angle_and_identities(ob):
+    T = ob.se3_exp(np.zeros(6))
+    assert np.allclose(T, [0, 0, 0, 1, 0, 0, 0])
+    u = np.array([0.3, -0.2, 0.1, 0.4, -0.5, 0.2])
+    T = ob.se3_exp(u)
+    Ti = ob.se3_inv(T)
+    assert np.allclose(ob.se3_mul(T, Ti), [0, 0, 0, 1, 0, 0, 0], atol=1e-15)
+    assert abs(np.linalg.norm(T[:4]) - 1) < 1e-15
+    # exp(u) exp(-u) = I
+    assert np.allclose(ob.se3_mul(T, ob.se3_exp(-u)), [0, 0, 0, 1, 0, 0, 0], atol=1e-15)
+    # rotation part matches Rodrigues
+    R, t = ob.se3_matrix(T)
+    w = u[3:]
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / th
+    Rr = np.eye(3) + math.sin(th) * K + (1 - math.cos(th)) * K @ K
+    assert np.allclose(R, Rr, atol=1e-15)
+    # pure translation
+    assert np.allclose(ob.se3_exp([1, 2, 3, 0, 0, 0])[4:], [1, 2, 3])
+    # tiny rotation uses the series branch and stays finite/unit
+    T = ob.se3_exp([0, 0, 0, 1e-12, 0, 0])
+    assert abs(np.linalg.norm(T[:4]) - 1) < 1e-15 and abs(T[0] - 0.5e-12) < 1e-24
+
+
+def test_se3_act_matches_matrix(ob):
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        T = ob.se3_exp(rng.normal(0, 1, 6))
+        p = rng.normal(0, 3, 3)
+        R, t = ob.se3_matrix(T)
+        assert np.allclose(ob.se3_act(T, p), R @ p + t, atol=1e-14)
+        A, B = ob.se3_exp(rng.normal(0, 1, 6)), ob.se3_exp(rng.normal(0, 1, 6))
+        assert np.allclose(ob.se3_act(ob.se3_mul(A, B), p), ob.se3_act(A, ob.se3_act(B, p)), atol=1e-13)
+
+
+def test_jacobian_xyz2uv_is_minus_projection_derivative(ob):
+    """Frame::jacobian_xyz2uv = - d proj(exp(xi) p) / d xi at xi = 0 (include/plsvo/frame.h:138-160)"""
+    rng = np.random.default_rng(2)
+    for _ in range(10):
+        p = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(2, 6)])
+        J = ob.jacobian_xyz2uv(p)
+        h = 1e-6
+        num = np.zeros((2, 6))
+        for k in range(6):
+            d = np.zeros(6)
+            d[k] = h
+            qp, qm = ob.se3_act(ob.se3_exp(d), p), ob.se3_act(ob.se3_exp(-d), p)
+            num[:, k] = (qp[:2] / qp[2] - qm[:2] / qm[2]) / (2 * h)
+        assert np.allclose(J, -num, atol=1e-8)
+    assert ob.jacobian_xyz2uv([0.3, 0.2, 2.0])[0, 1] == 0.0 and ob.jacobian_xyz2uv([0.3, 0.2, 2.0])[1, 0] == 0.0
+
+
+def test_ldlt_solve_and_inverse(ob):
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        A = rng.normal(0, 1, (12, 6))
+        H = A.T @ A + 1e-3 * np.eye(6)
+        b = rng.normal(0, 1, 6)
+        assert np.allclose(ob.ldlt_solve6(H, b), np.linalg.solve(H, b), rtol=1e-9, atol=1e-12)
+        assert np.allclose(ob.inv6(H), np.linalg.inv(H), rtol=1e-8, atol=1e-10)
+    # all-zero system: Eigen's LDLT returns 0 (zero measurements must leave the pose alone)
+    assert np.array_equal(ob.ldlt_solve6(np.zeros((6, 6)), np.ones(6)), np.zeros(6))
+    # NaN propagates into x[0] (solve() failure path, src/sparse_img_align.cpp:700)
+    H = np.eye(6)
+    H[2, 3] = H[3, 2] = np.nan
+    assert np.isnan(ob.ldlt_solve6(H, np.ones(6))[0])
+    # indefinite but non-singular: pivoted LDLT still solves it
+    H = np.diag([1.0, -2.0, 3.0, 4.0, -5.0, 6.0])
+    H[0, 1] = H[1, 0] = 0.5
+    assert np.allclose(ob.ldlt_solve6(H, np.arange(6.0)), np.linalg.solve(H, np.arange(6.0)))
+
+
+def test_setup_sampling_table(ob):
+    """LineFeat::setupSampling (src/feature.cpp:160-173): N = max(1, length / (2*4*corr)), corr = 2 sqrt(1+sin^2)"""
+    n, dif = ob.setup_sampling([0, 0], [160, 0], 160.0)          # horizontal: corr = 2 -> N = 160/16
+    assert n == 10 and np.allclose(dif, [160, 0])
+    n, _ = ob.setup_sampling([0, 0], [0, 97], 97.0)              # vertical, truncation
+    assert n == 6
+    L = 100 * math.sqrt(2)
+    n, _ = ob.setup_sampling([0, 0], [100, 100], L)              # 45 deg: sin = 1/sqrt2, corr = 2 sqrt(1.5)
+    assert n == int(L / (8 * 2 * math.sqrt(1.5)))
+    n, _ = ob.setup_sampling([5, 5], [8, 6], math.hypot(3, 1))   # short segment: one sample
+    assert n == 1
+    n, _ = ob.setup_sampling([5, 5], [5, 5], 0.0)                # degenerate: NaN inside, std::max gives 1
+    assert n == 1
+    # per-level reduction N_l = 1 + (N-1) / 2^l is integer arithmetic (src/sparse_img_align.cpp:320)
+    assert [1 + (10 - 1) // (1 << l) for l in range(4)] == [10, 5, 3, 2]
+
+
+def test_line_normal(ob):
+    sf = np.array([0.1, 0.2, 1.0]) / np.linalg.norm([0.1, 0.2, 1.0])
+    ef = np.array([-0.3, 0.25, 1.0]) / np.linalg.norm([-0.3, 0.25, 1.0])
+    l = ob.line_normal(sf, ef)
+    assert abs(math.hypot(l[0], l[1]) - 1) < 1e-15
+    assert abs(l @ (sf / sf[2])) < 1e-15 and abs(l @ (ef / ef[2])) < 1e-15   # both end points lie on the line
+
+
+def test_robust_cost_known_answers(ob):
+    assert ob.tukey(0.0) == 1.0
+    assert ob.tukey(4.6851) == 0.0 or ob.tukey(4.6851) < 1e-12
+    assert ob.tukey(5.0) == 0.0
+    assert ob.tukey(float("inf")) == 0.0 and ob.tukey(float("nan")) == 0.0
+    x = 2.0
+    b2 = np.float32(4.6851) ** 2
+    assert ob.tukey(x) == pytest.approx(float((np.float32(1) - np.float32(4) / b2) ** 2), rel=1e-6)
+    assert ob.mad_scale([1, 2, 3, 4, 5]) == pytest.approx(1.48 * 3, rel=1e-6)
+    assert ob.mad_scale([4, 1, 3, 2]) == pytest.approx(1.48 * 3, rel=1e-6)      # upper median, no averaging
+    assert ob.median_f64([0.5, 0.1, 0.9, 0.3]) == 0.5
+
+
+def test_halfsample_known_answers(ob):
+    img = np.array([[10, 11, 200, 202], [12, 13, 201, 203], [0, 1, 2, 3], [255, 255, 255, 255]], dtype=np.uint8)
+    sse = ob.halfsample(img, 0)     # avg(avg(a,c),avg(b,d)) with rounding averages
+    sca = ob.halfsample(img, 1)     # (a+b+c+d)/4 truncating
+    assert sse.tolist() == [[12, 202], [128, 129]]
+    assert sca.tolist() == [[11, 201], [127, 128]]
+    odd = ob.halfsample(np.zeros((5, 7), np.uint8), 0)
+    assert odd.shape == (2, 3)
+
+
+def test_camera_roundtrip(ob, P):
+    cam = P.abi.Pinhole(416.0, 416.0, 320.0, 240.0, 640, 480)
+    import ctypes as C
+    px = np.array([100.5, 300.25])
+    f = np.empty(3)
+    ob.lib().plsvo_oracle_cam2world(C.byref(cam), px.ctypes.data_as(P.abi.c_double_p), f.ctypes.data_as(P.abi.c_double_p))
+    assert abs(np.linalg.norm(f) - 1) < 1e-15
+    back = np.empty(2)
+    xyz = f * 3.7
+    ob.lib().plsvo_oracle_world2cam(C.byref(cam), xyz.ctypes.data_as(P.abi.c_double_p), back.ctypes.data_as(P.abi.c_double_p))
+    assert np.allclose(back, px, atol=1e-12)
