@@ -1,0 +1,320 @@
+// hip_adapter.hpp -- C++ host side of the drop-in: re-creates the reference's two call signatures
+//
+//     plsvo::SparseImgAlign(max_level, min_level, n_iter, method, display, verbose).run(ref_frame, cur_frame)
+//                                   (include/plsvo/sparse_img_align.h:46-66, src/sparse_img_align.cpp:40-95)
+//     plsvo::pose_optimizer::optimizeGaussNewton(reproj_thresh, n_iter, verbose, frame, estimated_scale,
+//                                   error_init, error_final, num_obs_pt, num_obs_ls)
+//                                   (include/plsvo/pose_optimizer.h:47-64, src/pose_optimizer.cpp:38-260, :262-582)
+//
+// on top of the C ABI (include/plsvo_hip.h).  Header-only and duck-typed on the frame/feature types: it reads
+// exactly the members the reference's hot path reads (include/plsvo/frame.h:58-71, feature.h:41-92,
+// feature3D.h:103,149-150) and reproduces every mutation the reference performs:
+//     cur_frame->T_f_w_ (sparse_img_align.cpp:92), LineFeat::feat3D = NULL for culled segments (:687-688),
+//     frame->T_f_w_, frame->Cov_ and feat3D = NULL for culled observations (pose_optimizer.cpp:183-199,218,239),
+//     the scalar outputs.
+// It compiles against the reference's own headers (Eigen/Sophus/OpenCV types expose the accessors used here)
+// and against the dependency-free look-alike types in mini_types.hpp used by this repo's tests.
+// The few places where the reference's third-party types need help (pinhole intrinsics sit behind
+// vk::AbstractCamera*) are customisation points in plsvo_hip_adapter::traits -- see INTEGRATION.md.
+//
+// There is NO CPU fallback: if the C ABI reports an error the adapter prints it and behaves like the
+// reference's own failure paths (run() returns 0; optimizeGaussNewton leaves its outputs untouched).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <list>
+#include <type_traits>
+#include <vector>
+
+#include "../../../include/plsvo_hip.h"
+#include "../../csrc/plsvo_math.hpp"
+
+namespace plsvo_hip_adapter {
+
+// ---- customisation points --------------------------------------------------------------------
+template <class Cam>
+struct camera_traits {  // default: the camera type has fx()/fy()/cx()/cy()/width()/height() (vk::PinholeCamera does)
+  static plsvo_pinhole get(const Cam& c) {
+    plsvo_pinhole p;
+    p.fx = c.fx(); p.fy = c.fy(); p.cx = c.cx(); p.cy = c.cy(); p.width = c.width(); p.height = c.height();
+    return p;
+  }
+};
+template <class Img>
+struct image_traits {  // default: cv::Mat-like (data, cols, rows, step)
+  static const uint8_t* data(const Img& m) { return reinterpret_cast<const uint8_t*>(m.data); }
+  static int cols(const Img& m) { return m.cols; }
+  static int rows(const Img& m) { return m.rows; }
+  static int stride(const Img& m) { return static_cast<int>(static_cast<size_t>(m.step)); }
+};
+template <class SE3T>
+struct se3_traits {  // default: non-templated Sophus::SE3 (unit_quaternion(), translation(), ctor from both)
+  static void get(const SE3T& T, double out[7]) {
+    const auto& q = T.unit_quaternion();
+    const auto& t = T.translation();
+    out[0] = q.x(); out[1] = q.y(); out[2] = q.z(); out[3] = q.w(); out[4] = t[0]; out[5] = t[1]; out[6] = t[2];
+  }
+  static void set(SE3T& T, const double in[7]) {
+    typedef typename std::decay<decltype(T.unit_quaternion())>::type Q;   // Eigen::Quaterniond: ctor (w, x, y, z)
+    typedef typename std::decay<decltype(T.translation())>::type V;       // Eigen::Vector3d: ctor (x, y, z)
+    T = SE3T(Q(in[3], in[0], in[1], in[2]), V(in[4], in[5], in[6]));
+  }
+};
+template <class Mat66>
+struct mat66_traits {  // default: Eigen-like operator()(row, col)
+  static void set(Mat66& M, const double* row_major) {
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) M(i, j) = row_major[i * 6 + j];
+  }
+};
+
+// ---- one context per calling thread -------------------------------------------------------------
+struct Context {
+  plsvo_ctx* ctx = nullptr;
+  int width = 0, height = 0, levels = 0;
+  ~Context() { if (ctx) plsvo_hip_destroy(ctx); }
+  bool ensure(int w, int h, int n_levels) {
+    if (!ctx) {
+      const char* dev = std::getenv("PLSVO_DEVICE");
+      if (plsvo_hip_create(dev ? std::atoi(dev) : 0, nullptr, &ctx) != PLSVO_OK) {
+        std::fprintf(stderr, "[plsvo_hip] %s\n", plsvo_hip_last_error(nullptr));
+        ctx = nullptr;
+        return false;
+      }
+    }
+    if (w != width || h != height || n_levels != levels) {
+      if (plsvo_hip_config_pyramids(ctx, 2, w, h, n_levels) != PLSVO_OK) {
+        std::fprintf(stderr, "[plsvo_hip] %s\n", plsvo_hip_last_error(ctx));
+        return false;
+      }
+      width = w; height = h; levels = n_levels;
+    }
+    return true;
+  }
+};
+inline Context& default_context() { static thread_local Context c; return c; }
+
+template <class V>
+inline void copy3(const V& v, double* o) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; }
+
+template <class Frame>
+inline bool upload_frame_pyramid(Context& c, int slot, const Frame& f, int n_levels) {
+  typedef typename std::remove_reference<decltype(f.img_pyr_[0])>::type Img;
+  std::vector<const uint8_t*> ptr((size_t)n_levels);
+  std::vector<int> w((size_t)n_levels), h((size_t)n_levels), s((size_t)n_levels);
+  for (int l = 0; l < n_levels; ++l) {
+    const Img& m = f.img_pyr_[(size_t)l];
+    ptr[(size_t)l] = image_traits<Img>::data(m); w[(size_t)l] = image_traits<Img>::cols(m);
+    h[(size_t)l] = image_traits<Img>::rows(m); s[(size_t)l] = image_traits<Img>::stride(m);
+  }
+  if (plsvo_hip_upload_pyramid(c.ctx, slot, n_levels, ptr.data(), w.data(), h.data(), s.data()) != PLSVO_OK) {
+    std::fprintf(stderr, "[plsvo_hip] %s\n", plsvo_hip_last_error(c.ctx));
+    return false;
+  }
+  return true;
+}
+
+}  // namespace plsvo_hip_adapter
+
+namespace plsvo {
+
+/// Optimize the pose of the frame by minimizing the photometric error of feature patches
+/// (same public surface as include/plsvo/sparse_img_align.h:46-70; the vk::NLLSSolver base is gone because the
+/// Gauss-Newton loop runs on the device).
+template <class FramePtrT>
+class SparseImgAlignT {
+ public:
+  enum Method { GaussNewton, LevenbergMarquardt };  // vk::NLLSSolver::Method; the call sites pass GaussNewton
+
+  SparseImgAlignT(int max_level, int min_level, int n_iter, Method method, bool display, bool verbose)
+      : max_level_(max_level), min_level_(min_level), n_iter_(n_iter), method_(method), display_(display), verbose_(verbose),
+        eps_(0.000001) {
+    for (int k = 0; k < 36; ++k) H_[k] = 0.0;
+  }
+
+  /// returns the number of tracked features, n_meas_/patch_area_ (src/sparse_img_align.cpp:94)
+  size_t run(FramePtrT ref_frame, FramePtrT cur_frame) {
+    using namespace plsvo_hip_adapter;
+    using namespace plsvo_hip;
+    if (ref_frame->pt_fts_.empty() && ref_frame->seg_fts_.empty()) {  // :58-62
+      std::fprintf(stderr, "\033[0;33m[WARN] SparseImgAlign: no features (points or segments) to track!\033[0;0m\n");
+      return 0;
+    }
+    if (method_ != GaussNewton) {
+      std::fprintf(stderr, "[plsvo_hip] SparseImgAlign: only GaussNewton is implemented (the reference's call sites use it)\n");
+      return 0;
+    }
+    typedef typename std::remove_reference<decltype(*ref_frame->cam_)>::type Cam;
+    plsvo_align_in in;
+    in.cam = camera_traits<Cam>::get(*ref_frame->cam_);
+    const int n_levels = max_level_ + 1;
+    Context& c = default_context();
+    if ((int)ref_frame->img_pyr_.size() < n_levels || (int)cur_frame->img_pyr_.size() < n_levels) return 0;
+    if (!c.ensure(in.cam.width, in.cam.height, n_levels)) return 0;
+    if (!upload_frame_pyramid(c, 0, *ref_frame, n_levels) || !upload_frame_pyramid(c, 1, *cur_frame, n_levels)) return 0;
+
+    // poses: T_cur_from_ref = cur.T_f_w * ref.T_f_w^-1 (:80); ref_pos = ref.T_f_w^-1 translation (frame.h:131)
+    double Tr[7], Tc[7];
+    typedef typename std::remove_reference<decltype(ref_frame->T_f_w_)>::type SE3T;
+    se3_traits<SE3T>::get(ref_frame->T_f_w_, Tr);
+    se3_traits<SE3T>::get(cur_frame->T_f_w_, Tc);
+    const SE3d T_ref = se3_load(Tr), T_cur = se3_load(Tc);
+    const SE3d T_ref_inv = se3_inv(T_ref);
+    const SE3d T_cfr = se3_mul(T_cur, T_ref_inv);
+    const double* ref_pos = T_ref_inv.t;
+
+    // flatten the reference frame's features (the only walk over the std::lists)
+    std::vector<double> pt_px, pt_xyz, spx, epx, len, pref, qref;
+    std::vector<uint8_t> alive;
+    for (auto it = ref_frame->pt_fts_.begin(); it != ref_frame->pt_fts_.end(); ++it) {
+      if ((*it)->feat3D == NULL) continue;
+      double pos[3], f[3];
+      copy3((*it)->feat3D->pos_, pos); copy3((*it)->f, f);
+      const double d0 = pos[0] - ref_pos[0], d1 = pos[1] - ref_pos[1], d2 = pos[2] - ref_pos[2];
+      const double depth = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2);          // :229
+      pt_px.push_back((*it)->px[0]); pt_px.push_back((*it)->px[1]);
+      pt_xyz.push_back(f[0] * depth); pt_xyz.push_back(f[1] * depth); pt_xyz.push_back(f[2] * depth);  // :230
+    }
+    std::vector<decltype(&**ref_frame->seg_fts_.begin())> seg_ptr;
+    for (auto it = ref_frame->seg_fts_.begin(); it != ref_frame->seg_fts_.end(); ++it) {
+      auto* s = &**it;
+      seg_ptr.push_back(s);
+      spx.push_back(s->spx[0]); spx.push_back(s->spx[1]); epx.push_back(s->epx[0]); epx.push_back(s->epx[1]);
+      len.push_back(s->length);
+      double p[3] = { 0, 0, 1 }, q[3] = { 0, 0, 1 };
+      if (s->feat3D != NULL) {
+        double sp[3], ep[3], sf[3], ef[3];
+        copy3(s->feat3D->spos_, sp); copy3(s->feat3D->epos_, ep); copy3(s->sf, sf); copy3(s->ef, ef);
+        const double pd = std::sqrt((sp[0] - ref_pos[0]) * (sp[0] - ref_pos[0]) + (sp[1] - ref_pos[1]) * (sp[1] - ref_pos[1]) + (sp[2] - ref_pos[2]) * (sp[2] - ref_pos[2]));
+        const double qd = std::sqrt((ep[0] - ref_pos[0]) * (ep[0] - ref_pos[0]) + (ep[1] - ref_pos[1]) * (ep[1] - ref_pos[1]) + (ep[2] - ref_pos[2]) * (ep[2] - ref_pos[2]));
+        for (int k = 0; k < 3; ++k) { p[k] = sf[k] * pd; q[k] = ef[k] * qd; }   // :327-330
+      }
+      for (int k = 0; k < 3; ++k) { pref.push_back(p[k]); qref.push_back(q[k]); }
+      alive.push_back(s->feat3D != NULL ? 1 : 0);
+    }
+    in.ref_slot = 0; in.cur_slot = 1;
+    in.max_level = max_level_; in.min_level = min_level_; in.n_iter = n_iter_; in.reserved0 = 0; in.eps = eps_;
+    se3_store(T_cfr, in.T_cur_from_ref);
+    in.n_pts = (int)(pt_px.size() / 2); in.n_seg = (int)len.size();
+    in.pt_px = pt_px.data(); in.pt_xyz_ref = pt_xyz.data();
+    in.seg_spx = spx.data(); in.seg_epx = epx.data(); in.seg_len = len.data();
+    in.seg_p_ref = pref.data(); in.seg_q_ref = qref.data(); in.seg_alive_in = alive.data();
+    if (in.n_pts == 0 && in.n_seg == 0) return 0;
+
+    plsvo_align_out out;
+    std::vector<uint8_t> alive_out(alive.size() ? alive.size() : 1, 1);
+    out.seg_alive_out = alive_out.data();
+    if (plsvo_sparse_align(c.ctx, &in, &out) != PLSVO_OK) {
+      std::fprintf(stderr, "[plsvo_hip] sparse_align failed: %s\n", plsvo_hip_last_error(c.ctx));
+      return 0;
+    }
+    // write back exactly what the reference mutates
+    const SE3d T_new = se3_mul(se3_load(out.T_cur_from_ref), T_ref);             // :92
+    double Tn[7];
+    se3_store(T_new, Tn);
+    se3_traits<SE3T>::set(cur_frame->T_f_w_, Tn);
+    for (size_t s = 0; s < seg_ptr.size(); ++s)
+      if (alive[s] && !alive_out[s]) seg_ptr[s]->feat3D = NULL;                    // :687-688
+    for (int k = 0; k < 36; ++k) H_[k] = out.H[k];
+    n_meas_ = out.n_meas; chi2_ = out.chi2; stop_ = (out.status & 1) != 0;
+    for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) iters_per_level_[l] = out.iters_per_level[l];
+    if (verbose_)
+      for (int l = max_level_; l >= min_level_; --l) std::printf("PYRAMID LEVEL %i: %d iterations\n", l, iters_per_level_[l]);
+    return (size_t)out.n_tracked;                                                  // :94
+  }
+
+  /// Fisher information H_/sigma_i^2 (src/sparse_img_align.cpp:97-102), row-major 6x6 into `I`
+  template <class Mat66>
+  void getFisherInformation(Mat66& I) const {
+    const double sigma_i_sq = 5e-4 * 255 * 255;
+    double tmp[36];
+    for (int k = 0; k < 36; ++k) tmp[k] = H_[k] / sigma_i_sq;
+    plsvo_hip_adapter::mat66_traits<Mat66>::set(I, tmp);
+  }
+
+  // solver state the reference exposes through vk::NLLSSolver
+  size_t n_meas_ = 0;
+  double chi2_ = 1e10;
+  bool stop_ = false;
+  int iters_per_level_[PLSVO_MAX_LEVELS] = { 0 };
+
+ private:
+  int max_level_, min_level_, n_iter_;
+  Method method_;
+  bool display_, verbose_;
+  double eps_;
+  double H_[36];
+};
+
+namespace pose_optimizer {
+
+/// Motion-only bundle adjustment (include/plsvo/pose_optimizer.h:47-64).  n_iter_ref < 0 selects the
+/// 9-argument overload's behaviour, >= 0 the 10-argument one.
+template <class FramePtrT>
+void optimizeGaussNewtonImpl(const double reproj_thresh, const size_t n_iter, const long n_iter_ref, const bool verbose,
+                             FramePtrT& frame, double& estimated_scale, double& error_init, double& error_final,
+                             size_t& num_obs_pt, size_t& num_obs_ls) {
+  using namespace plsvo_hip_adapter;
+  Context& c = default_context();
+  if (!c.ctx && !c.ensure(64, 64, 1)) return;
+  typedef typename std::remove_reference<decltype(frame->T_f_w_)>::type SE3T;
+  plsvo_poseopt_in in;
+  se3_traits<SE3T>::get(frame->T_f_w_, in.T_f_w);
+  in.fx = frame->cam_->errorMultiplier2();
+  in.reproj_thresh = reproj_thresh; in.n_iter = (int)n_iter; in.n_iter_ref = (int)n_iter_ref;
+  std::vector<double> f, pos, line, spos, epos;
+  std::vector<int32_t> plev, slev;
+  std::vector<decltype(&**frame->pt_fts_.begin())> pt_ptr;
+  std::vector<decltype(&**frame->seg_fts_.begin())> seg_ptr;
+  for (auto it = frame->pt_fts_.begin(); it != frame->pt_fts_.end(); ++it) {
+    if ((*it)->feat3D == NULL) continue;
+    pt_ptr.push_back(&**it);
+    for (int k = 0; k < 3; ++k) { f.push_back((*it)->f[k]); pos.push_back((*it)->feat3D->pos_[k]); }
+    plev.push_back((*it)->level);
+  }
+  for (auto it = frame->seg_fts_.begin(); it != frame->seg_fts_.end(); ++it) {
+    if ((*it)->feat3D == NULL) continue;
+    seg_ptr.push_back(&**it);
+    for (int k = 0; k < 3; ++k) { line.push_back((*it)->line[k]); spos.push_back((*it)->feat3D->spos_[k]); epos.push_back((*it)->feat3D->epos_[k]); }
+    slev.push_back((*it)->level);
+  }
+  in.n_pts = (int)plev.size(); in.n_seg = (int)slev.size();
+  in.pt_f = f.data(); in.pt_pos = pos.data(); in.pt_level = plev.data();
+  in.seg_line = line.data(); in.seg_spos = spos.data(); in.seg_epos = epos.data(); in.seg_level = slev.data();
+  plsvo_poseopt_out out;
+  std::vector<uint8_t> pk(pt_ptr.size() ? pt_ptr.size() : 1, 1), sk(seg_ptr.size() ? seg_ptr.size() : 1, 1);
+  out.pt_keep = pk.data(); out.seg_keep = sk.data();
+  if (plsvo_pose_optimize(c.ctx, &in, &out) != PLSVO_OK) {
+    std::fprintf(stderr, "[plsvo_hip] pose_optimize failed: %s\n", plsvo_hip_last_error(c.ctx));
+    return;
+  }
+  num_obs_pt = (size_t)out.num_obs_pt;                                             // :71 (set before the early return)
+  if (out.status & 1) return;                                                     // errors.empty() :88-89
+  se3_traits<SE3T>::set(frame->T_f_w_, out.T_f_w);
+  mat66_traits<typename std::remove_reference<decltype(frame->Cov_)>::type>::set(frame->Cov_, out.cov);  // :199
+  for (size_t i = 0; i < pt_ptr.size(); ++i) if (!pk[i]) pt_ptr[i]->feat3D = NULL;                        // :218
+  for (size_t i = 0; i < seg_ptr.size(); ++i) if (!sk[i]) seg_ptr[i]->feat3D = NULL;                      // :239
+  estimated_scale = out.estimated_scale; error_init = out.error_init; error_final = out.error_final;
+  num_obs_ls = (size_t)out.num_obs_ls;
+  if (verbose)
+    std::printf("n deleted obs = %zu points \t %zu lines\t scale = %g\t error init = %g\t error end = %g\n",
+                pt_ptr.size() - (size_t)out.num_obs_pt, seg_ptr.size() - (size_t)out.num_obs_ls, estimated_scale, error_init, error_final);
+}
+
+template <class FramePtrT>
+void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const bool verbose, FramePtrT& frame,
+                         double& estimated_scale, double& error_init, double& error_final, size_t& num_obs_pt, size_t& num_obs_ls) {
+  optimizeGaussNewtonImpl(reproj_thresh, n_iter, -1L, verbose, frame, estimated_scale, error_init, error_final, num_obs_pt, num_obs_ls);
+}
+template <class FramePtrT>
+void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const size_t n_iter_ref, const bool verbose, FramePtrT& frame,
+                         double& estimated_scale, double& error_init, double& error_final, size_t& num_obs_pt, size_t& num_obs_ls) {
+  optimizeGaussNewtonImpl(reproj_thresh, n_iter, (long)n_iter_ref, verbose, frame, estimated_scale, error_init, error_final, num_obs_pt, num_obs_ls);
+}
+
+}  // namespace pose_optimizer
+}  // namespace plsvo
+
+namespace svo = plsvo;  // BASELINE.json spells the upstream name svo::SparseImgAlign

@@ -1,0 +1,61 @@
+"""The C++ drop-in adapter (pl-svo_amd/host/plsvo/hip_adapter.hpp): frames with std::lists of features go in,
+the reference's two calls are made as FrameHandlerMono::processFrame makes them
+(src/frame_handler_mono.cpp:272-274, 327-329), and every mutation the reference performs is checked against
+the oracle: cur_frame->T_f_w_, LineFeat::feat3D = NULL, frame->T_f_w_, Cov_, the scalar outputs, culled features."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "pl-svo_amd", "host", "adapter_driver")
+
+
+def test_adapter_reproduces_reference_mutations(P, ob, tmp_path):
+    assert os.path.exists(DRIVER), "build it with __graft_entry__.build()"
+    W, H, nlev, maxl, minl, npts, nseg, ndead = 320, 240, 4, 3, 1, 60, 24, 3
+    st, ref, cur, _ = Hh.make_case(ob, 777, W, H, npts, nseg, nlev, maxl, minl)
+    fr = P.synth.make_poseopt_frame(778, 90, 30, W, H)
+    blob = [np.array([W, H, nlev, maxl, minl, npts, nseg, 90, 30, ndead, 0, 0], float), np.array(st.cam[:4], float),
+            st.T_ref_w, st.T_cur_w_init]
+    path = tmp_path / "in.bin"
+    with open(path, "wb") as f:
+        for a in blob:
+            np.asarray(a, np.float64).tofile(f)
+        for pyr in (ref, cur):
+            for l in pyr:
+                np.ascontiguousarray(l, np.uint8).tofile(f)
+        np.hstack([st.pt_px, st.pt_f, st.pt_pos_w]).astype(np.float64).tofile(f)
+        np.hstack([st.seg_spx, st.seg_epx, st.seg_sf, st.seg_ef, st.seg_spos_w, st.seg_epos_w, st.seg_len[:, None]]).astype(np.float64).tofile(f)
+        np.asarray(fr.T_init, np.float64).tofile(f)
+        np.hstack([fr.pt_f, fr.pt_pos, fr.pt_level[:, None].astype(float)]).astype(np.float64).tofile(f)
+        np.hstack([fr.seg_line, fr.seg_spos, fr.seg_epos, fr.seg_level[:, None].astype(float)]).astype(np.float64).tofile(f)
+    out = tmp_path / "out.txt"
+    subprocess.run([DRIVER, str(path), str(out)], check=True, timeout=120)
+    got = {l.split()[0]: l.split()[1:] for l in open(out).read().strip().splitlines()}
+
+    # oracle on the same flattened inputs (first `ndead` segments have no landmark)
+    alive_in = np.ones(nseg, np.uint8)
+    alive_in[:ndead] = 0
+    job = P.abi.AlignJob(st.cam, maxl, minl, 30, 1e-6, st.T_init, st.pt_px, st.pt_xyz_ref, st.seg_spx, st.seg_epx, st.seg_len,
+                         st.seg_p_ref, st.seg_q_ref, seg_alive_in=alive_in)
+    ro, _ = ob.sparse_align(job, ref, cur)
+    T_cur = np.array(got["T_cur"], float)
+    ang, tr, ok = Hh.pose_close(T_cur, Hh.frame_pose(ro.T, st))
+    assert ok, (ang, tr)
+    assert int(got["n_tracked"][0]) == ro.n_tracked or abs(int(got["n_tracked"][0]) - ro.n_tracked) <= 1
+    assert [int(x) for x in got["alive"]] == list(ro.seg_alive)
+    assert float(got["fisher00"][0]) == pytest.approx(ro.H[0, 0] / (5e-4 * 255 * 255), rel=1e-4)
+
+    po, _ = ob.pose_optimize(P.poseopt_job_from_frame(fr))
+    assert Hh.pose_close(np.array(got["T_opt"], float), po.T)[2]
+    sc = got["scalars"]
+    assert float(sc[0]) == pytest.approx(po.estimated_scale, rel=1e-6)
+    assert float(sc[1]) == pytest.approx(po.error_init, rel=1e-9) and float(sc[2]) == pytest.approx(po.error_final, rel=1e-6)
+    assert (int(sc[3]), int(sc[4])) == (po.num_obs_pt, po.num_obs_ls)
+    assert float(sc[5]) == pytest.approx(po.cov[0, 0], rel=1e-6)
+    assert [int(x) for x in got["pt_keep"]] == list(po.pt_keep) and [int(x) for x in got["seg_keep"]] == list(po.seg_keep)
