@@ -11,7 +11,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplsvo_hip.so")
+LIB_PATH = os.environ.get("PLSVO_HIP_LIB", os.path.join(_HERE, "libplsvo_hip.so"))  # override only for instrumented builds
 
 # every symbol include/plsvo_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [

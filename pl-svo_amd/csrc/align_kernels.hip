@@ -1,5 +1,5 @@
 // align_kernels.hip -- sparse image alignment on gfx950 (CDNA4): one workgroup per (ref,cur) frame pair,
-// one launch per pyramid level; the whole Gauss-Newton loop of a level runs on the device.
+// ONE launch for all pyramid levels; the coarse-to-fine loop and every Gauss-Newton iteration run on the device.
 //
 // Replaces (reference file:line):
 //   SparseImgAlign::precomputeGaussNewtonParamsPoints/Segments   src/sparse_img_align.cpp:195-268, 270-378
@@ -10,8 +10,13 @@
 // Design (not a translation of the CPU loops):
 //   * features of a level are flattened into a PATCH TABLE (points: 1 patch, segments: N samples),
 //     built on the device by a block-wide scan; a patch is 4x4 pixels;
-//   * the current level image is staged once per level into LDS with coalesced 16-byte loads; every
-//     GN iteration gathers its 5x5 windows from LDS (two dword reads + v_alignbyte per patch row);
+//   * small level images (<= lds_img_cap bytes, i.e. the coarse levels) are staged once per level into LDS
+//     with coalesced 16-byte loads; larger ones are gathered through L2.  Either way a 5x5 window costs two
+//     dword reads + v_alignbyte per patch row.  Keeping LDS below ~40 KB per workgroup lets four 256-thread
+//     workgroups share a CU, which hides each other's serial solve/update tails (measured: +13 % over
+//     staging the 77 KB level-1 image and running one workgroup per CU);
+//   * phase 1 is software-pipelined: the cache lines and image dwords of the next patch round are requested
+//     before the current round is computed;
 //   * 4 lanes per patch (one lane per patch row).  The 6-vector Jacobian of a pixel is
 //     J = fs * (dx * r0 + dy * r1) with r0, r1 the two rows of the 2x6 projection Jacobian of the PATCH,
 //     so sum_pix w J J^T = fs^2 (A r0 r0^T + B (r0 r1^T + r1 r0^T) + C r1 r1^T) with
@@ -136,235 +141,375 @@ __global__ void align_init_kernel(AlignBatchDev b) {
     for (int k = 0; k < 36; ++k) st->H[k] = 0.0;
     for (int k = 0; k < PLSVO_MAX_LEVELS; ++k) st->iters[k] = 0;
     st->patch_levels = 0; st->patch_iters = 0;
+    for (int k = 0; k < 8; ++k) st->phase_ticks[k] = 0;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // one pyramid level of SparseImgAlign::run for every job of the batch
 // ------------------------------------------------------------------------------------------------
+// optional per-phase timing (compile with -DPLSVO_TIMING): thread 0 accumulates s_memtime deltas
+#ifdef PLSVO_TIMING
+#define TICK(slot) do { if (tid == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); s_time[slot] += t__ - s_tlast; s_tlast = t__; } } while (0)
+#else
+#define TICK(slot) do { } while (0)
+#endif
+
 #define RED_N 32  // doubles per wave in the block reduction (21 H + 6 Jres + chi2 + 2 counters + pad)
 
-template <int T, bool LDS_IMG>
-__global__ __launch_bounds__(T) void align_level_kernel(AlignBatchDev b, int level, int cap) {
+// sin and cos of a small angle (|x| <= pi/4: Taylor/Horner to x^17 / x^16, < 1 ulp); larger angles use ocml.
+// Gauss-Newton updates are tiny rotations, so the fast path is the one that runs.
+__device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
+  if (fabs(x) <= 0.7853981633974483) {
+    const double z = x * x;
+    double ps = -1.0 / 355687428096000.0;                      // -1/17!
+    ps = ps * z + 1.0 / 1307674368000.0;                       //  1/15!
+    ps = ps * z - 1.0 / 6227020800.0;                          // -1/13!
+    ps = ps * z + 1.0 / 39916800.0;                            //  1/11!
+    ps = ps * z - 1.0 / 362880.0;                              // -1/9!
+    ps = ps * z + 1.0 / 5040.0;                                //  1/7!
+    ps = ps * z - 1.0 / 120.0;                                 // -1/5!
+    ps = ps * z + 1.0 / 6.0;                                   //  1/3!  (sign folded below)
+    *s = x - x * z * ps;
+    double pc = 1.0 / 20922789888000.0;                        //  1/16!
+    pc = pc * z - 1.0 / 87178291200.0;                         // -1/14!
+    pc = pc * z + 1.0 / 479001600.0;                           //  1/12!
+    pc = pc * z - 1.0 / 3628800.0;                             // -1/10!
+    pc = pc * z + 1.0 / 40320.0;                               //  1/8!
+    pc = pc * z - 1.0 / 720.0;                                 // -1/6!
+    pc = pc * z + 1.0 / 24.0;                                  //  1/4!
+    *c = 1.0 - 0.5 * z + z * z * pc;
+  } else {
+    *s = sin(x); *c = cos(x);
+  }
+}
+
+// Sophus::SE3::exp with the small-angle sincos above (same formulas as plsvo_math.hpp::se3_exp)
+__device__ __forceinline__ SE3d se3_exp_dev(const double* u) {
+  SE3d r;
+  const double ox = u[3], oy = u[4], oz = u[5];
+  const double theta = sqrt(ox * ox + oy * oy + oz * oz);
+  double sh, ch, st, ct;
+  sincos_small(0.5 * theta, &sh, &ch);
+  sincos_small(theta, &st, &ct);
+  double imag_factor;
+  if (theta < 1e-10) {
+    const double theta_sq = theta * theta;
+    imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * (theta_sq * theta_sq);
+  } else {
+    imag_factor = sh / theta;
+  }
+  Quat q = { imag_factor * ox, imag_factor * oy, imag_factor * oz, ch };
+  r.q = quat_normalized(q);
+  double V[9];
+  if (theta < 1e-10) {
+    quat_to_matrix(r.q, V);
+  } else {
+    const double theta_sq = theta * theta;
+    const double a = (1 - ct) / theta_sq;
+    const double b = (theta - st) / (theta_sq * theta);
+    const double O2_00 = -(oy * oy + oz * oz), O2_11 = -(ox * ox + oz * oz), O2_22 = -(ox * ox + oy * oy);
+    const double O2_01 = ox * oy, O2_02 = ox * oz, O2_12 = oy * oz;
+    V[0] = 1.0 + b * O2_00;      V[1] = a * -oz + b * O2_01;  V[2] = a * oy + b * O2_02;
+    V[3] = a * oz + b * O2_01;   V[4] = 1.0 + b * O2_11;      V[5] = a * -ox + b * O2_12;
+    V[6] = a * -oy + b * O2_02;  V[7] = a * ox + b * O2_12;   V[8] = 1.0 + b * O2_22;
+  }
+  for (int i = 0; i < 3; ++i) r.t[i] = V[i * 3 + 0] * u[0] + V[i * 3 + 1] * u[1] + V[i * 3 + 2] * u[2];
+  return r;
+}
+
+// what phase 1 requests one patch round ahead
+struct P1Fetch {
+  float2 uv;
+  uint32_t t0, t1, b0, b1;   // the two aligned dword pairs covering 5 bytes of the top / bottom image row
+  int sh;                    // byte shift inside the first dword
+  float4 vr, vx, vy;         // cached reference intensity and gradient of this patch row
+  int flags;                 // bit 0: live (in frame, line alive), bit 1: point patch
+};
+
+// ------------------------------------------------------------------------------------------------
+// SparseImgAlign::run for every job of the batch: levels [level_hi .. level_lo] of each job's range
+// ------------------------------------------------------------------------------------------------
+#ifndef PLSVO_MIN_WAVES
+#define PLSVO_MIN_WAVES 2   // measured: capping VGPRs at 128 (4 waves/SIMD) spills and loses to 2 unspilled waves/SIMD
+#endif
+template <int T>
+__global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBatchDev b, int cap, int lds_img_cap, int level_hi, int level_lo) {
   const int job_id = blockIdx.x;
   const AlignJobDev job = b.jobs[job_id];
-  if (job.skip || level > job.max_level || level < job.min_level) return;
+  if (job.skip) return;
+  const int lv_first = min(job.max_level, level_hi), lv_last = max(job.min_level, level_lo);
+  if (lv_first < lv_last) return;
   AlignStateDev* st = b.state + job_id;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int G = T / 4;  // 4-lane patch groups per workgroup
   const int grp = tid >> 2, row = tid & 3;
-  const int W = b.pyr.w[level], Hh = b.pyr.h[level];
-  const uint8_t* ref_img = b.pyr.base + (size_t)job.ref_slot * b.pyr.slot_bytes + b.pyr.off[level];
-  const uint8_t* cur_img = b.pyr.base + (size_t)job.cur_slot * b.pyr.slot_bytes + b.pyr.off[level];
 
   extern __shared__ __align__(16) unsigned char smem[];
   double* s_red = reinterpret_cast<double*>(smem);                       // RED_N * (T/64)
   double* s_pose = s_red + RED_N * (T / 64);                             // 0..8 R, 9..11 t, 12..18 model, 19..25 old model, 26 chi2_, 27 #evals
   double* s_tot = s_pose + 32;                                           // block totals of the last iteration: 21 H, 6 Jres, chi2, n_meas, evals
-  int* s_ctl = reinterpret_cast<int*>(s_tot + 32);                       // 0 break, 1 stop, 2 iterations done, 4.. scan tmp
+  int* s_ctl = reinterpret_cast<int*>(s_tot + 32);                       // 0 break, 1 stop, 2 iterations done, 3 error, 4.. scan tmp
   float2* s_uv = reinterpret_cast<float2*>(s_ctl + 32);                  // cap
   int2* s_meta = reinterpret_cast<int2*>(s_uv + cap);                    // cap
   float* s_abs = reinterpret_cast<float*>(s_meta + cap);                 // cap
   int* s_dead = reinterpret_cast<int*>(s_abs + cap);                     // cap
-  uint8_t* s_img = reinterpret_cast<uint8_t*>(s_dead + cap);             // W*Hh + 16 (16-byte aligned: cap % 4 == 0)
+  uint8_t* s_img = reinterpret_cast<uint8_t*>(s_dead + cap);             // lds_img_cap (16-byte aligned: cap % 4 == 0)
 
-  // ---- stage the current level image into LDS (coalesced 16 B per lane) ----
-  const int img_bytes = W * Hh;
-  if (LDS_IMG) {
-    const int n16 = img_bytes >> 4;
-    for (int i = tid; i < n16; i += T)
-      reinterpret_cast<uint4*>(s_img)[i] = reinterpret_cast<const uint4*>(cur_img)[i];
-    for (int i = (n16 << 4) + tid; i < img_bytes + 16; i += T)
-      s_img[i] = (i < img_bytes) ? cur_img[i] : (uint8_t)0;
-  }
-  const uint8_t* gimg = LDS_IMG ? s_img : cur_img;
-
+#ifdef PLSVO_TIMING
+  __shared__ unsigned long long s_time[8];
+  __shared__ unsigned long long s_tlast;
+  if (tid == 0) { for (int k = 0; k < 8; ++k) s_time[k] = 0; s_tlast = __builtin_amdgcn_s_memtime(); }
+#endif
   if (tid == 0) {
     for (int k = 0; k < 7; ++k) { s_pose[12 + k] = st->T[k]; s_pose[19 + k] = st->T[k]; }
-    s_pose[26] = st->chi2; s_pose[27] = 0.0;
+    s_pose[26] = st->chi2;
     for (int k = 0; k < 32; ++k) s_tot[k] = 0.0;
-    s_ctl[0] = 0; s_ctl[1] = st->stop; s_ctl[2] = 0;
+    s_ctl[1] = st->stop; s_ctl[3] = 0;
   }
-
-  // ---- patch table: count, scan, emit ----
-  const double scale = 1.0 / (double)(1 << level);  // the reference's float scale is a power of two: exact
-  const int nfeat = job.n_pts + job.n_seg;
-  int* s_cnt = reinterpret_cast<int*>(s_uv);  // aliased: nfeat <= cap
-  for (int f = tid; f < nfeat; f += T) {
-    int cnt = 0;
-    if (f < job.n_pts) {
-      // precomputeGaussNewtonParamsPoints :216-219: floor of the float position, 3 px border
-      const float u = (float)(b.pt_px[2 * (job.pt_off + f)] * scale), v = (float)(b.pt_px[2 * (job.pt_off + f) + 1] * scale);
-      cnt = (u >= 3.0f && v >= 3.0f && u < (float)(W - 3) && v < (float)(Hh - 3)) ? 1 : 0;
-    } else {
-      const int s = job.seg_off + (f - job.n_pts);
-      if (b.seg_alive[s]) {
-        // precomputeGaussNewtonParamsSegments :299-301: (px*scale).cast<int>() against cam->isInFrame(.,3,level)
-        const double sx = b.seg_spx[2 * s], sy = b.seg_spx[2 * s + 1], ex = b.seg_epx[2 * s], ey = b.seg_epx[2 * s + 1];
-        const int cw = job.width / (1 << level), ch = job.height / (1 << level);
-        const int isx = (int)(sx * scale), isy = (int)(sy * scale), iex = (int)(ex * scale), iey = (int)(ey * scale);
-        const bool vis = isx >= 3 && isx < cw - 3 && isy >= 3 && isy < ch - 3 && iex >= 3 && iex < cw - 3 && iey >= 3 && iey < ch - 3;
-        if (vis) cnt = seg_num_samples(sx, sy, ex, ey, b.seg_len[s], level);
-      }
-    }
-    s_cnt[f] = cnt;
-  }
-  __syncthreads();
-  const int n_patch = block_exclusive_scan<T>(s_cnt, nfeat, s_ctl + 4);
-  if (n_patch > cap || n_patch > job.patch_cap) {  // host capacity bound violated: flag and bail out (uniform)
-    if (tid == 0) st->error = 1;
-    return;
-  }
-  // every feature thread reads its own offset before s_uv (aliased) is overwritten by anybody
-  int my_off[4]; int my_cnt[4];  // up to 4 features per thread without re-reading (nfeat <= 4*T), else loop below
-  const int feat_rounds = (nfeat + T - 1) / T;
-  for (int k = 0; k < 4; ++k) {
-    const int f = tid + k * T;
-    my_off[k] = (k < feat_rounds && f < nfeat) ? s_cnt[f] : 0;
-    my_cnt[k] = (k < feat_rounds && f < nfeat) ? ((f + 1 < nfeat ? s_cnt[f + 1] : n_patch) - s_cnt[f]) : 0;
-  }
-  if (feat_rounds > 4) { if (tid == 0) st->error = 2; return; }
-  __syncthreads();
   const size_t pbase = (size_t)job.patch_off;
-  for (int k = 0; k < feat_rounds; ++k) {
-    const int f = tid + k * T;
-    if (f >= nfeat || my_cnt[k] == 0) continue;
-    const int p0 = my_off[k];
-    if (f < job.n_pts) {
-      const int i = job.pt_off + f;
-      s_meta[p0] = make_int2(f, p0 | (1 << 20));                 // x >= 0: point index; y: first | N<<20
-      s_dead[p0] = 0;
-      b.patch_uvref[2 * (pbase + p0)] = (float)(b.pt_px[2 * i] * scale);
-      b.patch_uvref[2 * (pbase + p0) + 1] = (float)(b.pt_px[2 * i + 1] * scale);
-      b.patch_xyz[3 * (pbase + p0)] = b.pt_xyz[3 * i];
-      b.patch_xyz[3 * (pbase + p0) + 1] = b.pt_xyz[3 * i + 1];
-      b.patch_xyz[3 * (pbase + p0) + 2] = b.pt_xyz[3 * i + 2];
-    } else {
-      const int sl = f - job.n_pts, s = job.seg_off + sl;
-      const int N = my_cnt[k];
-      // :316-332: 2-D step on the level image, 3-D step between the end points, both accumulated
-      const double sx = b.seg_spx[2 * s], sy = b.seg_spx[2 * s + 1];
-      double inc2x = (b.seg_epx[2 * s] - sx) * scale / (double)(N - 1);
-      double inc2y = (b.seg_epx[2 * s + 1] - sy) * scale / (double)(N - 1);
-      double px = sx * scale, py = sy * scale;
-      double xr[3], inc3[3];
-      for (int c = 0; c < 3; ++c) {
-        const double pr = b.seg_p[3 * s + c];
-        inc3[c] = (b.seg_q[3 * s + c] - pr) / (double)(N - 1);
-        xr[c] = pr;
-      }
-      for (int n = 0; n < N; ++n) {
-        const int p = p0 + n;
-        s_meta[p] = make_int2(-1 - sl, p0 | (N << 20));           // x < 0: segment index = -1 - x
-        s_dead[p] = 0;
-        b.patch_uvref[2 * (pbase + p)] = (float)px;
-        b.patch_uvref[2 * (pbase + p) + 1] = (float)py;
-        b.patch_xyz[3 * (pbase + p)] = xr[0];
-        b.patch_xyz[3 * (pbase + p) + 1] = xr[1];
-        b.patch_xyz[3 * (pbase + p) + 2] = xr[2];
-        px += inc2x; py += inc2y;
-        xr[0] += inc3[0]; xr[1] += inc3[1]; xr[2] += inc3[2];
-      }
+  const int nfeat = job.n_pts + job.n_seg;
+
+  for (int level = lv_first; level >= lv_last; --level) {
+    // (level geometry is recomputed instead of indexing the kernel-argument arrays with a run-time level,
+    //  which would force the whole argument struct into scratch memory)
+    const int W = job.width >> level, Hh = job.height >> level;
+    const unsigned int lvl_off = pyr_level_offset(job.width, job.height, level);
+    const uint8_t* ref_img = b.pyr.base + (size_t)job.ref_slot * b.pyr.slot_bytes + lvl_off;
+    const uint8_t* cur_img = b.pyr.base + (size_t)job.cur_slot * b.pyr.slot_bytes + lvl_off;
+    const int img_bytes = W * Hh;
+    const bool lds_img = img_bytes + 16 <= lds_img_cap;   // wave-uniform
+    __syncthreads();  // previous level done with every LDS table
+
+    // ---- stage the current level image into LDS when it is small (coalesced 16 B per lane) ----
+    if (lds_img) {
+      const int n16 = img_bytes >> 4;
+      for (int i = tid; i < n16; i += T)
+        reinterpret_cast<uint4*>(s_img)[i] = reinterpret_cast<const uint4*>(cur_img)[i];
+      for (int i = (n16 << 4) + tid; i < img_bytes + 16; i += T)
+        s_img[i] = (i < img_bytes) ? cur_img[i] : (uint8_t)0;
     }
-  }
-  __syncthreads();  // patch_uvref / patch_xyz (global) and s_meta (LDS) visible to the workgroup
+    if (tid == 0) { s_ctl[0] = 0; s_ctl[2] = 0; s_pose[27] = 0.0; }
 
-  // ---- reference patches: interpolated intensity + central-difference gradient (:236-264, :348-375) ----
-  for (int pb = 0; pb < n_patch; pb += G) {
-    const int p = pb + grp;
-    if (p < n_patch) {
-      const float u = b.patch_uvref[2 * (pbase + p)], v = b.patch_uvref[2 * (pbase + p) + 1];
-      const PatchW pw = patch_weights(u, v);
-      // patch row `row` sits on image row vi-2+row; the stencil needs image rows -1..+2 around it
-      const int r0 = pw.vi - 2 + row - 1;
-      const int c0 = pw.ui - 2 - 1;
-      float I[4][7];
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) load_row7(ref_img, (r0 + rr) * W + c0, I[rr]);
-      float4 vr, vx, vy;
-      float* pr = reinterpret_cast<float*>(&vr); float* pxp = reinterpret_cast<float*>(&vx); float* pyp = reinterpret_cast<float*>(&vy);
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        const int c = x + 1;  // column of pixel x inside I[.][0..6]
-        // B(r,c) = wTL*I[r][c] + wTR*I[r][c+1] + wBL*I[r+1][c] + wBR*I[r+1][c+1]
-        const float ref = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, I[1][c], I[1][c + 1], I[2][c], I[2][c + 1]);
-        const float xp = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, I[1][c + 1], I[1][c + 2], I[2][c + 1], I[2][c + 2]);
-        const float xm = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, I[1][c - 1], I[1][c], I[2][c - 1], I[2][c]);
-        const float yp = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, I[2][c], I[2][c + 1], I[3][c], I[3][c + 1]);
-        const float ym = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, I[0][c], I[0][c + 1], I[1][c], I[1][c + 1]);
-        pr[x] = ref;
-        pxp[x] = __fmul_rn(0.5f, __fsub_rn(xp, xm));
-        pyp[x] = __fmul_rn(0.5f, __fsub_rn(yp, ym));
-      }
-      const size_t q = (pbase + p) * 4 + row;  // float4 index: patch-major, row-minor -> coalesced
-      reinterpret_cast<float4*>(b.cache_ref)[q] = vr;
-      reinterpret_cast<float4*>(b.cache_dx)[q] = vx;
-      reinterpret_cast<float4*>(b.cache_dy)[q] = vy;
-    }
-  }
-  __syncthreads();  // LDS image, pose state and cache complete
-
-  // ---- Gauss-Newton iterations ([ext] NLLSSolver::optimizeGaussNewton) ----
-  const double fs = fabs(job.fx) / (double)(1 << level);  // focal_length / (1<<level)  :262
-  const float colmax = (float)(W - 2), rowmax = (float)(Hh - 2);
-  if (tid == 0) { SE3d m = se3_load(s_pose + 12); quat_to_matrix(m.q, s_pose); s_pose[9] = m.t[0]; s_pose[10] = m.t[1]; s_pose[11] = m.t[2]; }
-  __syncthreads();
-
-  for (int iter = 0; iter < job.n_iter; ++iter) {
-    // -- phase 0: one lane per patch: warp the 3-D point, project, in-frame test (:422-431, :583-594)
-    {
-      const double R0 = s_pose[0], R1 = s_pose[1], R2 = s_pose[2], R3 = s_pose[3], R4 = s_pose[4], R5 = s_pose[5],
-                   R6 = s_pose[6], R7 = s_pose[7], R8 = s_pose[8], t0 = s_pose[9], t1 = s_pose[10], t2 = s_pose[11];
-      for (int p = tid; p < n_patch; p += T) {
-        const int2 meta = s_meta[p];
-        const int first = meta.y & 0xfffff;
-        float2 uv;
-        if (meta.x < 0 && s_dead[first]) {
-          uv = make_float2(-2.0f, -2.0f);  // line already culled
-        } else {
-          const double x = b.patch_xyz[3 * (pbase + p)], y = b.patch_xyz[3 * (pbase + p) + 1], z = b.patch_xyz[3 * (pbase + p) + 2];
-          const double xc = R0 * x + R1 * y + R2 * z + t0;
-          const double yc = R3 * x + R4 * y + R5 * z + t1;
-          const double zc = R6 * x + R7 * y + R8 * z + t2;
-          const float u = (float)((job.fx * (xc / zc) + job.cx) * scale);
-          const float v = (float)((job.fy * (yc / zc) + job.cy) * scale);
-          // Patch::isInFrame(halfsize=2) on floorf(u), floorf(v); NaN -> out of frame
-          const bool in = (u >= 2.0f) && (v >= 2.0f) && (u < colmax) && (v < rowmax);
-          uv = in ? make_float2(u, v) : make_float2(-1.0f, -1.0f);
+    // ---- patch table: count, scan, emit ----
+    const double scale = 1.0 / (double)(1 << level);  // the reference's float scale is a power of two: exact
+    int* s_cnt = reinterpret_cast<int*>(s_uv);  // aliased: nfeat <= cap
+    for (int f = tid; f < nfeat; f += T) {
+      int cnt = 0;
+      if (f < job.n_pts) {
+        // precomputeGaussNewtonParamsPoints :216-219: floor of the float position, 3 px border
+        const float u = (float)(b.pt_px[2 * (job.pt_off + f)] * scale), v = (float)(b.pt_px[2 * (job.pt_off + f) + 1] * scale);
+        cnt = (u >= 3.0f && v >= 3.0f && u < (float)(W - 3) && v < (float)(Hh - 3)) ? 1 : 0;
+      } else {
+        const int s = job.seg_off + (f - job.n_pts);
+        if (b.seg_alive[s]) {
+          // precomputeGaussNewtonParamsSegments :299-301: (px*scale).cast<int>() against cam->isInFrame(.,3,level)
+          const double sx = b.seg_spx[2 * s], sy = b.seg_spx[2 * s + 1], ex = b.seg_epx[2 * s], ey = b.seg_epx[2 * s + 1];
+          const int cw = job.width / (1 << level), ch = job.height / (1 << level);
+          const int isx = (int)(sx * scale), isy = (int)(sy * scale), iex = (int)(ex * scale), iey = (int)(ey * scale);
+          const bool vis = isx >= 3 && isx < cw - 3 && isy >= 3 && isy < ch - 3 && iex >= 3 && iex < cw - 3 && iey >= 3 && iey < ch - 3;
+          if (vis) cnt = seg_num_samples(sx, sy, ex, ey, b.seg_len[s], level);
         }
-        s_uv[p] = uv;
       }
+      s_cnt[f] = cnt;
     }
     __syncthreads();
+    const int n_patch = block_exclusive_scan<T>(s_cnt, nfeat, s_ctl + 4);
+    constexpr int FR = (T >= 256) ? 4 : 1024 / T;   // features per thread kept in registers across the emit
+    const int feat_rounds = (nfeat + T - 1) / T;
+    if (n_patch > cap || n_patch > job.patch_cap || feat_rounds > FR) {  // host capacity bound violated: flag and bail out (uniform)
+      if (tid == 0) st->error = (feat_rounds > FR) ? 2 : 1;
+      return;
+    }
+    // every feature thread reads its own offset before s_uv (aliased) is overwritten by anybody
+    int my_off[FR]; int my_cnt[FR];
+#pragma unroll
+    for (int k = 0; k < FR; ++k) {
+      const int f = tid + k * T;
+      my_off[k] = (k < feat_rounds && f < nfeat) ? s_cnt[f] : 0;
+      my_cnt[k] = (k < feat_rounds && f < nfeat) ? ((f + 1 < nfeat ? s_cnt[f + 1] : n_patch) - s_cnt[f]) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < FR; ++k) {
+      const int f = tid + k * T;
+      if (k >= feat_rounds || f >= nfeat || my_cnt[k] == 0) continue;
+      const int p0 = my_off[k];
+      if (f < job.n_pts) {
+        const int i = job.pt_off + f;
+        s_meta[p0] = make_int2(f, p0 | (1 << 20));                 // x >= 0: point index; y: first | N<<20
+        s_dead[p0] = 0;
+        b.patch_uvref[2 * (pbase + p0)] = (float)(b.pt_px[2 * i] * scale);
+        b.patch_uvref[2 * (pbase + p0) + 1] = (float)(b.pt_px[2 * i + 1] * scale);
+        b.patch_xyz[3 * (pbase + p0)] = b.pt_xyz[3 * i];
+        b.patch_xyz[3 * (pbase + p0) + 1] = b.pt_xyz[3 * i + 1];
+        b.patch_xyz[3 * (pbase + p0) + 2] = b.pt_xyz[3 * i + 2];
+      } else {
+        const int sl = f - job.n_pts, s = job.seg_off + sl;
+        const int N = my_cnt[k];
+        // :316-332: 2-D step on the level image, 3-D step between the end points, both accumulated
+        const double sx = b.seg_spx[2 * s], sy = b.seg_spx[2 * s + 1];
+        double inc2x = (b.seg_epx[2 * s] - sx) * scale / (double)(N - 1);
+        double inc2y = (b.seg_epx[2 * s + 1] - sy) * scale / (double)(N - 1);
+        double px = sx * scale, py = sy * scale;
+        double xr[3], inc3[3];
+        for (int c = 0; c < 3; ++c) {
+          const double pr = b.seg_p[3 * s + c];
+          inc3[c] = (b.seg_q[3 * s + c] - pr) / (double)(N - 1);
+          xr[c] = pr;
+        }
+        for (int n = 0; n < N; ++n) {
+          const int p = p0 + n;
+          s_meta[p] = make_int2(-1 - sl, p0 | (N << 20));           // x < 0: segment index = -1 - x
+          s_dead[p] = 0;
+          b.patch_uvref[2 * (pbase + p)] = (float)px;
+          b.patch_uvref[2 * (pbase + p) + 1] = (float)py;
+          b.patch_xyz[3 * (pbase + p)] = xr[0];
+          b.patch_xyz[3 * (pbase + p) + 1] = xr[1];
+          b.patch_xyz[3 * (pbase + p) + 2] = xr[2];
+          px += inc2x; py += inc2y;
+          xr[0] += inc3[0]; xr[1] += inc3[1]; xr[2] += inc3[2];
+        }
+      }
+    }
+    __syncthreads();  // patch_uvref / patch_xyz (global) and s_meta (LDS) visible to the workgroup
 
-    // -- phase 1: 4 lanes per patch, one patch row each: residuals and the five patch sums
-    int evals = 0;
+    // ---- reference patches: interpolated intensity + central-difference gradient (:236-264, :348-375) ----
     for (int pb = 0; pb < n_patch; pb += G) {
       const int p = pb + grp;
-      double sA = 0, sB = 0, sC = 0, sD = 0, sE = 0, sChi = 0;
-      float sAbs = 0.0f;
-      bool live = false;
       if (p < n_patch) {
-        const float2 uv = s_uv[p];
-        if (uv.x >= 0.0f) {
-          live = true;
-          const bool is_point = s_meta[p].x >= 0;
-          const PatchW pw = patch_weights(uv.x, uv.y);
+        const float u = b.patch_uvref[2 * (pbase + p)], v = b.patch_uvref[2 * (pbase + p) + 1];
+        const PatchW pw = patch_weights(u, v);
+        // patch row `row` sits on image row vi-2+row; the stencil needs image rows -1..+2 around it
+        const int r0 = pw.vi - 2 + row - 1;
+        const int c0 = pw.ui - 2 - 1;
+        float I[4][7];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) load_row7(ref_img, (r0 + rr) * W + c0, I[rr]);
+        float4 vr, vx, vy;
+        float* pr = reinterpret_cast<float*>(&vr); float* pxp = reinterpret_cast<float*>(&vx); float* pyp = reinterpret_cast<float*>(&vy);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int c = x + 1;  // column of pixel x inside I[.][0..6]
+          // B(r,c) = wTL*I[r][c] + wTR*I[r][c+1] + wBL*I[r+1][c] + wBR*I[r+1][c+1]
+          const float ref = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, I[1][c], I[1][c + 1], I[2][c], I[2][c + 1]);
+          const float xp = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, I[1][c + 1], I[1][c + 2], I[2][c + 1], I[2][c + 2]);
+          const float xm = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, I[1][c - 1], I[1][c], I[2][c - 1], I[2][c]);
+          const float yp = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, I[2][c], I[2][c + 1], I[3][c], I[3][c + 1]);
+          const float ym = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, I[0][c], I[0][c + 1], I[1][c], I[1][c + 1]);
+          pr[x] = ref;
+          pxp[x] = __fmul_rn(0.5f, __fsub_rn(xp, xm));
+          pyp[x] = __fmul_rn(0.5f, __fsub_rn(yp, ym));
+        }
+        const size_t q = (pbase + p) * 4 + row;  // float4 index: patch-major, row-minor -> coalesced
+        reinterpret_cast<float4*>(b.cache_ref)[q] = vr;
+        reinterpret_cast<float4*>(b.cache_dx)[q] = vx;
+        reinterpret_cast<float4*>(b.cache_dy)[q] = vy;
+      }
+    }
+    if (tid == 0) { SE3d m = se3_load(s_pose + 12); quat_to_matrix(m.q, s_pose); s_pose[9] = m.t[0]; s_pose[10] = m.t[1]; s_pose[11] = m.t[2]; }
+    __syncthreads();  // LDS image, pose state and cache complete
+    TICK(0);
+
+    // ---- Gauss-Newton iterations ([ext] NLLSSolver::optimizeGaussNewton) ----
+    const double fs = fabs(job.fx) / (double)(1 << level);  // focal_length / (1<<level)  :262
+    const float colmax = (float)(W - 2), rowmax = (float)(Hh - 2);
+
+    for (int iter = 0; iter < job.n_iter; ++iter) {
+      // -- phase 0: one lane per patch: warp the 3-D point, project, in-frame test (:422-431, :583-594)
+      {
+        const double R0 = s_pose[0], R1 = s_pose[1], R2 = s_pose[2], R3 = s_pose[3], R4 = s_pose[4], R5 = s_pose[5],
+                     R6 = s_pose[6], R7 = s_pose[7], R8 = s_pose[8], t0 = s_pose[9], t1 = s_pose[10], t2 = s_pose[11];
+        for (int p = tid; p < n_patch; p += T) {
+          const int2 meta = s_meta[p];
+          const int first = meta.y & 0xfffff;
+          float2 uv;
+          if (meta.x < 0 && s_dead[first]) {
+            uv = make_float2(-2.0f, -2.0f);  // line already culled
+          } else {
+            const double x = b.patch_xyz[3 * (pbase + p)], y = b.patch_xyz[3 * (pbase + p) + 1], z = b.patch_xyz[3 * (pbase + p) + 2];
+            const double xc = R0 * x + R1 * y + R2 * z + t0;
+            const double yc = R3 * x + R4 * y + R5 * z + t1;
+            const double zc = R6 * x + R7 * y + R8 * z + t2;
+            const float u = (float)((job.fx * (xc / zc) + job.cx) * scale);
+            const float v = (float)((job.fy * (yc / zc) + job.cy) * scale);
+            // Patch::isInFrame(halfsize=2) on floorf(u), floorf(v); NaN -> out of frame
+            const bool in = (u >= 2.0f) && (v >= 2.0f) && (u < colmax) && (v < rowmax);
+            uv = in ? make_float2(u, v) : make_float2(-1.0f, -1.0f);
+          }
+          s_uv[p] = uv;
+        }
+      }
+      __syncthreads();
+      TICK(1);
+
+      // -- phase 1: 4 lanes per patch, one patch row each: residuals and the five patch sums.
+      //    Software-pipelined: the loads of round r+1 are issued before round r is computed.
+      int evals = 0;
+      auto fetch = [&](int pb) -> P1Fetch {
+        P1Fetch f;
+        f.flags = 0; f.uv = make_float2(-1.0f, -1.0f); f.t0 = f.t1 = f.b0 = f.b1 = 0u; f.sh = 0;
+        f.vr = f.vx = f.vy = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int p = pb + grp;
+        if (p < n_patch) {
+          f.uv = s_uv[p];
+          if (f.uv.x >= 0.0f) {
+            f.flags = 1 | ((s_meta[p].x >= 0) ? 2 : 0);
+            const int ui = (int)floorf(f.uv.x), vi = (int)floorf(f.uv.y);
+            const int off = (vi - 2 + row) * W + (ui - 2);
+            const int a = off & ~3, ab = (off + W) & ~3;
+            f.sh = off & 3;
+            if (lds_img) {
+              f.t0 = *reinterpret_cast<const uint32_t*>(s_img + a); f.t1 = *reinterpret_cast<const uint32_t*>(s_img + a + 4);
+              f.b0 = *reinterpret_cast<const uint32_t*>(s_img + ab); f.b1 = *reinterpret_cast<const uint32_t*>(s_img + ab + 4);
+            } else {
+              f.t0 = *reinterpret_cast<const uint32_t*>(cur_img + a); f.t1 = *reinterpret_cast<const uint32_t*>(cur_img + a + 4);
+              f.b0 = *reinterpret_cast<const uint32_t*>(cur_img + ab); f.b1 = *reinterpret_cast<const uint32_t*>(cur_img + ab + 4);
+            }
+            const size_t q = (pbase + p) * 4 + row;
+            f.vr = reinterpret_cast<const float4*>(b.cache_ref)[q];
+            f.vx = reinterpret_cast<const float4*>(b.cache_dx)[q];
+            f.vy = reinterpret_cast<const float4*>(b.cache_dy)[q];
+          }
+        }
+        return f;
+      };
+#ifdef PLSVO_NO_PREFETCH
+      P1Fetch cur;
+      for (int pb = 0; pb < n_patch; pb += G) {
+        cur = fetch(pb);
+        const P1Fetch nxt = cur;
+#else
+      P1Fetch cur = fetch(0);
+      for (int pb = 0; pb < n_patch; pb += G) {
+        const P1Fetch nxt = fetch(pb + G);
+#endif
+        const int p = pb + grp;
+        double sA = 0, sB = 0, sC = 0, sD = 0, sE = 0, sChi = 0;
+        float sAbs = 0.0f;
+        const bool live = (cur.flags & 1) != 0;
+        if (live) {
+          const bool is_point = (cur.flags & 2) != 0;
+          const PatchW pw = patch_weights(cur.uv.x, cur.uv.y);
+          const int sh_t = cur.sh, sh_b = (cur.sh + W) & 3;   // byte shifts of the top / bottom row inside their dword pairs
           float top[5], bot[5];
-          const int off = (pw.vi - 2 + row) * W + (pw.ui - 2);
-          load_row5(gimg, off, top);
-          load_row5(gimg, off + W, bot);
-          const size_t q = (pbase + p) * 4 + row;
-          const float4 vr = reinterpret_cast<const float4*>(b.cache_ref)[q];
-          const float4 vx = reinterpret_cast<const float4*>(b.cache_dx)[q];
-          const float4 vy = reinterpret_cast<const float4*>(b.cache_dy)[q];
-          const float* pr = reinterpret_cast<const float*>(&vr);
-          const float* pxp = reinterpret_cast<const float*>(&vx);
-          const float* pyp = reinterpret_cast<const float*>(&vy);
+          {
+            const uint32_t w0 = __builtin_amdgcn_alignbyte(cur.t1, cur.t0, sh_t);
+            top[0] = (float)(w0 & 0xffu); top[1] = (float)((w0 >> 8) & 0xffu); top[2] = (float)((w0 >> 16) & 0xffu); top[3] = (float)(w0 >> 24);
+            top[4] = (float)((cur.t1 >> (8 * sh_t)) & 0xffu);
+          }
+          {
+            const uint32_t w0 = __builtin_amdgcn_alignbyte(cur.b1, cur.b0, sh_b);
+            bot[0] = (float)(w0 & 0xffu); bot[1] = (float)((w0 >> 8) & 0xffu); bot[2] = (float)((w0 >> 16) & 0xffu); bot[3] = (float)(w0 >> 24);
+            bot[4] = (float)((cur.b1 >> (8 * sh_b)) & 0xffu);
+          }
+          const float* pr = reinterpret_cast<const float*>(&cur.vr);
+          const float* pxp = reinterpret_cast<const float*>(&cur.vx);
+          const float* pyp = reinterpret_cast<const float*>(&cur.vy);
 #pragma unroll
           for (int x = 0; x < 4; ++x) {
-            const float cur = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, top[x], top[x + 1], bot[x], bot[x + 1]);
-            const float res = __fsub_rn(cur, pr[x]);
+            const float c = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, top[x], top[x + 1], bot[x], bot[x + 1]);
+            const float res = __fsub_rn(c, pr[x]);
             const float ares = fabsf(res);
             // points: w = 1/(1+|r|) (:479); line pixels are accumulated unweighted (:627-629)
             const float w = is_point ? robust_weight(ares) : 1.0f;
@@ -376,167 +521,205 @@ __global__ __launch_bounds__(T) void align_level_kernel(AlignBatchDev b, int lev
             sAbs += ares;
           }
         }
-      }
-      sA = quad_sum(sA); sB = quad_sum(sB); sC = quad_sum(sC); sD = quad_sum(sD); sE = quad_sum(sE);
-      sChi = quad_sum(sChi); sAbs = quad_sum(sAbs);
-      if (p < n_patch && row == 0) {
-        double* dst = b.partial + 6 * (pbase + p);
-        dst[0] = sA; dst[1] = sB; dst[2] = sC; dst[3] = sD; dst[4] = sE; dst[5] = sChi;
-        s_abs[p] = live ? sAbs : -1.0f;
-        evals += live ? 1 : 0;
-      }
-    }
-    __syncthreads();
-
-    // -- phase 2: one lane per patch: per-line weight, 6x6 expansion, lane-private accumulation
-    double aH[21], aJ[6], aChi = 0.0;
-#pragma unroll
-    for (int k = 0; k < 21; ++k) aH[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) aJ[k] = 0.0;
-    int n_meas = 0;
-    for (int p = tid; p < n_patch; p += T) {
-      const int2 meta = s_meta[p];
-      const float2 uv = s_uv[p];
-      double wh = 0.0, wj = 0.0;
-      const double* src = b.partial + 6 * (pbase + p);
-      if (meta.x >= 0) {
-        if (uv.x >= 0.0f) { wh = 1.0; wj = 1.0; n_meas += PLSVO_PATCH_AREA; aChi += src[5]; }
-      } else if (uv.x > -1.5f) {  // live line (not culled earlier); uv.x == -1 marks an out-of-frame sample
-        const int first = meta.y & 0xfffff, N = meta.y >> 20;
-        bool good = true; float sum = 0.0f;
-        for (int n = 0; n < N; ++n) { const float a = s_abs[first + n]; good = good && (a >= 0.0f); sum += a; }
-        const float res_ = (float)((double)sum / (double)N);                 // :647 (divides by #samples)
-        if (good && (double)res_ < 200.0) {                                  // :648
-          const float w = (float)(1.0 / (1.0 + (double)res_));               // :675
-          wh = (double)w / (double)res_;                                     // :681  H += H_ * w / res_
-          wj = (double)w;                                                    // :682  Jres += Jres_ * w
-          if (p == first) { aChi += (double)__fmul_rn(__fmul_rn(res_, res_), w); n_meas += 1; }  // :683-684
-        } else if (p == first) {
-          s_dead[first] = 1;                                                 // :687-688 it->feat3D = NULL
-          b.seg_alive[job.seg_off + (-1 - meta.x)] = 0;
+        sA = quad_sum(sA); sB = quad_sum(sB); sC = quad_sum(sC); sD = quad_sum(sD); sE = quad_sum(sE);
+        sChi = quad_sum(sChi); sAbs = quad_sum(sAbs);
+        if (p < n_patch && row == 0) {
+          double* dst = b.partial + 6 * (pbase + p);
+          dst[0] = sA; dst[1] = sB; dst[2] = sC; dst[3] = sD; dst[4] = sE; dst[5] = sChi;
+          s_abs[p] = live ? sAbs : -1.0f;
+          evals += live ? 1 : 0;
         }
+        cur = nxt;
       }
-      if (wh != 0.0 || wj != 0.0) {
-        double xyz[3] = { b.patch_xyz[3 * (pbase + p)], b.patch_xyz[3 * (pbase + p) + 1], b.patch_xyz[3 * (pbase + p) + 2] };
-        double J[12];
-        jacobian_xyz2uv(xyz, J);
-        const double hs = wh * fs * fs, js = wj * fs;
-        const double A = src[0] * hs, B = src[1] * hs, C = src[2] * hs, D = src[3] * js, E = src[4] * js;
-        double P[6], Q[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { P[k] = A * J[k] + B * J[6 + k]; Q[k] = B * J[k] + C * J[6 + k]; }
-        int k = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-          for (int jj = i; jj < 6; ++jj) { aH[k] += J[i] * P[jj] + J[6 + i] * Q[jj]; ++k; }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) aJ[i] -= D * J[i] + E * J[6 + i];
-      }
-    }
-    // -- block reduction (fixed shape): DPP inside the wave, LDS across waves
-    {
-      double* dst = s_red + RED_N * wave;
-#pragma unroll
-      for (int k = 0; k < 21; ++k) { const double v = wave_sum_to_lane63(aH[k]); if (lane == 63) dst[k] = v; }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) { const double v = wave_sum_to_lane63(aJ[k]); if (lane == 63) dst[21 + k] = v; }
-      { const double v = wave_sum_to_lane63(aChi); if (lane == 63) dst[27] = v; }
-      { const double v = wave_sum_to_lane63((double)n_meas); if (lane == 63) dst[28] = v; }
-      { const double v = wave_sum_to_lane63((double)evals); if (lane == 63) dst[29] = v; }
-    }
-    __syncthreads();
+      __syncthreads();
+      TICK(2);
 
-    // -- cross-wave totals (fixed order), then wave 0 solves the 6x6 system cooperatively and its
-    //    lane 0 takes the accept / roll back / update decision
-    if (tid < 30) { double v = 0.0; for (int w = 0; w < T / 64; ++w) v += s_red[RED_N * w + tid]; s_tot[tid] = v; }
-    __syncthreads();
-    if (wave == 0) {
-      double x[6];
-      wave_solve6(s_tot, x);                                                 // solve() :699
-      if (lane == 0) {
-        const unsigned long long nm = (unsigned long long)(s_tot[28] + 0.5);
-        s_pose[27] += s_tot[29];
-        s_ctl[2] += 1;
-        // computeResiduals returns float chi2 / n_meas_ (:171,192)
-        const double new_chi2 = (double)((float)s_tot[27] / (float)nm);
-        int stop = s_ctl[1];
-        if (isnan(x[0])) stop = 1;                                           // :700
-        SE3d model = se3_load(s_pose + 12);
-        int accepted, brk = 0;
-        if ((iter > 0 && new_chi2 > s_pose[26]) || stop) {
-          model = se3_load(s_pose + 19);                                     // rollback to old_model
-          accepted = 0; brk = 1;
-        } else {
-          double mx[6];
-          for (int k = 0; k < 6; ++k) mx[k] = -x[k];
-          const SE3d nm_ = se3_mul(model, se3_exp(mx));                      // update() :709
-          se3_store(model, s_pose + 19);                                     // old_model = model
-          model = nm_;
-          s_pose[26] = new_chi2;
-          accepted = 1;
-          if (norm_max6(x) <= job.eps) brk = 1;
-        }
-        se3_store(model, s_pose + 12);
-        quat_to_matrix(model.q, s_pose); s_pose[9] = model.t[0]; s_pose[10] = model.t[1]; s_pose[11] = model.t[2];
-        s_ctl[1] = stop; s_ctl[0] = brk;
-        if (b.log) {
-          const int lc = st->log_count;
-          if (lc < b.log_cap) {
-            plsvo_align_iterlog* r = b.log + (size_t)job_id * b.log_cap + lc;
-            r->level = level; r->iter = iter; r->accepted = accepted; r->stop = stop; r->n_meas = nm; r->new_chi2 = new_chi2;
-            for (int i = 0; i < 6; ++i) for (int jj = 0; jj < 6; ++jj) r->H[i * 6 + jj] = s_tot[sym6_index(i, jj)];
-            for (int k = 0; k < 6; ++k) { r->Jres[k] = s_tot[21 + k]; r->x[k] = x[k]; }
-            se3_store(model, r->T_after);
+      // -- phase 2: one lane per patch: per-line weight, 6x6 expansion, lane-private accumulation
+      double acc[30];   // 0..20 H (upper, row-major), 21..26 Jres, 27 chi2, 28 n_meas, 29 evals
+#pragma unroll
+      for (int k = 0; k < 30; ++k) acc[k] = 0.0;
+      int n_meas = 0;
+      for (int p = tid; p < n_patch; p += T) {
+        const int2 meta = s_meta[p];
+        const float2 uv = s_uv[p];
+        double wh = 0.0, wj = 0.0;
+        const double* src = b.partial + 6 * (pbase + p);
+        if (meta.x >= 0) {
+          if (uv.x >= 0.0f) { wh = 1.0; wj = 1.0; n_meas += PLSVO_PATCH_AREA; acc[27] += src[5]; }
+        } else if (uv.x > -1.5f) {  // live line (not culled earlier); uv.x == -1 marks an out-of-frame sample
+          const int first = meta.y & 0xfffff, N = meta.y >> 20;
+          bool good = true; float sum = 0.0f;
+          for (int n = 0; n < N; ++n) { const float a = s_abs[first + n]; good = good && (a >= 0.0f); sum += a; }
+          const float res_ = (float)((double)sum / (double)N);                 // :647 (divides by #samples)
+          if (good && (double)res_ < 200.0) {                                  // :648
+            const float w = (float)(1.0 / (1.0 + (double)res_));               // :675
+            wh = (double)w / (double)res_;                                     // :681  H += H_ * w / res_
+            wj = (double)w;                                                    // :682  Jres += Jres_ * w
+            if (p == first) { acc[27] += (double)__fmul_rn(__fmul_rn(res_, res_), w); n_meas += 1; }  // :683-684
+          } else if (p == first) {
+            s_dead[first] = 1;                                                 // :687-688 it->feat3D = NULL
+            b.seg_alive[job.seg_off + (-1 - meta.x)] = 0;
           }
-          st->log_count = lc + 1;
+        }
+        if (wh != 0.0 || wj != 0.0) {
+          double xyz[3] = { b.patch_xyz[3 * (pbase + p)], b.patch_xyz[3 * (pbase + p) + 1], b.patch_xyz[3 * (pbase + p) + 2] };
+          double J[12];
+          jacobian_xyz2uv(xyz, J);
+          const double hs = wh * fs * fs, js = wj * fs;
+          const double A = src[0] * hs, B = src[1] * hs, C = src[2] * hs, D = src[3] * js, E = src[4] * js;
+          // H += r0 (A r0 + B r1)^T + r1 (B r0 + C r1)^T, in two passes to keep the live register set small
+          {
+            double Pv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Pv[k] = A * J[k] + B * J[6 + k];
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+              for (int jj = i; jj < 6; ++jj) { acc[k] += J[i] * Pv[jj]; ++k; }
+          }
+          {
+            double Qv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Qv[k] = B * J[k] + C * J[6 + k];
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+              for (int jj = i; jj < 6; ++jj) { acc[k] += J[6 + i] * Qv[jj]; ++k; }
+          }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) acc[21 + i] -= D * J[i] + E * J[6 + i];
         }
       }
-    }
-    __syncthreads();
-    if (s_ctl[0]) break;
-  }
+      acc[28] = (double)n_meas; acc[29] = (double)evals;
+      TICK(3);
+      // -- block reduction (fixed shape).  Step-major over all 30 values so the DPP chains interleave.
+#pragma unroll
+      for (int c0 = 0; c0 < 30; c0 += 6) {   // six independent chains at a time: enough ILP, bounded live registers
+#pragma unroll
+        for (int k = c0; k < c0 + 6; ++k) acc[k] += dpp_mov_f64<DPP_QUAD_XOR1>(acc[k]);
+#pragma unroll
+        for (int k = c0; k < c0 + 6; ++k) acc[k] += dpp_mov_f64<DPP_QUAD_XOR2>(acc[k]);
+#pragma unroll
+        for (int k = c0; k < c0 + 6; ++k) acc[k] += dpp_mov_f64<DPP_ROW_HALF_MIRROR>(acc[k]);
+#pragma unroll
+        for (int k = c0; k < c0 + 6; ++k) acc[k] += dpp_mov_f64<DPP_ROW_MIRROR>(acc[k]);
+#pragma unroll
+        for (int k = c0; k < c0 + 6; ++k) acc[k] += dpp_bcast_f64<DPP_ROW_BCAST15, 0xA>(acc[k]);
+#pragma unroll
+        for (int k = c0; k < c0 + 6; ++k) acc[k] += dpp_bcast_f64<DPP_ROW_BCAST31, 0xC>(acc[k]);
+      }
+      if (lane == 63) {
+        double* dst = s_red + RED_N * wave;
+#pragma unroll
+        for (int k = 0; k < 30; ++k) dst[k] = acc[k];
+      }
+      __syncthreads();
+      TICK(4);
 
+      // -- wave 0: cross-wave totals (fixed order) in lanes 0..29, cooperative 6x6 solve, then lane 0 takes
+      //    the accept / roll back / update decision
+      if (wave == 0) {
+        double tot = 0.0;
+        if (lane < 30) { for (int w = 0; w < T / 64; ++w) tot += s_red[RED_N * w + lane]; s_tot[lane] = tot; }
+        double x[6];
+        wave_solve6_reg(tot, x);                                               // solve() :699
+        const double chi_sum = readlane_f64(tot, 27), nm_d = readlane_f64(tot, 28), ev_d = readlane_f64(tot, 29);
+        if (lane == 0) {
+          const unsigned long long nm = (unsigned long long)(nm_d + 0.5);
+          s_pose[27] += ev_d;
+          s_ctl[2] += 1;
+          // computeResiduals returns float chi2 / n_meas_ (:171,192)
+          const double new_chi2 = (double)((float)chi_sum / (float)nm);
+          int stop = s_ctl[1];
+          if (isnan(x[0])) stop = 1;                                           // :700
+          SE3d model = se3_load(s_pose + 12);
+          int accepted, brk = 0;
+          if ((iter > 0 && new_chi2 > s_pose[26]) || stop) {
+            model = se3_load(s_pose + 19);                                     // rollback to old_model
+            accepted = 0; brk = 1;
+          } else {
+            double mx[6];
+            for (int k = 0; k < 6; ++k) mx[k] = -x[k];
+            const SE3d nm_ = se3_mul(model, se3_exp_dev(mx));                  // update() :709
+            se3_store(model, s_pose + 19);                                     // old_model = model
+            model = nm_;
+            s_pose[26] = new_chi2;
+            accepted = 1;
+            if (norm_max6(x) <= job.eps) brk = 1;
+          }
+          se3_store(model, s_pose + 12);
+          quat_to_matrix(model.q, s_pose); s_pose[9] = model.t[0]; s_pose[10] = model.t[1]; s_pose[11] = model.t[2];
+          s_ctl[1] = stop; s_ctl[0] = brk;
+          if (b.log) {
+            const int lc = st->log_count;
+            if (lc < b.log_cap) {
+              plsvo_align_iterlog* r = b.log + (size_t)job_id * b.log_cap + lc;
+              r->level = level; r->iter = iter; r->accepted = accepted; r->stop = stop; r->n_meas = nm; r->new_chi2 = new_chi2;
+              for (int k = 0; k < 6; ++k) r->x[k] = x[k];
+              se3_store(model, r->T_after);
+            }
+            st->log_count = lc + 1;
+          }
+        }
+      }
+      __syncthreads();
+      if (b.log && tid == 0) {  // H and Jres of the trace come from s_tot (written by lanes 0..26 above)
+        const int lc = st->log_count - 1;
+        if (lc >= 0 && lc < b.log_cap) {
+          plsvo_align_iterlog* r = b.log + (size_t)job_id * b.log_cap + lc;
+          for (int i = 0; i < 6; ++i) for (int jj = 0; jj < 6; ++jj) r->H[i * 6 + jj] = s_tot[sym6_index(i, jj)];
+          for (int k = 0; k < 6; ++k) r->Jres[k] = s_tot[21 + k];
+        }
+      }
+      TICK(5);
+      if (s_ctl[0]) break;
+    }
+
+    if (tid == 0) {
+      st->iters[level] = s_ctl[2];
+      st->patch_levels += (unsigned long long)n_patch;
+      st->patch_iters += (unsigned long long)(s_pose[27] + 0.5);
+    }
+  }  // levels
+
+  __syncthreads();
   if (tid == 0) {
     for (int k = 0; k < 7; ++k) st->T[k] = s_pose[12 + k];
     st->chi2 = s_pose[26];
     st->stop = s_ctl[1];
     st->n_meas = (unsigned long long)(s_tot[28] + 0.5);
     for (int i = 0; i < 6; ++i) for (int jj = 0; jj < 6; ++jj) st->H[i * 6 + jj] = s_tot[sym6_index(i, jj)];
-    st->iters[level] = s_ctl[2];
-    st->patch_levels += (unsigned long long)n_patch;
-    st->patch_iters += (unsigned long long)(s_pose[27] + 0.5);
+#ifdef PLSVO_TIMING
+    for (int k = 0; k < 8; ++k) st->phase_ticks[k] += s_time[k];
+#endif
   }
 }
 
-// LDS bytes the level kernel needs for a given patch capacity / level image (host side helper)
-size_t align_level_lds_bytes(int threads, int cap, int img_bytes_or_0) {
+// LDS bytes the kernel needs for a given patch capacity and staged-image capacity (host side helper)
+size_t align_level_lds_bytes(int threads, int cap, int lds_img_cap) {
   size_t o = sizeof(double) * RED_N * (threads / 64) + sizeof(double) * 64 + sizeof(int) * 32;
   o += (size_t)cap * (sizeof(float2) + sizeof(int2) + sizeof(float) + sizeof(int));
-  if (img_bytes_or_0 > 0) o += (size_t)img_bytes_or_0 + 16;
+  o += (size_t)lds_img_cap;
   return o;
 }
 
 template <int T>
-static hipError_t launch_level_T(const AlignBatchDev& b, int level, int cap, bool lds_img, size_t lds, hipStream_t stream) {
-  if (lds_img) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_level_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((align_level_kernel<T, true>), dim3(b.n_jobs), dim3(T), lds, stream, b, level, cap);
-  } else {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_level_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((align_level_kernel<T, false>), dim3(b.n_jobs), dim3(T), lds, stream, b, level, cap);
-  }
+static hipError_t launch_fused_T(const AlignBatchDev& b, int cap, int lds_img_cap, int level_hi, int level_lo, size_t lds, hipStream_t stream) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_fused_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((align_fused_kernel<T>), dim3(b.n_jobs), dim3(T), lds, stream, b, cap, lds_img_cap, level_hi, level_lo);
   return hipGetLastError();
 }
 
-hipError_t launch_align_level(const AlignBatchDev& b, int level, int cap, int threads, bool lds_img, size_t lds, hipStream_t stream) {
+hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int lds_img_cap, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream) {
   switch (threads) {
-    case 256: return launch_level_T<256>(b, level, cap, lds_img, lds, stream);
-    case 512: return launch_level_T<512>(b, level, cap, lds_img, lds, stream);
-    case 1024: return launch_level_T<1024>(b, level, cap, lds_img, lds, stream);
+    case 64: return launch_fused_T<64>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
+    case 128: return launch_fused_T<128>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
+    case 256: return launch_fused_T<256>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
+    case 512: return launch_fused_T<512>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
+    case 1024: return launch_fused_T<1024>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
     default: return hipErrorInvalidValue;
   }
 }

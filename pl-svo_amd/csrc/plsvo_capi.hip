@@ -18,8 +18,8 @@
 
 namespace plsvo_hip {
 // kernels (align_kernels.hip, poseopt_kernels.hip, pyramid_kernels.hip)
-size_t align_level_lds_bytes(int threads, int cap, int img_bytes_or_0);
-hipError_t launch_align_level(const AlignBatchDev& b, int level, int cap, int threads, bool lds_img, size_t lds, hipStream_t stream);
+size_t align_level_lds_bytes(int threads, int cap, int lds_img_cap);
+hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int lds_img_cap, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream);
 hipError_t launch_align_init(const AlignBatchDev& b, hipStream_t stream);
 hipError_t launch_align_finish(const AlignBatchDev& b, double* d_poses, hipStream_t stream);
 hipError_t launch_pose_opt(const PoseBatchDev& b, hipStream_t stream);
@@ -213,8 +213,8 @@ extern "C" int plsvo_hip_config_pyramids(plsvo_ctx* c, int n_slots, int width, i
   for (int l = 0; l < n_levels; ++l) {
     d.w[l] = width >> l; d.h[l] = height >> l;
     if (d.w[l] <= 0 || d.h[l] <= 0) return fail(c, PLSVO_E_INVALID, "config_pyramids: too many levels for this image size");
-    d.off[l] = (unsigned int)off;
-    off += (((size_t)d.w[l] * d.h[l] + 64) + 255) & ~(size_t)255;  // >= 64 bytes of slack after every level (gather over-read)
+    d.off[l] = pyr_level_offset(width, height, l);
+    off = (size_t)pyr_level_offset(width, height, l + 1);           // >= 64 bytes of slack after every level (gather over-read)
   }
   d.slot_bytes = off; d.n_slots = n_slots; d.n_levels = n_levels;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -403,31 +403,27 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   return PLSVO_OK;
 }
 
-// choose workgroup size / LDS mode for one level launch
-static void pick_level_config(plsvo_ctx* c, int level, int cap, int* threads, bool* lds_img, size_t* lds) {
-  const int img_bytes = c->pyr.w[level] * c->pyr.h[level];
-  int forced_t = 0;
-  if (const char* s = getenv("PLSVO_ALIGN_THREADS")) forced_t = atoi(s);
-  bool allow_lds = true;
-  if (const char* s = getenv("PLSVO_ALIGN_NO_LDS_IMG")) allow_lds = atoi(s) == 0;
-  const size_t limit = c->lds_per_block;
-  // LDS need with the image staged (tables are the same for every workgroup size up to the reduce scratch)
-  const size_t need_img = align_level_lds_bytes(1024, cap, img_bytes);
-  *lds_img = allow_lds && need_img <= limit;
-  int t;
-  if (*lds_img) {
-    // aim at ~16 waves per CU: workgroups per CU limited by LDS (160 KiB), size the workgroup to fill the rest
-    const size_t per_cu = 160 * 1024;
-    int wgs = (int)std::min<size_t>(8, per_cu / need_img);
-    if (wgs < 1) wgs = 1;
-    const int want = 1024 / wgs;
-    t = want <= 256 ? 256 : (want <= 512 ? 512 : 1024);
-  } else {
-    t = 256;
+// Launch configuration of the alignment kernel.
+//   threads      256 (default): four workgroups share a CU when LDS stays below ~40 KB and VGPRs at 128, which
+//                hides the serial solve/update tail of one frame behind the pixel phases of the others.
+//   lds_img_cap  level images up to this many bytes are staged in LDS (default 20 KB: level >= 2 of 640x480),
+//                larger levels are gathered through L2.
+// Environment overrides (experiments only): PLSVO_ALIGN_THREADS, PLSVO_LDS_IMG_CAP, PLSVO_ALIGN_PER_LEVEL.
+static void pick_align_config(plsvo_ctx* c, int cap, int* threads, int* lds_img_cap, size_t* lds) {
+  int t = 256, icap = 20480;
+  if (const char* s = getenv("PLSVO_ALIGN_THREADS")) { const int v = atoi(s); if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) t = v; }
+  if (const char* s = getenv("PLSVO_LDS_IMG_CAP")) icap = atoi(s);
+  if (const char* s = getenv("PLSVO_ALIGN_NO_LDS_IMG")) { if (atoi(s) != 0) icap = 0; }
+  icap = (std::max(icap, 0) + 15) & ~15;
+  // never stage more than the largest level that is actually used, and never exceed the LDS limit
+  int biggest = 0;
+  for (int l = c->a_gmin; l <= c->a_gmax && l >= 0; ++l) {
+    const int bytes = c->pyr.w[l] * c->pyr.h[l] + 16;
+    if (bytes <= icap) biggest = std::max(biggest, bytes);
   }
-  if (forced_t == 256 || forced_t == 512 || forced_t == 1024) t = forced_t;
-  *threads = t;
-  *lds = align_level_lds_bytes(t, cap, *lds_img ? img_bytes : 0);
+  icap = (biggest + 15) & ~15;
+  while (icap > 0 && align_level_lds_bytes(t, cap, icap) > c->lds_per_block) icap = 0;
+  *threads = t; *lds_img_cap = icap; *lds = align_level_lds_bytes(t, cap, icap);
 }
 
 extern "C" int plsvo_align_run(plsvo_ctx* c) {
@@ -439,14 +435,25 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
     HIP_TRY(c, launch_align_init(c->a_b, c->stream));
     prof_end(c, PLSVO_K_ALIGN_INIT, &ep);
   }
-  for (int level = c->a_gmax; level >= c->a_gmin && level >= 0; --level) {
-    const int cap = std::max(c->a_cap[level], 4);
-    int threads; bool lds_img; size_t lds;
-    pick_level_config(c, level, cap, &threads, &lds_img, &lds);
+  if (c->a_gmax >= c->a_gmin && c->a_gmax >= 0) {
+    int cap = 4;
+    for (int l = c->a_gmin; l <= c->a_gmax; ++l) cap = std::max(cap, c->a_cap[l]);
+    int threads, lds_img_cap; size_t lds;
+    pick_align_config(c, cap, &threads, &lds_img_cap, &lds);
     if (lds > c->lds_per_block) return fail(c, PLSVO_E_CAPACITY, "align_run: patch tables do not fit in LDS (too many features in one job)");
-    EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
-    HIP_TRY(c, launch_align_level(c->a_b, level, cap, threads, lds_img, lds, c->stream));
-    prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
+    bool per_level = false;
+    if (const char* s = getenv("PLSVO_ALIGN_PER_LEVEL")) per_level = atoi(s) != 0;
+    if (!per_level) {
+      EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
+      HIP_TRY(c, launch_align_levels(c->a_b, cap, lds_img_cap, c->a_gmax, c->a_gmin, threads, lds, c->stream));
+      prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
+    } else {
+      for (int level = c->a_gmax; level >= c->a_gmin; --level) {
+        EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
+        HIP_TRY(c, launch_align_levels(c->a_b, cap, lds_img_cap, level, level, threads, lds, c->stream));
+        prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
+      }
+    }
   }
   HIP_TRY(c, launch_align_finish(c->a_b, c->a_d_poses.as<double>(), c->stream));
   return PLSVO_OK;
@@ -520,6 +527,17 @@ extern "C" int plsvo_align_fetch_trace(plsvo_ctx* c, int job, plsvo_align_iterlo
 }
 
 extern "C" const double* plsvo_align_poses_dev(plsvo_ctx* c) { return (c && c->a_staged) ? c->a_d_poses.as<double>() : nullptr; }
+
+// debug: per-phase s_memtime ticks summed over the batch (all zero unless built with -DPLSVO_TIMING); not in the public header
+extern "C" int plsvo_align_phase_ticks(plsvo_ctx* c, unsigned long long* out8) {
+  CTX_CHECK(c);
+  if (!c->a_staged || !out8) return fail(c, PLSVO_E_STATE, "phase_ticks: no staged batch");
+  std::vector<AlignStateDev> st((size_t)c->a_n);
+  HIP_TRY(c, hipMemcpyAsync(st.data(), c->a_d_state.p, (size_t)c->a_n * sizeof(AlignStateDev), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 8; ++k) { out8[k] = 0; for (auto& s : st) out8[k] += s.phase_ticks[k]; }
+  return PLSVO_OK;
+}
 
 extern "C" int plsvo_align_copy_poses(plsvo_ctx* c, double* d_dst) {
   CTX_CHECK(c);

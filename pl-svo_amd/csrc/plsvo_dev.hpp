@@ -16,6 +16,17 @@
 
 namespace plsvo_hip {
 
+// byte offset of level `level` inside a pyramid slot: every level is followed by >= 64 bytes of slack and
+// starts on a 256-byte boundary (one formula for host and device)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline unsigned int pyr_level_offset(int width, int height, int level) {
+  unsigned long long off = 0;
+  for (int l = 0; l < level; ++l) off += (((unsigned long long)(width >> l) * (unsigned long long)(height >> l) + 64) + 255) & ~255ull;
+  return (unsigned int)off;
+}
+
 struct PyrDesc {
   const uint8_t* base;
   unsigned long long slot_bytes;
@@ -45,6 +56,7 @@ struct AlignStateDev {
   unsigned long long patch_levels, patch_iters;  // work counters
   int error;                   // device-side capacity/consistency error
   int reserved0;
+  unsigned long long phase_ticks[8];  // only filled by -DPLSVO_TIMING builds (s_memtime ticks per phase)
 };
 
 struct AlignBatchDev {

@@ -71,12 +71,30 @@ __device__ __forceinline__ int sym6_index(int r, int c) {
 // src/pose_optimizer.cpp:170 call H.ldlt().solve()).  Lane 8*i+j holds entry (i,j); column 6 is the rhs.
 // The pivots are exactly LDLT's D entries; like Eigen's solve, a pivot that is zero (or below 1/DBL_MAX)
 // yields a zero component, so an all-zero system returns x = 0.  NaN/Inf propagate into x.
+__device__ __forceinline__ void wave_solve6_core(double m, double* x);
+
 __device__ __forceinline__ void wave_solve6(const double* tot, double* x) {
   const int lane = threadIdx.x & 63;
   const int i = lane >> 3, j = lane & 7;
   double m = 0.0;
   if (i < 6 && j < 6) m = tot[sym6_index(i, j)];
   else if (i < 6 && j == 6) m = tot[21 + i];
+  wave_solve6_core(m, x);
+}
+
+// the same, with the 27 inputs held in registers: lane k (k < 27) passes tot[k] in `tot_lane`
+__device__ __forceinline__ void wave_solve6_reg(double tot_lane, double* x) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane >> 3, j = lane & 7;
+  const int src = (i < 6 && j < 6) ? sym6_index(i, j) : ((i < 6 && j == 6) ? 21 + i : 0);
+  double m = __shfl(tot_lane, src, 64);
+  if (!(i < 6 && j <= 6)) m = 0.0;
+  wave_solve6_core(m, x);
+}
+
+__device__ __forceinline__ void wave_solve6_core(double m, double* x) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane >> 3, j = lane & 7;
   unsigned done = 0u, zero_piv = 0u;
 #pragma unroll 1
   for (int step = 0; step < 6; ++step) {

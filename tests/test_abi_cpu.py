@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(P):
 
 def test_shared_object_contains_gfx950_code(P):
     blob = open(P.capi.LIB_PATH, "rb").read()
-    assert b"gfx950" in blob and b"align_level_kernel" in blob and b"pose_opt_kernel" in blob
+    assert b"gfx950" in blob and b"align_fused_kernel" in blob and b"pose_opt_kernel" in blob
 
 
 def test_ctypes_structs_match_the_c_header(P, tmp_path):
