@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PLSVO_BENCH_BATCH", "2048")), help="streams per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PLSVO_BENCH_BATCH", "4096")), help="streams per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -133,7 +133,7 @@ def main():
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get("align_level_kernel_bytes_per_launch")
+            traffic = json.load(open(tfile)).get("align_fused_kernel_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -155,7 +155,7 @@ def main():
                        "parallelism": f"streams sharded x{world}, RCCL all-gather of poses" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "align_level_kernel", "avg_launch_ms": round(avg_launch_ms, 4),
+                         "kernel": "align_fused_kernel", "avg_launch_ms": round(avg_launch_ms, 4),
                          "launches": int(lvl_launches), "algorithmic_bytes_per_launch": int(alg_bytes_per_step // launches_per_step),
                          "patch_levels_per_step": int(patch_levels), "patch_iters_per_step": int(patch_iters)},
             "kernel_ms_per_step": {"align_level": round(lvl_ms / args.steps, 4), "pose_opt": round(pose_ms / args.steps, 4)},

@@ -157,67 +157,6 @@ __global__ void align_init_kernel(AlignBatchDev b) {
 
 #define RED_N 32  // doubles per wave in the block reduction (21 H + 6 Jres + chi2 + 2 counters + pad)
 
-// sin and cos of a small angle (|x| <= pi/4: Taylor/Horner to x^17 / x^16, < 1 ulp); larger angles use ocml.
-// Gauss-Newton updates are tiny rotations, so the fast path is the one that runs.
-__device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
-  if (fabs(x) <= 0.7853981633974483) {
-    const double z = x * x;
-    double ps = -1.0 / 355687428096000.0;                      // -1/17!
-    ps = ps * z + 1.0 / 1307674368000.0;                       //  1/15!
-    ps = ps * z - 1.0 / 6227020800.0;                          // -1/13!
-    ps = ps * z + 1.0 / 39916800.0;                            //  1/11!
-    ps = ps * z - 1.0 / 362880.0;                              // -1/9!
-    ps = ps * z + 1.0 / 5040.0;                                //  1/7!
-    ps = ps * z - 1.0 / 120.0;                                 // -1/5!
-    ps = ps * z + 1.0 / 6.0;                                   //  1/3!  (sign folded below)
-    *s = x - x * z * ps;
-    double pc = 1.0 / 20922789888000.0;                        //  1/16!
-    pc = pc * z - 1.0 / 87178291200.0;                         // -1/14!
-    pc = pc * z + 1.0 / 479001600.0;                           //  1/12!
-    pc = pc * z - 1.0 / 3628800.0;                             // -1/10!
-    pc = pc * z + 1.0 / 40320.0;                               //  1/8!
-    pc = pc * z - 1.0 / 720.0;                                 // -1/6!
-    pc = pc * z + 1.0 / 24.0;                                  //  1/4!
-    *c = 1.0 - 0.5 * z + z * z * pc;
-  } else {
-    *s = sin(x); *c = cos(x);
-  }
-}
-
-// Sophus::SE3::exp with the small-angle sincos above (same formulas as plsvo_math.hpp::se3_exp)
-__device__ __forceinline__ SE3d se3_exp_dev(const double* u) {
-  SE3d r;
-  const double ox = u[3], oy = u[4], oz = u[5];
-  const double theta = sqrt(ox * ox + oy * oy + oz * oz);
-  double sh, ch, st, ct;
-  sincos_small(0.5 * theta, &sh, &ch);
-  sincos_small(theta, &st, &ct);
-  double imag_factor;
-  if (theta < 1e-10) {
-    const double theta_sq = theta * theta;
-    imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * (theta_sq * theta_sq);
-  } else {
-    imag_factor = sh / theta;
-  }
-  Quat q = { imag_factor * ox, imag_factor * oy, imag_factor * oz, ch };
-  r.q = quat_normalized(q);
-  double V[9];
-  if (theta < 1e-10) {
-    quat_to_matrix(r.q, V);
-  } else {
-    const double theta_sq = theta * theta;
-    const double a = (1 - ct) / theta_sq;
-    const double b = (theta - st) / (theta_sq * theta);
-    const double O2_00 = -(oy * oy + oz * oz), O2_11 = -(ox * ox + oz * oz), O2_22 = -(ox * ox + oy * oy);
-    const double O2_01 = ox * oy, O2_02 = ox * oz, O2_12 = oy * oz;
-    V[0] = 1.0 + b * O2_00;      V[1] = a * -oz + b * O2_01;  V[2] = a * oy + b * O2_02;
-    V[3] = a * oz + b * O2_01;   V[4] = 1.0 + b * O2_11;      V[5] = a * -ox + b * O2_12;
-    V[6] = a * -oy + b * O2_02;  V[7] = a * ox + b * O2_12;   V[8] = 1.0 + b * O2_22;
-  }
-  for (int i = 0; i < 3; ++i) r.t[i] = V[i * 3 + 0] * u[0] + V[i * 3 + 1] * u[1] + V[i * 3 + 2] * u[2];
-  return r;
-}
-
 // what phase 1 requests one patch round ahead
 struct P1Fetch {
   float2 uv;

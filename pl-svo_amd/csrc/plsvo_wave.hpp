@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "plsvo_math.hpp"
+
 namespace plsvo_hip {
 
 template <int CTRL>
@@ -49,6 +51,26 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
   v += dpp_bcast_f64<DPP_ROW_BCAST15, 0xA>(v);
   v += dpp_bcast_f64<DPP_ROW_BCAST31, 0xC>(v);
   return v;
+}
+
+// wave-sum of N values at once (N multiple of 6): six independent DPP chains at a time; totals valid in lane 63
+template <int N>
+__device__ __forceinline__ void wave_sum_array(double* v) {
+#pragma unroll
+  for (int c0 = 0; c0 < N; c0 += 6) {
+#pragma unroll
+    for (int k = c0; k < c0 + 6; ++k) v[k] += dpp_mov_f64<DPP_QUAD_XOR1>(v[k]);
+#pragma unroll
+    for (int k = c0; k < c0 + 6; ++k) v[k] += dpp_mov_f64<DPP_QUAD_XOR2>(v[k]);
+#pragma unroll
+    for (int k = c0; k < c0 + 6; ++k) v[k] += dpp_mov_f64<DPP_ROW_HALF_MIRROR>(v[k]);
+#pragma unroll
+    for (int k = c0; k < c0 + 6; ++k) v[k] += dpp_mov_f64<DPP_ROW_MIRROR>(v[k]);
+#pragma unroll
+    for (int k = c0; k < c0 + 6; ++k) v[k] += dpp_bcast_f64<DPP_ROW_BCAST15, 0xA>(v[k]);
+#pragma unroll
+    for (int k = c0; k < c0 + 6; ++k) v[k] += dpp_bcast_f64<DPP_ROW_BCAST31, 0xC>(v[k]);
+  }
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int src_lane /*wave-uniform*/) {
@@ -121,5 +143,67 @@ __device__ __forceinline__ void wave_solve6_core(double m, double* x) {
 #pragma unroll
   for (int r = 0; r < 6; ++r) x[r] = readlane_f64(xi, 8 * r);
 }
+
+// sin and cos of a small angle (|x| <= pi/4: Taylor/Horner to x^17 / x^16, < 1 ulp); larger angles use ocml.
+// Gauss-Newton updates are tiny rotations, so the fast path is the one that runs.
+__device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
+  if (fabs(x) <= 0.7853981633974483) {
+    const double z = x * x;
+    double ps = -1.0 / 355687428096000.0;                      // -1/17!
+    ps = ps * z + 1.0 / 1307674368000.0;                       //  1/15!
+    ps = ps * z - 1.0 / 6227020800.0;                          // -1/13!
+    ps = ps * z + 1.0 / 39916800.0;                            //  1/11!
+    ps = ps * z - 1.0 / 362880.0;                              // -1/9!
+    ps = ps * z + 1.0 / 5040.0;                                //  1/7!
+    ps = ps * z - 1.0 / 120.0;                                 // -1/5!
+    ps = ps * z + 1.0 / 6.0;                                   //  1/3!  (sign folded below)
+    *s = x - x * z * ps;
+    double pc = 1.0 / 20922789888000.0;                        //  1/16!
+    pc = pc * z - 1.0 / 87178291200.0;                         // -1/14!
+    pc = pc * z + 1.0 / 479001600.0;                           //  1/12!
+    pc = pc * z - 1.0 / 3628800.0;                             // -1/10!
+    pc = pc * z + 1.0 / 40320.0;                               //  1/8!
+    pc = pc * z - 1.0 / 720.0;                                 // -1/6!
+    pc = pc * z + 1.0 / 24.0;                                  //  1/4!
+    *c = 1.0 - 0.5 * z + z * z * pc;
+  } else {
+    *s = sin(x); *c = cos(x);
+  }
+}
+
+// Sophus::SE3::exp with the small-angle sincos above (same formulas as plsvo_math.hpp::se3_exp)
+__device__ __forceinline__ SE3d se3_exp_dev(const double* u) {
+  SE3d r;
+  const double ox = u[3], oy = u[4], oz = u[5];
+  const double theta = sqrt(ox * ox + oy * oy + oz * oz);
+  double sh, ch, st, ct;
+  sincos_small(0.5 * theta, &sh, &ch);
+  sincos_small(theta, &st, &ct);
+  double imag_factor;
+  if (theta < 1e-10) {
+    const double theta_sq = theta * theta;
+    imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * (theta_sq * theta_sq);
+  } else {
+    imag_factor = sh / theta;
+  }
+  Quat q = { imag_factor * ox, imag_factor * oy, imag_factor * oz, ch };
+  r.q = quat_normalized(q);
+  double V[9];
+  if (theta < 1e-10) {
+    quat_to_matrix(r.q, V);
+  } else {
+    const double theta_sq = theta * theta;
+    const double a = (1 - ct) / theta_sq;
+    const double b = (theta - st) / (theta_sq * theta);
+    const double O2_00 = -(oy * oy + oz * oz), O2_11 = -(ox * ox + oz * oz), O2_22 = -(ox * ox + oy * oy);
+    const double O2_01 = ox * oy, O2_02 = ox * oz, O2_12 = oy * oz;
+    V[0] = 1.0 + b * O2_00;      V[1] = a * -oz + b * O2_01;  V[2] = a * oy + b * O2_02;
+    V[3] = a * oz + b * O2_01;   V[4] = 1.0 + b * O2_11;      V[5] = a * -ox + b * O2_12;
+    V[6] = a * -oy + b * O2_02;  V[7] = a * ox + b * O2_12;   V[8] = 1.0 + b * O2_22;
+  }
+  for (int i = 0; i < 3; ++i) r.t[i] = V[i * 3 + 0] * u[0] + V[i * 3 + 1] * u[1] + V[i * 3 + 2] * u[2];
+  return r;
+}
+
 
 }  // namespace plsvo_hip

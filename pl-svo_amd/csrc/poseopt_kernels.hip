@@ -69,6 +69,24 @@ __device__ U block_radix_select(GET get, int n, int k, int* s_hist, int* s_sel) 
   return prefix;
 }
 
+// k-th smallest (0-based) of n <= PO_RANK_MAX values by rank counting: element i's rank is the number of elements
+// that sort before it (ties broken by index); exact, one barrier, O(n^2 / T) LDS broadcasts.  `vals` is an LDS
+// array of bit patterns (non-negative IEEE values order like unsigned integers).
+#define PO_RANK_MAX 0   // rank counting measured slower than the 11-bit radix select on MI355X (64-bit compares); kept for reference
+template <typename U>
+__device__ U block_rank_select(const U* vals, int n, int k, U* s_out) {
+  for (int i = threadIdx.x; i < n; i += PO_T) {
+    const U vi = vals[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) { const U vj = vals[j]; rank += (vj < vi || (vj == vi && j < i)) ? 1 : 0; }
+    if (rank == k) *s_out = vi;
+  }
+  __syncthreads();
+  const U r = *s_out;
+  __syncthreads();
+  return r;
+}
+
 // LDS roles: s_red PO_RED*(PO_T/64) doubles; s_pose 0..8 R, 9..11 t, 12..18 model, 19..25 T_old, 26 chi2;
 // s_ctl[0] break flag
 
@@ -141,31 +159,35 @@ __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseS
       aChi += (e0 * e0 + e1 * e1) * weight;
     }
     {
-      double* dst = s_red + PO_RED * wave;
+      double acc[30];
 #pragma unroll
-      for (int k = 0; k < 21; ++k) { const double v = wave_sum_to_lane63(aH[k]); if (lane == 63) dst[k] = v; }
+      for (int k = 0; k < 21; ++k) acc[k] = aH[k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { const double v = wave_sum_to_lane63(aB[k]); if (lane == 63) dst[21 + k] = v; }
-      { const double v = wave_sum_to_lane63(aChi); if (lane == 63) dst[27] = v; }
-      { const double v = wave_sum_to_lane63((double)cpt); if (lane == 63) dst[28] = v; }
-      { const double v = wave_sum_to_lane63((double)cls); if (lane == 63) dst[29] = v; }
+      for (int k = 0; k < 6; ++k) acc[21 + k] = aB[k];
+      acc[27] = aChi; acc[28] = (double)cpt; acc[29] = (double)cls;
+      wave_sum_array<30>(acc);
+      if (lane == 63) {
+        double* dst = s_red + PO_RED * wave;
+#pragma unroll
+        for (int k = 0; k < 30; ++k) dst[k] = acc[k];
+      }
     }
     __syncthreads();
-    if (tid < 30) { double v = 0.0; for (int w = 0; w < PO_T / 64; ++w) v += s_red[PO_RED * w + tid]; s_tot[tid] = v; }
-    __syncthreads();
     if (wave == 0) {
+      double tot = 0.0;
+      if (lane < 30) { for (int w = 0; w < PO_T / 64; ++w) tot += s_red[PO_RED * w + lane]; s_tot[lane] = tot; }
       double dT[6];
-      wave_solve6(s_tot, dT);                                                // A.ldlt().solve(b) :170
+      wave_solve6_reg(tot, dT);                                              // A.ldlt().solve(b) :170
+      const double new_chi2 = readlane_f64(tot, 27), npt = readlane_f64(tot, 28), nls = readlane_f64(tot, 29);
       if (lane == 0) {
-        s_pose[27] += s_tot[28]; s_pose[28] += s_tot[29];
+        s_pose[27] += npt; s_pose[28] += nls;
         s_ctl[1 + phase] += 1;
-        const double new_chi2 = s_tot[27];
         SE3d model = se3_load(s_pose + 12);
         int accepted = 1, brk = 0;
         if ((iter > 0 && new_chi2 > s_pose[26]) || isnan(dT[0])) {          // :173-180
           model = se3_load(s_pose + 19); accepted = 0; brk = 1;
         } else {
-          const SE3d Tn = se3_mul(se3_exp(dT), model);                       // :183 left update
+          const SE3d Tn = se3_mul(se3_exp_dev(dT), model);                   // :183 left update
           se3_store(model, s_pose + 19);
           model = Tn; s_pose[26] = new_chi2;
           if (norm_max6(dT) <= 0.0000000001) brk = 1;                        // EPS, global.h:99
@@ -178,8 +200,7 @@ __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseS
           if (lc < b.log_cap) {
             plsvo_poseopt_iterlog* r = b.log + (size_t)job_id * b.log_cap + lc;
             r->phase = phase; r->iter = iter; r->accepted = accepted; r->reserved0 = 0; r->new_chi2 = new_chi2;
-            for (int i = 0; i < 6; ++i) for (int jj = 0; jj < 6; ++jj) r->A[i * 6 + jj] = s_tot[sym6_index(i, jj)];
-            for (int k = 0; k < 6; ++k) { r->b[k] = s_tot[21 + k]; r->dT[k] = dT[k]; }
+            for (int k = 0; k < 6; ++k) r->dT[k] = dT[k];
             se3_store(model, r->T_after);
           }
           st->log_count = lc + 1;
@@ -187,6 +208,14 @@ __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseS
       }
     }
     __syncthreads();
+    if (b.log && tid == 0) {   // A and b of the trace come from s_tot (written by lanes 0..26 of wave 0 above)
+      const int lc = st->log_count - 1;
+      if (lc >= 0 && lc < b.log_cap) {
+        plsvo_poseopt_iterlog* r = b.log + (size_t)job_id * b.log_cap + lc;
+        for (int i = 0; i < 6; ++i) for (int jj = 0; jj < 6; ++jj) r->A[i * 6 + jj] = s_tot[sym6_index(i, jj)];
+        for (int k = 0; k < 6; ++k) r->b[k] = s_tot[21 + k];
+      }
+    }
     if (s_ctl[0]) break;
   }
 }
@@ -202,8 +231,9 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b) {
   __shared__ double s_pose[32];   // 27: point-iterations, 28: line-iterations
   __shared__ double s_tot[32];
   __shared__ int s_ctl[32];
-  __shared__ int s_hist[PO_BINS];
+  __shared__ int s_hist[PO_BINS];                           // 8 KB: radix histogram, or staging for the rank select
   __shared__ int s_sel[16];
+  __shared__ unsigned long long s_rank_out;
 
   // scratch: floats [0,np) point errors, [np, np+ns) line errors; doubles [0,nf) init (first loop),
   // [nf,2nf) init (refinement), [2nf,3nf) final
@@ -257,14 +287,20 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b) {
   __syncthreads();
   // MAD scale = 1.48f * median (float).  Zero points: the reference is undefined (:70); we define 1.0.
   double scale_pt = 1.0, scale_ls = 1.0;
-  if (np > 0) {
-    const uint32_t bits = block_radix_select<32, uint32_t>([&](int i) { return (uint32_t)__float_as_uint(errs[i]); }, np, np / 2, s_hist, s_sel);
-    scale_pt = (double)__fmul_rn(1.48f, __uint_as_float(bits));
-  }
-  if (ns > 0) {
-    const uint32_t bits = block_radix_select<32, uint32_t>([&](int i) { return (uint32_t)__float_as_uint(errs[np + i]); }, ns, ns / 2, s_hist, s_sel);
-    scale_ls = (double)__fmul_rn(1.48f, __uint_as_float(bits));
-  }
+  unsigned long long* s_vals = reinterpret_cast<unsigned long long*>(s_hist);   // PO_RANK_MAX 64-bit patterns fit in 8 KB
+  auto median_f32 = [&](const float* v, int n) -> float {
+    uint32_t bits;
+    if (n <= PO_RANK_MAX) {
+      for (int i = tid; i < n; i += PO_T) s_vals[i] = (unsigned long long)__float_as_uint(v[i]);
+      __syncthreads();
+      bits = (uint32_t)block_rank_select<unsigned long long>(s_vals, n, n / 2, &s_rank_out);
+    } else {
+      bits = block_radix_select<32, uint32_t>([&](int i) { return (uint32_t)__float_as_uint(v[i]); }, n, n / 2, s_hist, s_sel);
+    }
+    return __uint_as_float(bits);
+  };
+  if (np > 0) scale_pt = (double)__fmul_rn(1.48f, median_f32(errs, np));
+  if (ns > 0) scale_ls = (double)__fmul_rn(1.48f, median_f32(errs + np, ns));
 
   // ---- first GN loop ----
   if (job.n_iter <= 0) for (int f = tid; f < nf; f += PO_T) vec[f] = __longlong_as_double(0x7ff0000000000000LL);
@@ -333,12 +369,17 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b) {
   __syncthreads();
 
   // ---- medians :244-249 ----
+  auto kth_f64 = [&](const double* v, int n, int k) -> unsigned long long {
+    if (n <= PO_RANK_MAX) {
+      for (int i = tid; i < n; i += PO_T) s_vals[i] = (unsigned long long)__double_as_longlong(v[i]);
+      __syncthreads();
+      return block_rank_select<unsigned long long>(s_vals, n, k, &s_rank_out);
+    }
+    return block_radix_select<64, unsigned long long>([&](int i) { return (unsigned long long)__double_as_longlong(v[i]); }, n, k, s_hist, s_sel);
+  };
   unsigned long long mi = 0;
-  if (n_init > 0)
-    mi = block_radix_select<64, unsigned long long>(
-        [&](int i) { return (unsigned long long)__double_as_longlong(vec[i]); }, 2 * nf, n_init / 2, s_hist, s_sel);
-  const unsigned long long mf = block_radix_select<64, unsigned long long>(
-      [&](int i) { return (unsigned long long)__double_as_longlong(vec[2 * nf + i]); }, nf, nf / 2, s_hist, s_sel);
+  if (n_init > 0) mi = kth_f64(vec, (job.n_iter_ref > 0) ? 2 * nf : nf, n_init / 2);   // unwritten refinement entries hold +inf and sort last
+  const unsigned long long mf = kth_f64(vec + 2 * nf, nf, nf / 2);
   if (tid == 0) {
     for (int k = 0; k < 7; ++k) st->T[k] = s_pose[12 + k];
     st->error_init = sqrt(__longlong_as_double((long long)mi)) * job.fx;

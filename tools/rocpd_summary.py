@@ -14,14 +14,31 @@ def main(db, out, cmd):
          "where name like '%plsvo%' group by name order by sum(duration) desc")
     for r in c.execute(q):
         lines.append(f"\"{r[0]}\",{r[1]},{r[2] / 1e3:.1f},{r[3] / 1e3:.1f},{r[4] / 1e3:.1f},{r[5] / 1e3:.1f}")
-    lines += ["", "## every align_level_kernel / pose_opt_kernel dispatch, in launch order",
+    lines += ["", "## every align_fused_kernel / pose_opt_kernel dispatch, in launch order",
               "name,grid_x,workgroup_x,lds_bytes,arch_vgpr,accum_vgpr,sgpr,scratch,duration_us"]
     q = ("select name, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size, duration "
-         "from kernels where name like '%align_level%' or name like '%pose_opt%' order by start")
+         "from kernels where name like '%align_fused%' or name like '%align_level%' or name like '%pose_opt%' order by start")
     for r in c.execute(q):
         lines.append(f"\"{r[0]}\",{r[1]},{r[2]},{r[3]},{r[4]},{r[5]},{r[6]},{r[7]},{r[8] / 1e3:.1f}")
     open(out, "w").write("\n".join(lines) + "\n")
 
 
+
+
+def counters(db, out, cmd):
+    """per-kernel PMC counter totals (rocprofv3 --pmc ... pass) for the plsvo kernels"""
+    c = sqlite3.connect(db)
+    lines = [f"# rocprofv3 --kernel-trace --pmc <counter> -- {cmd}", "# view counters_collection; one row per dispatch",
+             "kernel,counter,dispatch_index,grid,workgroup,value"]
+    q = ("select kernel_name, counter_name, dispatch_id, grid_size, workgroup_size, value from counters_collection "
+         "where kernel_name like '%plsvo%align_fused%' or kernel_name like '%plsvo%pose_opt%' order by dispatch_id")
+    for r in c.execute(q):
+        lines.append(f"\"{r[0]}\",{r[1]},{r[2]},{r[3]},{r[4]},{r[5]}")
+    open(out, "w").write("\n".join(lines) + "\n")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")
+    if sys.argv[1] == "--counters":
+        counters(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
+    else:
+        main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")
