@@ -121,7 +121,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel (align_level_kernel), from live hipEvent timings ----
+    # ---- roofline of the dominant kernel (align_fused_kernel), from live hipEvent timings ----
     lvl_ms, lvl_launches = ctx.kernel_time(abi.K_ALIGN_LEVEL)
     pose_ms, pose_launches = ctx.kernel_time(abi.K_POSEOPT)
     patch_levels, patch_iters = ctx.align_work()       # counted on the device, per run of the staged batch
@@ -133,7 +133,9 @@ def main():
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get("align_fused_kernel_bytes_per_launch")
+            # measured offline with rocprofv3 PMC passes on this same command (see profiles/hbm_traffic.json);
+            # stored per stream so that it follows --batch
+            traffic = round(json.load(open(tfile)).get("align_fused_kernel_bytes_per_stream") * B)
         except Exception:
             traffic = None
 
