@@ -172,7 +172,9 @@ struct P1Fetch {
 #ifndef PLSVO_MIN_WAVES
 #define PLSVO_MIN_WAVES 2   // measured: capping VGPRs at 128 (4 waves/SIMD) spills and loses to 2 unspilled waves/SIMD
 #endif
-template <int T>
+// LDS_PX: keep the per-iteration patch sums (6 doubles per patch) and the patches' 3-D points in LDS instead of
+// round-tripping them through L2/HBM every iteration (measured with FETCH_SIZE/WRITE_SIZE: ~36 % of the traffic)
+template <int T, bool LDS_PX>
 __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBatchDev b, int cap, int lds_img_cap, int level_hi, int level_lo) {
   const int job_id = blockIdx.x;
   const AlignJobDev job = b.jobs[job_id];
@@ -188,7 +190,9 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   double* s_red = reinterpret_cast<double*>(smem);                       // RED_N * (T/64)
   double* s_pose = s_red + RED_N * (T / 64);                             // 0..8 R, 9..11 t, 12..18 model, 19..25 old model, 26 chi2_, 27 #evals
   double* s_tot = s_pose + 32;                                           // block totals of the last iteration: 21 H, 6 Jres, chi2, n_meas, evals
-  int* s_ctl = reinterpret_cast<int*>(s_tot + 32);                       // 0 break, 1 stop, 2 iterations done, 3 error, 4.. scan tmp
+  double* s_part = s_tot + 32;                                           // 6 * cap  (LDS_PX only)
+  double* s_xyz = s_part + (LDS_PX ? 6 * cap : 0);                       // 3 * cap  (LDS_PX only)
+  int* s_ctl = reinterpret_cast<int*>(s_xyz + (LDS_PX ? 3 * cap : 0));   // 0 break, 1 stop, 2 iterations done, 3 error, 4.. scan tmp
   float2* s_uv = reinterpret_cast<float2*>(s_ctl + 32);                  // cap
   int2* s_meta = reinterpret_cast<int2*>(s_uv + cap);                    // cap
   float* s_abs = reinterpret_cast<float*>(s_meta + cap);                 // cap
@@ -208,6 +212,8 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   }
   const size_t pbase = (size_t)job.patch_off;
   const int nfeat = job.n_pts + job.n_seg;
+  double* const part = LDS_PX ? s_part : (b.partial + 6 * pbase);        // per-iteration patch sums
+  double* const pxyz = LDS_PX ? s_xyz : (b.patch_xyz + 3 * pbase);       // 3-D point of every patch (ref frame)
 
   for (int level = lv_first; level >= lv_last; --level) {
     // (level geometry is recomputed instead of indexing the kernel-argument arrays with a run-time level,
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     }
     __syncthreads();
     const int n_patch = block_exclusive_scan<T>(s_cnt, nfeat, s_ctl + 4);
-    constexpr int FR = (T >= 256) ? 4 : 1024 / T;   // features per thread kept in registers across the emit
+    constexpr int FR = 4;   // features per thread kept in registers across the emit
     const int feat_rounds = (nfeat + T - 1) / T;
     if (n_patch > cap || n_patch > job.patch_cap || feat_rounds > FR) {  // host capacity bound violated: flag and bail out (uniform)
       if (tid == 0) st->error = (feat_rounds > FR) ? 2 : 1;
@@ -280,9 +286,9 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         s_dead[p0] = 0;
         b.patch_uvref[2 * (pbase + p0)] = (float)(b.pt_px[2 * i] * scale);
         b.patch_uvref[2 * (pbase + p0) + 1] = (float)(b.pt_px[2 * i + 1] * scale);
-        b.patch_xyz[3 * (pbase + p0)] = b.pt_xyz[3 * i];
-        b.patch_xyz[3 * (pbase + p0) + 1] = b.pt_xyz[3 * i + 1];
-        b.patch_xyz[3 * (pbase + p0) + 2] = b.pt_xyz[3 * i + 2];
+        pxyz[3 * p0] = b.pt_xyz[3 * i];
+        pxyz[3 * p0 + 1] = b.pt_xyz[3 * i + 1];
+        pxyz[3 * p0 + 2] = b.pt_xyz[3 * i + 2];
       } else {
         const int sl = f - job.n_pts, s = job.seg_off + sl;
         const int N = my_cnt[k];
@@ -303,9 +309,9 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           s_dead[p] = 0;
           b.patch_uvref[2 * (pbase + p)] = (float)px;
           b.patch_uvref[2 * (pbase + p) + 1] = (float)py;
-          b.patch_xyz[3 * (pbase + p)] = xr[0];
-          b.patch_xyz[3 * (pbase + p) + 1] = xr[1];
-          b.patch_xyz[3 * (pbase + p) + 2] = xr[2];
+          pxyz[3 * p] = xr[0];
+          pxyz[3 * p + 1] = xr[1];
+          pxyz[3 * p + 2] = xr[2];
           px += inc2x; py += inc2y;
           xr[0] += inc3[0]; xr[1] += inc3[1]; xr[2] += inc3[2];
         }
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           if (meta.x < 0 && s_dead[first]) {
             uv = make_float2(-2.0f, -2.0f);  // line already culled
           } else {
-            const double x = b.patch_xyz[3 * (pbase + p)], y = b.patch_xyz[3 * (pbase + p) + 1], z = b.patch_xyz[3 * (pbase + p) + 2];
+            const double x = pxyz[3 * p], y = pxyz[3 * p + 1], z = pxyz[3 * p + 2];
             const double xc = R0 * x + R1 * y + R2 * z + t0;
             const double yc = R3 * x + R4 * y + R5 * z + t1;
             const double zc = R6 * x + R7 * y + R8 * z + t2;
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         sA = quad_sum(sA); sB = quad_sum(sB); sC = quad_sum(sC); sD = quad_sum(sD); sE = quad_sum(sE);
         sChi = quad_sum(sChi); sAbs = quad_sum(sAbs);
         if (p < n_patch && row == 0) {
-          double* dst = b.partial + 6 * (pbase + p);
+          double* dst = part + 6 * p;
           dst[0] = sA; dst[1] = sB; dst[2] = sC; dst[3] = sD; dst[4] = sE; dst[5] = sChi;
           s_abs[p] = live ? sAbs : -1.0f;
           evals += live ? 1 : 0;
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         const int2 meta = s_meta[p];
         const float2 uv = s_uv[p];
         double wh = 0.0, wj = 0.0;
-        const double* src = b.partial + 6 * (pbase + p);
+        const double* src = part + 6 * p;
         if (meta.x >= 0) {
           if (uv.x >= 0.0f) { wh = 1.0; wj = 1.0; n_meas += PLSVO_PATCH_AREA; acc[27] += src[5]; }
         } else if (uv.x > -1.5f) {  // live line (not culled earlier); uv.x == -1 marks an out-of-frame sample
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           }
         }
         if (wh != 0.0 || wj != 0.0) {
-          double xyz[3] = { b.patch_xyz[3 * (pbase + p)], b.patch_xyz[3 * (pbase + p) + 1], b.patch_xyz[3 * (pbase + p) + 2] };
+          double xyz[3] = { pxyz[3 * p], pxyz[3 * p + 1], pxyz[3 * p + 2] };
           double J[12];
           jacobian_xyz2uv(xyz, J);
           const double hs = wh * fs * fs, js = wj * fs;
@@ -637,28 +643,30 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 }
 
 // LDS bytes the kernel needs for a given patch capacity and staged-image capacity (host side helper)
-size_t align_level_lds_bytes(int threads, int cap, int lds_img_cap) {
+size_t align_level_lds_bytes(int threads, int cap, int lds_img_cap, bool lds_px) {
   size_t o = sizeof(double) * RED_N * (threads / 64) + sizeof(double) * 64 + sizeof(int) * 32;
+  if (lds_px) o += (size_t)cap * 9 * sizeof(double);
   o += (size_t)cap * (sizeof(float2) + sizeof(int2) + sizeof(float) + sizeof(int));
   o += (size_t)lds_img_cap;
   return o;
 }
 
-template <int T>
+template <int T, bool PX>
 static hipError_t launch_fused_T(const AlignBatchDev& b, int cap, int lds_img_cap, int level_hi, int level_lo, size_t lds, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_fused_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_fused_kernel<T, PX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((align_fused_kernel<T>), dim3(b.n_jobs), dim3(T), lds, stream, b, cap, lds_img_cap, level_hi, level_lo);
+  hipLaunchKernelGGL((align_fused_kernel<T, PX>), dim3(b.n_jobs), dim3(T), lds, stream, b, cap, lds_img_cap, level_hi, level_lo);
   return hipGetLastError();
 }
 
-hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int lds_img_cap, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream) {
+hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int lds_img_cap, bool lds_px, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream) {
   switch (threads) {
-    case 64: return launch_fused_T<64>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
-    case 128: return launch_fused_T<128>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
-    case 256: return launch_fused_T<256>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
-    case 512: return launch_fused_T<512>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
-    case 1024: return launch_fused_T<1024>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
+    case 256: return lds_px ? launch_fused_T<256, true>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream)
+                            : launch_fused_T<256, false>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
+    case 512: return lds_px ? launch_fused_T<512, true>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream)
+                            : launch_fused_T<512, false>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
+    case 1024: return lds_px ? launch_fused_T<1024, true>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream)
+                             : launch_fused_T<1024, false>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
     default: return hipErrorInvalidValue;
   }
 }
