@@ -174,7 +174,7 @@ struct P1Fetch {
 #endif
 // LDS_PX: keep the per-iteration patch sums (6 doubles per patch) and the patches' 3-D points in LDS instead of
 // round-tripping them through L2/HBM every iteration (measured with FETCH_SIZE/WRITE_SIZE: ~36 % of the traffic)
-template <int T, bool LDS_PX>
+template <int T, int LDS_PX>   // LDS_PX bit 0: patch sums in LDS, bit 1: patch 3-D points in LDS
 __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBatchDev b, int cap, int lds_img_cap, int level_hi, int level_lo) {
   const int job_id = blockIdx.x;
   const AlignJobDev job = b.jobs[job_id];
@@ -190,14 +190,15 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   double* s_red = reinterpret_cast<double*>(smem);                       // RED_N * (T/64)
   double* s_pose = s_red + RED_N * (T / 64);                             // 0..8 R, 9..11 t, 12..18 model, 19..25 old model, 26 chi2_, 27 #evals
   double* s_tot = s_pose + 32;                                           // block totals of the last iteration: 21 H, 6 Jres, chi2, n_meas, evals
-  double* s_part = s_tot + 32;                                           // 6 * cap  (LDS_PX only)
-  double* s_xyz = s_part + (LDS_PX ? 6 * cap : 0);                       // 3 * cap  (LDS_PX only)
-  int* s_ctl = reinterpret_cast<int*>(s_xyz + (LDS_PX ? 3 * cap : 0));   // 0 break, 1 stop, 2 iterations done, 3 error, 4.. scan tmp
+  double* s_part = s_tot + 32;                                           // 6 * cap  (LDS_PX & 1)
+  double* s_xyz = s_part + ((LDS_PX & 1) ? 6 * cap : 0);                 // 3 * cap  (LDS_PX & 2)
+  int* s_ctl = reinterpret_cast<int*>(s_xyz + ((LDS_PX & 2) ? 3 * cap : 0));   // 0 break, 1 stop, 2 iterations done, 3 error, 4.. scan tmp
   float2* s_uv = reinterpret_cast<float2*>(s_ctl + 32);                  // cap
   int2* s_meta = reinterpret_cast<int2*>(s_uv + cap);                    // cap
   float* s_abs = reinterpret_cast<float*>(s_meta + cap);                 // cap
   int* s_dead = reinterpret_cast<int*>(s_abs + cap);                     // cap
-  uint8_t* s_img = reinterpret_cast<uint8_t*>(s_dead + cap);             // lds_img_cap (16-byte aligned: cap % 4 == 0)
+  int* s_cnt = s_dead + cap;                                             // cap + 4: per-feature patch count / offset (nfeat <= cap)
+  uint8_t* s_img = reinterpret_cast<uint8_t*>(s_cnt + cap + 4);          // lds_img_cap (16-byte aligned: cap % 4 == 0)
 
 #ifdef PLSVO_TIMING
   __shared__ unsigned long long s_time[8];
@@ -212,8 +213,8 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   }
   const size_t pbase = (size_t)job.patch_off;
   const int nfeat = job.n_pts + job.n_seg;
-  double* const part = LDS_PX ? s_part : (b.partial + 6 * pbase);        // per-iteration patch sums
-  double* const pxyz = LDS_PX ? s_xyz : (b.patch_xyz + 3 * pbase);       // 3-D point of every patch (ref frame)
+  double* const part = (LDS_PX & 1) ? s_part : (b.partial + 6 * pbase);  // per-iteration patch sums
+  double* const pxyz = (LDS_PX & 2) ? s_xyz : (b.patch_xyz + 3 * pbase); // 3-D point of every patch (ref frame)
 
   for (int level = lv_first; level >= lv_last; --level) {
     // (level geometry is recomputed instead of indexing the kernel-argument arrays with a run-time level,
@@ -238,7 +239,6 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 
     // ---- patch table: count, scan, emit ----
     const double scale = 1.0 / (double)(1 << level);  // the reference's float scale is a power of two: exact
-    int* s_cnt = reinterpret_cast<int*>(s_uv);  // aliased: nfeat <= cap
     for (int f = tid; f < nfeat; f += T) {
       int cnt = 0;
       if (f < job.n_pts) {
@@ -260,26 +260,14 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     }
     __syncthreads();
     const int n_patch = block_exclusive_scan<T>(s_cnt, nfeat, s_ctl + 4);
-    constexpr int FR = 4;   // features per thread kept in registers across the emit
-    const int feat_rounds = (nfeat + T - 1) / T;
-    if (n_patch > cap || n_patch > job.patch_cap || feat_rounds > FR) {  // host capacity bound violated: flag and bail out (uniform)
-      if (tid == 0) st->error = (feat_rounds > FR) ? 2 : 1;
+    if (n_patch > cap || n_patch > job.patch_cap) {  // host capacity bound violated: flag and bail out (uniform)
+      if (tid == 0) st->error = 1;
       return;
     }
-    // every feature thread reads its own offset before s_uv (aliased) is overwritten by anybody
-    int my_off[FR]; int my_cnt[FR];
-#pragma unroll
-    for (int k = 0; k < FR; ++k) {
-      const int f = tid + k * T;
-      my_off[k] = (k < feat_rounds && f < nfeat) ? s_cnt[f] : 0;
-      my_cnt[k] = (k < feat_rounds && f < nfeat) ? ((f + 1 < nfeat ? s_cnt[f + 1] : n_patch) - s_cnt[f]) : 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < FR; ++k) {
-      const int f = tid + k * T;
-      if (k >= feat_rounds || f >= nfeat || my_cnt[k] == 0) continue;
-      const int p0 = my_off[k];
+    for (int f = tid; f < nfeat; f += T) {
+      const int p0 = s_cnt[f];
+      const int my_cnt_f = (f + 1 < nfeat ? s_cnt[f + 1] : n_patch) - p0;
+      if (my_cnt_f == 0) continue;
       if (f < job.n_pts) {
         const int i = job.pt_off + f;
         s_meta[p0] = make_int2(f, p0 | (1 << 20));                 // x >= 0: point index; y: first | N<<20
@@ -291,7 +279,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         pxyz[3 * p0 + 2] = b.pt_xyz[3 * i + 2];
       } else {
         const int sl = f - job.n_pts, s = job.seg_off + sl;
-        const int N = my_cnt[k];
+        const int N = my_cnt_f;
         // :316-332: 2-D step on the level image, 3-D step between the end points, both accumulated
         const double sx = b.seg_spx[2 * s], sy = b.seg_spx[2 * s + 1];
         double inc2x = (b.seg_epx[2 * s] - sx) * scale / (double)(N - 1);
@@ -643,15 +631,16 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 }
 
 // LDS bytes the kernel needs for a given patch capacity and staged-image capacity (host side helper)
-size_t align_level_lds_bytes(int threads, int cap, int lds_img_cap, bool lds_px) {
+size_t align_level_lds_bytes(int threads, int cap, int lds_img_cap, int lds_px) {
   size_t o = sizeof(double) * RED_N * (threads / 64) + sizeof(double) * 64 + sizeof(int) * 32;
-  if (lds_px) o += (size_t)cap * 9 * sizeof(double);
-  o += (size_t)cap * (sizeof(float2) + sizeof(int2) + sizeof(float) + sizeof(int));
+  if (lds_px & 1) o += (size_t)cap * 6 * sizeof(double);
+  if (lds_px & 2) o += (size_t)cap * 3 * sizeof(double);
+  o += (size_t)cap * (sizeof(float2) + sizeof(int2) + sizeof(float) + sizeof(int) + sizeof(int)) + 16;
   o += (size_t)lds_img_cap;
   return o;
 }
 
-template <int T, bool PX>
+template <int T, int PX>
 static hipError_t launch_fused_T(const AlignBatchDev& b, int cap, int lds_img_cap, int level_hi, int level_lo, size_t lds, hipStream_t stream) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_fused_kernel<T, PX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -659,14 +648,23 @@ static hipError_t launch_fused_T(const AlignBatchDev& b, int cap, int lds_img_ca
   return hipGetLastError();
 }
 
-hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int lds_img_cap, bool lds_px, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream) {
+template <int T>
+static hipError_t launch_fused_px(const AlignBatchDev& b, int cap, int lds_img_cap, int lds_px, int level_hi, int level_lo, size_t lds, hipStream_t stream) {
+  switch (lds_px) {
+    case 0: return launch_fused_T<T, 0>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
+    case 1: return launch_fused_T<T, 1>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
+    case 3: return launch_fused_T<T, 3>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int lds_img_cap, int lds_px, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream) {
   switch (threads) {
-    case 256: return lds_px ? launch_fused_T<256, true>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream)
-                            : launch_fused_T<256, false>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
-    case 512: return lds_px ? launch_fused_T<512, true>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream)
-                            : launch_fused_T<512, false>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
-    case 1024: return lds_px ? launch_fused_T<1024, true>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream)
-                             : launch_fused_T<1024, false>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
+    case 64: return launch_fused_px<64>(b, cap, lds_img_cap, lds_px, level_hi, level_lo, lds, stream);
+    case 128: return launch_fused_px<128>(b, cap, lds_img_cap, lds_px, level_hi, level_lo, lds, stream);
+    case 256: return launch_fused_px<256>(b, cap, lds_img_cap, lds_px, level_hi, level_lo, lds, stream);
+    case 512: return launch_fused_px<512>(b, cap, lds_img_cap, lds_px, level_hi, level_lo, lds, stream);
+    case 1024: return launch_fused_px<1024>(b, cap, lds_img_cap, lds_px, level_hi, level_lo, lds, stream);
     default: return hipErrorInvalidValue;
   }
 }
