@@ -242,6 +242,51 @@ int plsvo_poseopt_copy_poses(plsvo_ctx* ctx, double* d_dst);
 int plsvo_poseopt_work(plsvo_ctx* ctx, uint64_t* pt_iters, uint64_t* seg_iters);
 
 /* ------------------------------------------------------------------------------------------ */
+/* structure optimisation (hot-path contract row (f) "next" #3)                                */
+/* replaces plsvo::Point::optimize / plsvo::LineSeg::optimize (src/feature3D_impl.cpp:36-96,   */
+/* :98-175), called from FrameHandlerBase::optimizeStructure (src/frame_handler_base.cpp:      */
+/* 202-237; call site src/frame_handler_mono.cpp:340)                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* A batch of independent 3-D landmarks, each refined by its own 3x3 Gauss-Newton over its observations
+ * (Feature3D::obs_, include/plsvo/feature3D.h): observation = (frame pose T_f_w, unit bearing f).
+ *   frame_T        7*n_frames   poses of every frame referenced by an observation
+ *   pt_pos         3*n_pts      Point::pos_ on entry
+ *   pt_obs_off     n_pts+1      observations of point i are [pt_obs_off[i], pt_obs_off[i+1])
+ *   pt_obs_frame   n_pt_obs     index into frame_T            (Feature::frame)
+ *   pt_obs_f       3*n_pt_obs   Feature::f
+ *   seg_*                       the same for LineSeg::spos_/epos_ with LineFeat::sf / ef
+ * The landmark selection (nth_element on last_structure_optim_) stays on the host. */
+typedef struct plsvo_structopt_in {
+  int32_t n_frames;
+  int32_t n_iter_pts;               /* Config::structureOptimNumIter() */
+  int32_t n_iter_segs;              /* Config::structureOptimNumIterSegs() */
+  int32_t n_pts, n_seg;
+  int32_t reserved0;
+  const double* frame_T;
+  const double* pt_pos;
+  const int32_t* pt_obs_off;
+  const int32_t* pt_obs_frame;
+  const double* pt_obs_f;
+  const double* seg_spos;
+  const double* seg_epos;
+  const int32_t* seg_obs_off;
+  const int32_t* seg_obs_frame;
+  const double* seg_obs_sf;
+  const double* seg_obs_ef;
+} plsvo_structopt_in;
+
+typedef struct plsvo_structopt_out {   /* caller buffers; any of them may be NULL */
+  double* pt_pos;                   /* 3*n_pts  Point::pos_ on exit */
+  double* seg_spos;                 /* 3*n_seg */
+  double* seg_epos;                 /* 3*n_seg */
+  int32_t* pt_iters;                /* n_pts: residual evaluations executed (1..n_iter) */
+  int32_t* seg_iters;               /* n_seg */
+} plsvo_structopt_out;
+
+int plsvo_structure_optimize(plsvo_ctx* ctx, const plsvo_structopt_in* in, plsvo_structopt_out* out);
+
+/* ------------------------------------------------------------------------------------------ */
 /* multi-GPU: gather of per-stream pose records (new; the reference is single-process)         */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -258,7 +303,8 @@ int plsvo_gather_poses(plsvo_ctx* ctx, void* rccl_comm, const double* d_local, i
 #define PLSVO_K_ALIGN_LEVEL   1   /* the residual/Jacobian + GN kernel (dominant) */
 #define PLSVO_K_POSEOPT       2
 #define PLSVO_K_HALFSAMPLE    3
-#define PLSVO_K_COUNT         4
+#define PLSVO_K_STRUCTOPT     4
+#define PLSVO_K_COUNT         5
 int plsvo_hip_set_profiling(plsvo_ctx* ctx, int enable);
 /* accumulated GPU time and launch count of kernel family k since the last reset (synchronises) */
 int plsvo_hip_kernel_time(plsvo_ctx* ctx, int k, double* total_ms, int64_t* launches);

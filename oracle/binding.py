@@ -50,6 +50,8 @@ def lib():
         L.plsvo_oracle_pose_optimize.restype = C.c_int
         L.plsvo_oracle_pose_optimize.argtypes = [C.POINTER(abi.PoseOptIn), C.POINTER(abi.PoseOptOut),
                                                  C.POINTER(abi.PoseOptIterLog), C.c_int, C.POINTER(C.c_int)]
+        L.plsvo_oracle_structure_optimize.restype = C.c_int
+        L.plsvo_oracle_structure_optimize.argtypes = [C.POINTER(abi.StructOptIn), C.POINTER(abi.StructOptOut)]
         L.plsvo_oracle_halfsample.restype = None
         L.plsvo_oracle_halfsample.argtypes = [abi.c_u8_p, C.c_int, C.c_int, C.c_int, abi.c_u8_p, C.c_int, C.c_int]
         d = abi.c_double_p
@@ -138,6 +140,14 @@ def pose_optimize(job, max_log=0):
         raise RuntimeError(f"oracle pose_optimize failed rc={rc}")
     res = abi.PoseOptResult(out, pk[:job.n_pts].copy(), sk[:job.n_seg].copy())
     return res, abi.poseopt_log_to_dicts(log, min(n_log.value, max_log))
+
+
+def structure_optimize(job):
+    out, bufs = job.make_out()
+    rc = lib().plsvo_oracle_structure_optimize(C.byref(job.c), C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"oracle structure_optimize failed rc={rc}")
+    return job.trim(bufs)
 
 
 # --- small helpers for unit tests -------------------------------------------------------------

@@ -862,3 +862,132 @@ done:
   free(p.pt_keep); free(p.seg_keep); free(p.chi2_vec_init); free(chi2_vec_final); free(errors); free(errors_ls);
   return rc;
 }
+
+/* ============================================================================================ */
+/* Point::optimize / LineSeg::optimize  src/feature3D_impl.cpp:36-175                            */
+/* ============================================================================================ */
+
+/* [ext] Eigen::LDLT<Matrix3d>::compute + solve, the 3x3 instance of the algorithm restated above */
+static void ldlt_solve3(const double A[9], const double b[3], double x[3]) {
+  enum { N = 3 };
+  double m[N][N]; int tr[N];
+  for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) m[i][j] = A[i * N + j];
+  for (int k = 0; k < N; ++k) {
+    int big = k; double bigv = fabs(m[k][k]);
+    for (int i = k + 1; i < N; ++i) { const double v = fabs(m[i][i]); if (v > bigv) { bigv = v; big = i; } }
+    tr[k] = big;
+    if (k != big) {
+      for (int j = 0; j < k; ++j) { const double t = m[k][j]; m[k][j] = m[big][j]; m[big][j] = t; }
+      for (int i = big + 1; i < N; ++i) { const double t = m[i][k]; m[i][k] = m[i][big]; m[i][big] = t; }
+      { const double t = m[k][k]; m[k][k] = m[big][big]; m[big][big] = t; }
+      for (int i = k + 1; i < big; ++i) { const double t = m[i][k]; m[i][k] = m[big][i]; m[big][i] = t; }
+    }
+    if (k > 0) {
+      double temp[N];
+      for (int j = 0; j < k; ++j) temp[j] = m[j][j] * m[k][j];
+      double acc = 0.0;
+      for (int j = 0; j < k; ++j) acc += m[k][j] * temp[j];
+      m[k][k] -= acc;
+      for (int i = k + 1; i < N; ++i) {
+        double a2 = 0.0;
+        for (int j = 0; j < k; ++j) a2 += m[i][j] * temp[j];
+        m[i][k] -= a2;
+      }
+    }
+    const double akk = m[k][k];
+    const int pivot_is_valid = fabs(akk) > 0.0;
+    if (k == 0 && !pivot_is_valid) { for (int j = 0; j < N; ++j) tr[j] = j; break; }
+    if (k < N - 1 && pivot_is_valid) for (int i = k + 1; i < N; ++i) m[i][k] /= akk;
+  }
+  double d[N];
+  for (int i = 0; i < N; ++i) d[i] = b[i];
+  for (int k = 0; k < N; ++k) { const double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
+  for (int i = 0; i < N; ++i) for (int j = 0; j < i; ++j) d[i] -= m[i][j] * d[j];
+  const double tolerance = 1.0 / 1.7976931348623157e308;
+  for (int i = 0; i < N; ++i) { if (fabs(m[i][i]) > tolerance) d[i] /= m[i][i]; else d[i] = 0.0; }
+  for (int i = N - 1; i >= 0; --i) for (int j = i + 1; j < N; ++j) d[i] -= m[j][i] * d[j];
+  for (int k = N - 1; k >= 0; --k) { const double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
+  for (int i = 0; i < N; ++i) x[i] = d[i];
+}
+
+/* one observation's contribution: Point::jacobian_xyz2uv (include/plsvo/feature3D.h:126-140),
+ * e = project2d(f) - project2d(p_in_f), A += J^T J, b -= J^T e, chi2 += |e|^2  (feature3D_impl.cpp:49-58) */
+static void structopt_accumulate(const se3_t* T, const double R[9], const double f[3], const double pos[3],
+                                 double A[9], double b[3], double* chi2) {
+  double p[3];
+  se3_act(T, pos, p);
+  const double z_inv = 1.0 / p[2];
+  const double z_inv_sq = z_inv * z_inv;
+  const double P[6] = { z_inv, 0.0, -p[0] * z_inv_sq, 0.0, z_inv, -p[1] * z_inv_sq };
+  double J[6];
+  for (int r = 0; r < 2; ++r)
+    for (int c = 0; c < 3; ++c)   /* point_jac = - point_jac * R_f_w  parses as (-point_jac) * R_f_w */
+      J[r * 3 + c] = (-P[r * 3 + 0]) * R[0 * 3 + c] + (-P[r * 3 + 1]) * R[1 * 3 + c] + (-P[r * 3 + 2]) * R[2 * 3 + c];
+  const double e0 = f[0] / f[2] - p[0] / p[2], e1 = f[1] / f[2] - p[1] / p[2];
+  *chi2 += e0 * e0 + e1 * e1;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) A[i * 3 + j] += J[i] * J[j] + J[3 + i] * J[3 + j];
+    b[i] -= J[i] * e0 + J[3 + i] * e1;
+  }
+}
+
+static double norm_max3(const double v[3]) { double m = 0; for (int i = 0; i < 3; ++i) { const double a = fabs(v[i]); if (a > m) m = a; } return m; }
+
+int plsvo_oracle_structure_optimize(const plsvo_structopt_in* in, plsvo_structopt_out* out) {
+  if (!in || !out) return PLSVO_E_INVALID;
+  se3_t* T = (se3_t*)malloc(sizeof(se3_t) * (size_t)(in->n_frames > 0 ? in->n_frames : 1));
+  double* Rm = (double*)malloc(sizeof(double) * 9 * (size_t)(in->n_frames > 0 ? in->n_frames : 1));
+  for (int k = 0; k < in->n_frames; ++k) { T[k] = se3_load(in->frame_T + 7 * k); quat_to_matrix(T[k].q, Rm + 9 * k); }
+  /* Point::optimize :36-96 */
+  for (int i = 0; i < in->n_pts; ++i) {
+    double pos[3] = { in->pt_pos[3 * i], in->pt_pos[3 * i + 1], in->pt_pos[3 * i + 2] };
+    double old_point[3] = { pos[0], pos[1], pos[2] };
+    double chi2 = 0.0; int iters = 0;
+    for (int it = 0; it < in->n_iter_pts; ++it) {
+      double A[9] = { 0 }, b[3] = { 0 }, new_chi2 = 0.0;
+      ++iters;
+      for (int o = in->pt_obs_off[i]; o < in->pt_obs_off[i + 1]; ++o) {
+        const int fr = in->pt_obs_frame[o];
+        structopt_accumulate(&T[fr], Rm + 9 * fr, in->pt_obs_f + 3 * o, pos, A, b, &new_chi2);
+      }
+      double dp[3];
+      ldlt_solve3(A, b, dp);
+      if ((it > 0 && new_chi2 > chi2) || isnan(dp[0])) { pos[0] = old_point[0]; pos[1] = old_point[1]; pos[2] = old_point[2]; break; }
+      for (int k = 0; k < 3; ++k) { old_point[k] = pos[k]; pos[k] = pos[k] + dp[k]; }
+      chi2 = new_chi2;
+      if (norm_max3(dp) <= 0.0000000001) break;
+    }
+    if (out->pt_pos) { out->pt_pos[3 * i] = pos[0]; out->pt_pos[3 * i + 1] = pos[1]; out->pt_pos[3 * i + 2] = pos[2]; }
+    if (out->pt_iters) out->pt_iters[i] = iters;
+  }
+  /* LineSeg::optimize :98-175: both end points advance together and roll back together */
+  for (int i = 0; i < in->n_seg; ++i) {
+    double sp[3], ep[3], old_s[3], old_e[3];
+    for (int k = 0; k < 3; ++k) { sp[k] = old_s[k] = in->seg_spos[3 * i + k]; ep[k] = old_e[k] = in->seg_epos[3 * i + k]; }
+    double chi2s = 0.0, chi2e = 0.0; int iters = 0;
+    for (int it = 0; it < in->n_iter_segs; ++it) {
+      double As[9] = { 0 }, Ae[9] = { 0 }, bs[3] = { 0 }, be[3] = { 0 }, ncs = 0.0, nce = 0.0;
+      ++iters;
+      for (int o = in->seg_obs_off[i]; o < in->seg_obs_off[i + 1]; ++o) {
+        const int fr = in->seg_obs_frame[o];
+        structopt_accumulate(&T[fr], Rm + 9 * fr, in->seg_obs_sf + 3 * o, sp, As, bs, &ncs);
+        structopt_accumulate(&T[fr], Rm + 9 * fr, in->seg_obs_ef + 3 * o, ep, Ae, be, &nce);
+      }
+      double dps[3], dpe[3];
+      ldlt_solve3(As, bs, dps);
+      ldlt_solve3(Ae, be, dpe);
+      if ((it > 0 && ncs > chi2s) || isnan(dps[0]) || (it > 0 && nce > chi2e) || isnan(dpe[0])) {
+        for (int k = 0; k < 3; ++k) { sp[k] = old_s[k]; ep[k] = old_e[k]; }
+        break;
+      }
+      for (int k = 0; k < 3; ++k) { old_s[k] = sp[k]; sp[k] = sp[k] + dps[k]; old_e[k] = ep[k]; ep[k] = ep[k] + dpe[k]; }
+      chi2s = ncs; chi2e = nce;
+      if (norm_max3(dps) <= 0.0000000001 || norm_max3(dpe) <= 0.0000000001) break;
+    }
+    if (out->seg_spos) for (int k = 0; k < 3; ++k) out->seg_spos[3 * i + k] = sp[k];
+    if (out->seg_epos) for (int k = 0; k < 3; ++k) out->seg_epos[3 * i + k] = ep[k];
+    if (out->seg_iters) out->seg_iters[i] = iters;
+  }
+  free(T); free(Rm);
+  return 0;
+}

@@ -34,3 +34,8 @@ def poseopt_job_from_frame(fr, reproj_thresh=2.0, n_iter=10, n_iter_ref=-1):
                           pt_f=fr.pt_f, pt_pos=fr.pt_pos, pt_level=fr.pt_level, seg_line=fr.seg_line,
                           seg_spos=fr.seg_spos, seg_epos=fr.seg_epos, seg_level=fr.seg_level,
                           n_iter_ref=n_iter_ref)
+
+
+def structopt_job_from_batch(d, n_iter_pts=5, n_iter_segs=5):
+    return abi.StructOptJob(d["frame_T"], d["pt_pos"], d["pt_obs_off"], d["pt_obs_frame"], d["pt_obs_f"], d["seg_spos"], d["seg_epos"],
+                            d["seg_obs_off"], d["seg_obs_frame"], d["seg_obs_sf"], d["seg_obs_ef"], n_iter_pts, n_iter_segs)

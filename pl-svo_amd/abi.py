@@ -18,7 +18,7 @@ c_i32_p = C.POINTER(C.c_int32)
 OK, E_INVALID, E_NODEVICE, E_HIP, E_CAPACITY, E_STATE, E_RCCL = 0, -1, -2, -3, -4, -5, -6
 
 # kernel families for plsvo_hip_kernel_time
-K_ALIGN_INIT, K_ALIGN_LEVEL, K_POSEOPT, K_HALFSAMPLE, K_COUNT = 0, 1, 2, 3, 4
+K_ALIGN_INIT, K_ALIGN_LEVEL, K_POSEOPT, K_HALFSAMPLE, K_STRUCTOPT, K_COUNT = 0, 1, 2, 3, 4, 5
 
 
 class Pinhole(C.Structure):
@@ -67,6 +67,19 @@ class PoseOptIterLog(C.Structure):
     _fields_ = [("phase", C.c_int32), ("iter", C.c_int32), ("accepted", C.c_int32), ("reserved0", C.c_int32),
                 ("new_chi2", C.c_double), ("A", C.c_double * 36), ("b", C.c_double * 6), ("dT", C.c_double * 6),
                 ("T_after", C.c_double * 7)]
+
+
+class StructOptIn(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("n_iter_pts", C.c_int32), ("n_iter_segs", C.c_int32), ("n_pts", C.c_int32),
+                ("n_seg", C.c_int32), ("reserved0", C.c_int32), ("frame_T", c_double_p), ("pt_pos", c_double_p),
+                ("pt_obs_off", c_i32_p), ("pt_obs_frame", c_i32_p), ("pt_obs_f", c_double_p), ("seg_spos", c_double_p),
+                ("seg_epos", c_double_p), ("seg_obs_off", c_i32_p), ("seg_obs_frame", c_i32_p), ("seg_obs_sf", c_double_p),
+                ("seg_obs_ef", c_double_p)]
+
+
+class StructOptOut(C.Structure):
+    _fields_ = [("pt_pos", c_double_p), ("seg_spos", c_double_p), ("seg_epos", c_double_p), ("pt_iters", c_i32_p),
+                ("seg_iters", c_i32_p)]
 
 
 def _f64(a, n=None):
@@ -181,3 +194,41 @@ def poseopt_log_to_dicts(arr, n):
     return [dict(phase=r.phase, iter=r.iter, accepted=r.accepted, new_chi2=float(r.new_chi2),
                  A=np.array(r.A[:]).reshape(6, 6), b=np.array(r.b[:]), dT=np.array(r.dT[:]),
                  T_after=np.array(r.T_after[:])) for r in arr[:n]]
+
+
+class StructOptJob:
+    """A batch of landmarks for plsvo_structure_optimize; owns the numpy buffers and the output arrays."""
+
+    def __init__(self, frame_T, pt_pos, pt_obs_off, pt_obs_frame, pt_obs_f, seg_spos, seg_epos, seg_obs_off, seg_obs_frame,
+                 seg_obs_sf, seg_obs_ef, n_iter_pts=5, n_iter_segs=5):
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32).reshape(-1)
+        self.frame_T = _f64(frame_T).reshape(-1, 7)
+        self.pt_pos = _f64(pt_pos).reshape(-1, 3)
+        self.pt_obs_off, self.pt_obs_frame, self.pt_obs_f = i32(pt_obs_off), i32(pt_obs_frame), _f64(pt_obs_f).reshape(-1, 3)
+        self.seg_spos, self.seg_epos = _f64(seg_spos).reshape(-1, 3), _f64(seg_epos).reshape(-1, 3)
+        self.seg_obs_off, self.seg_obs_frame = i32(seg_obs_off), i32(seg_obs_frame)
+        self.seg_obs_sf, self.seg_obs_ef = _f64(seg_obs_sf).reshape(-1, 3), _f64(seg_obs_ef).reshape(-1, 3)
+        self.n_pts, self.n_seg = self.pt_pos.shape[0], self.seg_spos.shape[0]
+        c = StructOptIn()
+        c.n_frames, c.n_iter_pts, c.n_iter_segs, c.n_pts, c.n_seg = self.frame_T.shape[0], n_iter_pts, n_iter_segs, self.n_pts, self.n_seg
+        c.frame_T = _ptr(self.frame_T, c_double_p)
+        c.pt_pos, c.pt_obs_off = _ptr(self.pt_pos, c_double_p), _ptr(self.pt_obs_off, c_i32_p)
+        c.pt_obs_frame, c.pt_obs_f = _ptr(self.pt_obs_frame, c_i32_p), _ptr(self.pt_obs_f, c_double_p)
+        c.seg_spos, c.seg_epos = _ptr(self.seg_spos, c_double_p), _ptr(self.seg_epos, c_double_p)
+        c.seg_obs_off, c.seg_obs_frame = _ptr(self.seg_obs_off, c_i32_p), _ptr(self.seg_obs_frame, c_i32_p)
+        c.seg_obs_sf, c.seg_obs_ef = _ptr(self.seg_obs_sf, c_double_p), _ptr(self.seg_obs_ef, c_double_p)
+        self.c = c
+
+    def make_out(self):
+        o = StructOptOut()
+        bufs = dict(pt_pos=np.zeros((max(self.n_pts, 1), 3)), seg_spos=np.zeros((max(self.n_seg, 1), 3)),
+                    seg_epos=np.zeros((max(self.n_seg, 1), 3)), pt_iters=np.zeros(max(self.n_pts, 1), np.int32),
+                    seg_iters=np.zeros(max(self.n_seg, 1), np.int32))
+        o.pt_pos, o.seg_spos, o.seg_epos = (bufs[k].ctypes.data_as(c_double_p) for k in ("pt_pos", "seg_spos", "seg_epos"))
+        o.pt_iters, o.seg_iters = bufs["pt_iters"].ctypes.data_as(c_i32_p), bufs["seg_iters"].ctypes.data_as(c_i32_p)
+        return o, bufs
+
+    def trim(self, bufs):
+        return dict(pt_pos=bufs["pt_pos"][:self.n_pts].copy(), seg_spos=bufs["seg_spos"][:self.n_seg].copy(),
+                    seg_epos=bufs["seg_epos"][:self.n_seg].copy(), pt_iters=bufs["pt_iters"][:self.n_pts].copy(),
+                    seg_iters=bufs["seg_iters"][:self.n_seg].copy())

@@ -24,6 +24,7 @@ hipError_t launch_align_init(const AlignBatchDev& b, hipStream_t stream);
 hipError_t launch_align_finish(const AlignBatchDev& b, double* d_poses, hipStream_t stream);
 hipError_t launch_pose_opt(const PoseBatchDev& b, hipStream_t stream);
 hipError_t launch_pose_finish(const PoseBatchDev& b, double* d_poses, hipStream_t stream);
+hipError_t launch_structopt(const StructBatchDev& s, hipStream_t stream);
 hipError_t launch_halfsample(const uint8_t* src, size_t src_pitch, int in_w, int in_h, int in_stride, uint8_t* dst,
                              size_t dst_pitch, int n_slots, int rounding, hipStream_t stream);
 hipError_t launch_copy_level0(const uint8_t* src, size_t src_pitch, int w, int h, int stride, uint8_t* dst, size_t dst_pitch,
@@ -90,6 +91,9 @@ struct plsvo_ctx {
   DevBuf p_d_jobs, p_d_state, p_d_f, p_d_pos, p_d_plevel, p_d_line, p_d_spos, p_d_epos, p_d_slevel, p_d_ptkeep, p_d_segkeep;
   DevBuf p_d_s32, p_d_s64, p_d_log, p_d_poses;
   PoseBatchDev p_b{};
+
+  // structure optimisation (one-shot batches)
+  DevBuf s_d_in, s_d_out;
 
   // profiling
   bool profiling = false;
@@ -183,7 +187,7 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
                      &c->a_d_epx, &c->a_d_len, &c->a_d_p, &c->a_d_q, &c->a_d_alive_in, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv,
                      &c->a_d_cref, &c->a_d_cdx, &c->a_d_cdy, &c->a_d_partial, &c->a_d_log, &c->a_d_poses, &c->p_d_jobs, &c->p_d_state,
                      &c->p_d_f, &c->p_d_pos, &c->p_d_plevel, &c->p_d_line, &c->p_d_spos, &c->p_d_epos, &c->p_d_slevel,
-                     &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64, &c->p_d_log, &c->p_d_poses };
+                     &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64, &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out };
   for (DevBuf* b : bufs) b->release();
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -726,6 +730,67 @@ extern "C" int plsvo_poseopt_work(plsvo_ctx* c, uint64_t* pt_iters, uint64_t* se
   for (auto& s : st) { a += s.pt_iters; b2 += s.seg_iters; }
   if (pt_iters) *pt_iters = a;
   if (seg_iters) *seg_iters = b2;
+  return PLSVO_OK;
+}
+
+// ---- structure optimisation ------------------------------------------------------------------------
+extern "C" int plsvo_structure_optimize(plsvo_ctx* c, const plsvo_structopt_in* in, plsvo_structopt_out* out) {
+  CTX_CHECK(c);
+  if (!in || !out || in->n_pts < 0 || in->n_seg < 0 || in->n_frames < 0 || in->n_iter_pts < 0 || in->n_iter_segs < 0)
+    return fail(c, PLSVO_E_INVALID, "structure_optimize: bad arguments");
+  if ((in->n_pts > 0 && (!in->pt_pos || !in->pt_obs_off)) || (in->n_seg > 0 && (!in->seg_spos || !in->seg_epos || !in->seg_obs_off)))
+    return fail(c, PLSVO_E_INVALID, "structure_optimize: null landmark array");
+  if (in->n_pts + in->n_seg == 0) return PLSVO_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int np = in->n_pts, ns = in->n_seg;
+  const int npo = np > 0 ? in->pt_obs_off[np] : 0, nso = ns > 0 ? in->seg_obs_off[ns] : 0;
+  if (npo < 0 || nso < 0 || (npo > 0 && (!in->pt_obs_frame || !in->pt_obs_f)) || (nso > 0 && (!in->seg_obs_frame || !in->seg_obs_sf || !in->seg_obs_ef)) ||
+      ((npo > 0 || nso > 0) && (!in->frame_T || in->n_frames <= 0)))
+    return fail(c, PLSVO_E_INVALID, "structure_optimize: bad observation tables");
+  for (int i = 0; i < npo; ++i) if (in->pt_obs_frame[i] < 0 || in->pt_obs_frame[i] >= in->n_frames) return fail(c, PLSVO_E_INVALID, "structure_optimize: frame index out of range");
+  for (int i = 0; i < nso; ++i) if (in->seg_obs_frame[i] < 0 || in->seg_obs_frame[i] >= in->n_frames) return fail(c, PLSVO_E_INVALID, "structure_optimize: frame index out of range");
+  // one packed upload: doubles first, then ints
+  std::vector<double> d;
+  auto putd = [&](const double* p, size_t n) { const size_t o = d.size(); if (n) d.insert(d.end(), p, p + n); return o; };
+  const size_t o_T = putd(in->frame_T, (size_t)in->n_frames * 7), o_pp = putd(in->pt_pos, (size_t)np * 3), o_pf = putd(in->pt_obs_f, (size_t)npo * 3);
+  const size_t o_ss = putd(in->seg_spos, (size_t)ns * 3), o_se = putd(in->seg_epos, (size_t)ns * 3);
+  const size_t o_sf = putd(in->seg_obs_sf, (size_t)nso * 3), o_ef = putd(in->seg_obs_ef, (size_t)nso * 3);
+  std::vector<int> iv;
+  auto puti = [&](const int32_t* p, size_t n) { const size_t o = iv.size(); if (n) iv.insert(iv.end(), p, p + n); return o; };
+  const size_t o_po = puti(in->pt_obs_off, np > 0 ? (size_t)np + 1 : 0), o_pfr = puti(in->pt_obs_frame, (size_t)npo);
+  const size_t o_so = puti(in->seg_obs_off, ns > 0 ? (size_t)ns + 1 : 0), o_sfr = puti(in->seg_obs_frame, (size_t)nso);
+  const size_t dbytes = (d.size() + 1) * sizeof(double), ibytes = (iv.size() + 1) * sizeof(int);
+  HIP_TRY(c, c->s_d_in.ensure(dbytes + ibytes));
+  HIP_TRY(c, hipMemcpyAsync(c->s_d_in.p, d.data(), d.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (!iv.empty()) HIP_TRY(c, hipMemcpyAsync(reinterpret_cast<char*>(c->s_d_in.p) + dbytes, iv.data(), iv.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  const size_t out_d = (size_t)(np + 2 * ns) * 3, out_i = (size_t)(np + ns);
+  HIP_TRY(c, c->s_d_out.ensure((out_d + 1) * sizeof(double) + (out_i + 1) * sizeof(int)));
+  const double* dd = c->s_d_in.as<double>();
+  const int* di = reinterpret_cast<const int*>(reinterpret_cast<const char*>(c->s_d_in.p) + dbytes);
+  double* od = c->s_d_out.as<double>();
+  int* oi = reinterpret_cast<int*>(reinterpret_cast<char*>(c->s_d_out.p) + (out_d + 1) * sizeof(double));
+  StructBatchDev s{};
+  s.frame_T = dd + o_T; s.pt_pos = dd + o_pp; s.pt_obs_f = dd + o_pf; s.seg_spos = dd + o_ss; s.seg_epos = dd + o_se;
+  s.seg_obs_sf = dd + o_sf; s.seg_obs_ef = dd + o_ef;
+  s.pt_obs_off = di + o_po; s.pt_obs_frame = di + o_pfr; s.seg_obs_off = di + o_so; s.seg_obs_frame = di + o_sfr;
+  s.pt_pos_out = od; s.seg_spos_out = od + (size_t)np * 3; s.seg_epos_out = od + (size_t)(np + ns) * 3;
+  s.pt_iters = oi; s.seg_iters = oi + np;
+  s.n_pts = np; s.n_seg = ns; s.n_iter_pts = in->n_iter_pts; s.n_iter_segs = in->n_iter_segs;
+  {
+    EventPair ep{}; prof_begin(c, PLSVO_K_STRUCTOPT, &ep);
+    HIP_TRY(c, launch_structopt(s, c->stream));
+    prof_end(c, PLSVO_K_STRUCTOPT, &ep);
+  }
+  std::vector<double> hd(out_d + 1);
+  std::vector<int> hi(out_i + 1);
+  HIP_TRY(c, hipMemcpyAsync(hd.data(), od, out_d * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(hi.data(), oi, out_i * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (out->pt_pos && np) memcpy(out->pt_pos, hd.data(), (size_t)np * 3 * sizeof(double));
+  if (out->seg_spos && ns) memcpy(out->seg_spos, hd.data() + (size_t)np * 3, (size_t)ns * 3 * sizeof(double));
+  if (out->seg_epos && ns) memcpy(out->seg_epos, hd.data() + (size_t)(np + ns) * 3, (size_t)ns * 3 * sizeof(double));
+  if (out->pt_iters && np) memcpy(out->pt_iters, hi.data(), (size_t)np * sizeof(int));
+  if (out->seg_iters && ns) memcpy(out->seg_iters, hi.data() + np, (size_t)ns * sizeof(int));
   return PLSVO_OK;
 }
 

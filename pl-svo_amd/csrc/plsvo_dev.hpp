@@ -120,4 +120,13 @@ struct PoseBatchDev {
   int n_jobs;
 };
 
+struct StructBatchDev {
+  const double* frame_T;
+  const double* pt_pos; const int* pt_obs_off; const int* pt_obs_frame; const double* pt_obs_f;
+  const double* seg_spos; const double* seg_epos; const int* seg_obs_off; const int* seg_obs_frame;
+  const double* seg_obs_sf; const double* seg_obs_ef;
+  double* pt_pos_out; double* seg_spos_out; double* seg_epos_out; int* pt_iters; int* seg_iters;
+  int n_pts, n_seg, n_iter_pts, n_iter_segs;
+};
+
 }  // namespace plsvo_hip

@@ -304,3 +304,54 @@ def make_poseopt_frame(seed, n_pts=500, n_seg=200, W=640, H=480, noise_px=1.0, o
                         pt_level=rng.integers(0, 3, n_pts).astype(np.int32), pt_outlier=pt_out,
                         seg_line=line, seg_spos=spos, seg_epos=epos,
                         seg_level=rng.integers(0, 3, n_seg).astype(np.int32), seg_outlier=(so | eo))
+
+
+# ------------------------------------------------------------------------------------------------
+# structure optimisation: landmarks observed from several keyframes
+# ------------------------------------------------------------------------------------------------
+
+def make_structure_batch(seed, n_pts=20, n_seg=20, n_frames=6, W=640, H=480, noise_px=0.5, pert=0.05, obs_range=(2, 6)):
+    """Landmarks in front of `n_frames` nearby cameras; every landmark is observed (noisy unit bearings) from a random
+    subset of frames and starts `pert` metres off its true position.  Returns the flat arrays of plsvo_structopt_in
+    plus the ground truth."""
+    rng = np.random.default_rng(seed + 900000)
+    fx = 0.65 * W
+    frames = [se3_exp(np.concatenate([rng.uniform(-0.4, 0.4, 3), rng.uniform(-0.08, 0.08, 3)])) for _ in range(n_frames)]
+
+    def bearing(T, X):
+        p = se3_act(T, X)
+        uv = p[:2] / p[2] + rng.normal(0.0, noise_px / fx, 2)
+        r = np.array([uv[0], uv[1], 1.0])
+        return r / np.linalg.norm(r)
+
+    def landmark():
+        return np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.0, 1.0), rng.uniform(3.0, 8.0)])
+
+    def observe(points_of_landmark):
+        k = int(rng.integers(obs_range[0], min(obs_range[1], n_frames) + 1))
+        fr = rng.choice(n_frames, size=k, replace=False)
+        return fr, [[bearing(frames[f], X) for f in fr] for X in points_of_landmark]
+
+    pt_true = np.array([landmark() for _ in range(n_pts)]).reshape(-1, 3)
+    pt_off, pt_fr, pt_f = [0], [], []
+    for X in pt_true:
+        fr, fs = observe([X])
+        pt_fr += list(fr)
+        pt_f += fs[0]
+        pt_off.append(len(pt_fr))
+    s_true = np.array([landmark() for _ in range(n_seg)]).reshape(-1, 3)
+    e_true = s_true + rng.uniform(-0.6, 0.6, (n_seg, 3)) if n_seg else np.zeros((0, 3))
+    sg_off, sg_fr, sg_sf, sg_ef = [0], [], [], []
+    for Xs, Xe in zip(s_true, e_true):
+        fr, fs = observe([Xs, Xe])
+        sg_fr += list(fr)
+        sg_sf += fs[0]
+        sg_ef += fs[1]
+        sg_off.append(len(sg_fr))
+    z3 = np.zeros((0, 3))
+    return dict(frame_T=np.array(frames), pt_true=pt_true, pt_pos=pt_true + rng.normal(0, pert, pt_true.shape),
+                pt_obs_off=np.array(pt_off, np.int32), pt_obs_frame=np.array(pt_fr, np.int32), pt_obs_f=np.array(pt_f).reshape(-1, 3) if pt_f else z3,
+                seg_s_true=s_true, seg_e_true=e_true, seg_spos=s_true + rng.normal(0, pert, s_true.shape),
+                seg_epos=e_true + rng.normal(0, pert, e_true.shape), seg_obs_off=np.array(sg_off, np.int32),
+                seg_obs_frame=np.array(sg_fr, np.int32), seg_obs_sf=np.array(sg_sf).reshape(-1, 3) if sg_sf else z3,
+                seg_obs_ef=np.array(sg_ef).reshape(-1, 3) if sg_ef else z3)
