@@ -1,7 +1,7 @@
 // adapter_driver.cpp -- exercises the C++ adapter (hip_adapter.hpp) exactly the way
 // FrameHandlerMono::processFrame does (src/frame_handler_mono.cpp:266-274, 327-329), on frames built from a
 // binary dump written by tests/test_gpu_adapter.py.  Prints the mutated state for the test to compare with
-// the oracle.  Usage: adapter_driver <input.bin> <output.txt>
+// the oracle.  Usage: adapter_driver <input.bin> <output.txt> [structure.bin]
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -104,6 +104,46 @@ int main(int argc, char** argv) {
   fprintf(o, "\nseg_keep");
   for (int i = 0; i < po_seg; ++i) fprintf(o, " %d", qlf[(size_t)i].feat3D != nullptr ? 1 : 0);
   fprintf(o, "\n");
+
+  // ---- step 5 of processFrame: structure optimisation (optional third input file) ----
+  if (argc > 3) {
+    FILE* g = fopen(argv[3], "rb");
+    if (!g) { perror("open"); return 2; }
+    std::vector<double> h = read_doubles(g, 4);
+    const int nfr = (int)h[0], nsp = (int)h[1], nss = (int)h[2], n_it = (int)h[3];
+    std::vector<mini::Frame> kfs((size_t)nfr);
+    for (int k = 0; k < nfr; ++k) { std::vector<double> T = read_doubles(g, 7); kfs[(size_t)k].T_f_w_ = mini::SE3(mini::Quat(T[3], T[0], T[1], T[2]), mini::Vec3(T[4], T[5], T[6])); }
+    std::vector<mini::Point> lp((size_t)nsp); std::vector<mini::LineSeg> ll((size_t)nss);
+    std::list<mini::PointFeat> pf_store; std::list<mini::LineFeat> lf_store;
+    for (int i = 0; i < nsp; ++i) {
+      std::vector<double> d = read_doubles(g, 4);
+      lp[(size_t)i].pos_ = mini::Vec3(d[0], d[1], d[2]);
+      for (int k = 0; k < (int)d[3]; ++k) {
+        std::vector<double> ob = read_doubles(g, 4);
+        pf_store.emplace_back(); mini::PointFeat& F = pf_store.back();
+        F.frame = &kfs[(size_t)ob[0]]; F.f = mini::Vec3(ob[1], ob[2], ob[3]);
+        lp[(size_t)i].obs_.push_back(&F);
+      }
+    }
+    for (int i = 0; i < nss; ++i) {
+      std::vector<double> d = read_doubles(g, 7);
+      ll[(size_t)i].spos_ = mini::Vec3(d[0], d[1], d[2]); ll[(size_t)i].epos_ = mini::Vec3(d[3], d[4], d[5]);
+      for (int k = 0; k < (int)d[6]; ++k) {
+        std::vector<double> ob = read_doubles(g, 7);
+        lf_store.emplace_back(); mini::LineFeat& F = lf_store.back();
+        F.frame = &kfs[(size_t)ob[0]]; F.sf = mini::Vec3(ob[1], ob[2], ob[3]); F.ef = mini::Vec3(ob[4], ob[5], ob[6]);
+        ll[(size_t)i].obs_.push_back(&F);
+      }
+    }
+    fclose(g);
+    std::vector<mini::Point*> pp; std::vector<mini::LineSeg*> sp;
+    for (auto& x : lp) pp.push_back(&x);
+    for (auto& x : ll) sp.push_back(&x);
+    plsvo::structure_optimizer::optimize(pp.begin(), pp.end(), (size_t)n_it, sp.begin(), sp.end(), (size_t)n_it);
+    for (int i = 0; i < nsp; ++i) fprintf(o, "spt %.17g %.17g %.17g\n", lp[(size_t)i].pos_[0], lp[(size_t)i].pos_[1], lp[(size_t)i].pos_[2]);
+    for (int i = 0; i < nss; ++i) fprintf(o, "sseg %.17g %.17g %.17g %.17g %.17g %.17g\n", ll[(size_t)i].spos_[0], ll[(size_t)i].spos_[1], ll[(size_t)i].spos_[2],
+                                          ll[(size_t)i].epos_[0], ll[(size_t)i].epos_[1], ll[(size_t)i].epos_[2]);
+  }
   fclose(o);
   return 0;
 }

@@ -317,4 +317,81 @@ void optimizeGaussNewton(const double reproj_thresh, const size_t n_iter, const 
 }  // namespace pose_optimizer
 }  // namespace plsvo
 
+namespace plsvo_hip_adapter {
+// distinct frames referenced by the observations of a landmark batch, in first-seen order (C++11: no generic lambdas)
+struct FrameTable {
+  std::vector<const void*> frames;
+  std::vector<double>& poses;
+  explicit FrameTable(std::vector<double>& p) : poses(p) {}
+  template <class Frame>
+  int32_t index(const Frame* fr) {
+    for (size_t k = 0; k < frames.size(); ++k) if (frames[k] == (const void*)fr) return (int32_t)k;
+    frames.push_back((const void*)fr);
+    double T[7];
+    typedef typename std::remove_cv<typename std::remove_reference<decltype(fr->T_f_w_)>::type>::type SE3T;
+    se3_traits<SE3T>::get(fr->T_f_w_, T);
+    poses.insert(poses.end(), T, T + 7);
+    return (int32_t)(frames.size() - 1);
+  }
+};
+}  // namespace plsvo_hip_adapter
+
+namespace plsvo {
+namespace structure_optimizer {
+
+/// Batched replacement of the two loops of FrameHandlerBase::optimizeStructure (src/frame_handler_base.cpp:213-236):
+///     for (it in selected points)  (*it)->optimize(max_iter);          -> Point::optimize    (src/feature3D_impl.cpp:36-96)
+///     for (it in selected segs)    (*it)->optimize(max_iter_segs);     -> LineSeg::optimize  (src/feature3D_impl.cpp:98-175)
+/// The selection (nth_element on last_structure_optim_) and the last_structure_optim_ bookkeeping stay with the
+/// caller.  Iterators range over Point* / LineSeg*; observations are read from Feature3D::obs_
+/// (include/plsvo/feature3D.h) as (feature->frame->T_f_w_, feature->f | sf | ef).  Writes pos_ / spos_ / epos_.
+template <class PointIt, class SegIt>
+bool optimize(PointIt pts_begin, PointIt pts_end, size_t n_iter, SegIt segs_begin, SegIt segs_end, size_t n_iter_segs) {
+  using namespace plsvo_hip_adapter;
+  Context& c = default_context();
+  if (!c.ctx && !c.ensure(64, 64, 1)) return false;
+  std::vector<double> frame_T, pt_pos, pt_f, sp, ep, sf, ef;
+  std::vector<int32_t> pt_off(1, 0), pt_fr, sg_off(1, 0), sg_fr;
+  FrameTable frames_tab(frame_T);   // frame identity -> index into frame_T
+#define frame_index(fr) frames_tab.index(fr)
+  for (PointIt it = pts_begin; it != pts_end; ++it) {
+    for (int k = 0; k < 3; ++k) pt_pos.push_back((*it)->pos_[k]);
+    for (auto o = (*it)->obs_.begin(); o != (*it)->obs_.end(); ++o) {
+      pt_fr.push_back(frame_index((*o)->frame));
+      for (int k = 0; k < 3; ++k) pt_f.push_back((*o)->f[k]);
+    }
+    pt_off.push_back((int32_t)pt_fr.size());
+  }
+  for (SegIt it = segs_begin; it != segs_end; ++it) {
+    for (int k = 0; k < 3; ++k) { sp.push_back((*it)->spos_[k]); ep.push_back((*it)->epos_[k]); }
+    for (auto o = (*it)->obs_.begin(); o != (*it)->obs_.end(); ++o) {
+      sg_fr.push_back(frame_index((*o)->frame));
+      for (int k = 0; k < 3; ++k) { sf.push_back((*o)->sf[k]); ef.push_back((*o)->ef[k]); }
+    }
+    sg_off.push_back((int32_t)sg_fr.size());
+  }
+  plsvo_structopt_in in;
+#undef frame_index
+  in.n_frames = (int32_t)frames_tab.frames.size(); in.n_iter_pts = (int32_t)n_iter; in.n_iter_segs = (int32_t)n_iter_segs;
+  in.n_pts = (int32_t)pt_off.size() - 1; in.n_seg = (int32_t)sg_off.size() - 1; in.reserved0 = 0;
+  in.frame_T = frame_T.data(); in.pt_pos = pt_pos.data(); in.pt_obs_off = pt_off.data(); in.pt_obs_frame = pt_fr.data(); in.pt_obs_f = pt_f.data();
+  in.seg_spos = sp.data(); in.seg_epos = ep.data(); in.seg_obs_off = sg_off.data(); in.seg_obs_frame = sg_fr.data();
+  in.seg_obs_sf = sf.data(); in.seg_obs_ef = ef.data();
+  std::vector<double> o_pt(pt_pos.size() + 1), o_s(sp.size() + 1), o_e(ep.size() + 1);
+  plsvo_structopt_out out;
+  out.pt_pos = o_pt.data(); out.seg_spos = o_s.data(); out.seg_epos = o_e.data(); out.pt_iters = nullptr; out.seg_iters = nullptr;
+  if (plsvo_structure_optimize(c.ctx, &in, &out) != PLSVO_OK) {
+    std::fprintf(stderr, "[plsvo_hip] structure_optimize failed: %s\n", plsvo_hip_last_error(c.ctx));
+    return false;
+  }
+  size_t i = 0;
+  for (PointIt it = pts_begin; it != pts_end; ++it, ++i) for (int k = 0; k < 3; ++k) (*it)->pos_[k] = o_pt[3 * i + k];
+  i = 0;
+  for (SegIt it = segs_begin; it != segs_end; ++it, ++i) for (int k = 0; k < 3; ++k) { (*it)->spos_[k] = o_s[3 * i + k]; (*it)->epos_[k] = o_e[3 * i + k]; }
+  return true;
+}
+
+}  // namespace structure_optimizer
+}  // namespace plsvo
+
 namespace svo = plsvo;  // BASELINE.json spells the upstream name svo::SparseImgAlign

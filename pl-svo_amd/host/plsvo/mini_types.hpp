@@ -39,9 +39,12 @@ struct Camera {  // vk::PinholeCamera look-alike (no distortion)
   int width() const { return w_; } int height() const { return h_; }
   double errorMultiplier2() const { return std::fabs(fx_); }
 };
-struct Point { Vec3 pos_; };
-struct LineSeg { Vec3 spos_, epos_; };
-struct Feature { Vec2 px; Vec3 f; int level = 0; };
+struct Frame;
+struct PointFeat;
+struct LineFeat;
+struct Point { Vec3 pos_; std::list<PointFeat*> obs_; };              // Feature3D<PointFeat>::obs_
+struct LineSeg { Vec3 spos_, epos_; std::list<LineFeat*> obs_; };     // Feature3D<LineFeat>::obs_
+struct Feature { Frame* frame = nullptr; Vec2 px; Vec3 f; int level = 0; };
 struct PointFeat : Feature { Point* feat3D = nullptr; };
 struct LineFeat : Feature { Vec2 spx, epx; Vec3 sf, ef, line; LineSeg* feat3D = nullptr; double length = 0; };
 struct Frame {

@@ -34,9 +34,31 @@ def test_adapter_reproduces_reference_mutations(P, ob, tmp_path):
         np.asarray(fr.T_init, np.float64).tofile(f)
         np.hstack([fr.pt_f, fr.pt_pos, fr.pt_level[:, None].astype(float)]).astype(np.float64).tofile(f)
         np.hstack([fr.seg_line, fr.seg_spos, fr.seg_epos, fr.seg_level[:, None].astype(float)]).astype(np.float64).tofile(f)
+    # landmarks with observation lists for the structure-optimisation step (src/frame_handler_mono.cpp:340)
+    sb = P.synth.make_structure_batch(779, 12, 9, 5)
+    spath = tmp_path / "struct.bin"
+    with open(spath, "wb") as f:
+        np.array([5, 12, 9, 5], float).tofile(f)
+        sb["frame_T"].astype(np.float64).tofile(f)
+        for i in range(12):
+            o0, o1 = sb["pt_obs_off"][i], sb["pt_obs_off"][i + 1]
+            np.concatenate([sb["pt_pos"][i], [o1 - o0]]).astype(np.float64).tofile(f)
+            for o in range(o0, o1):
+                np.concatenate([[sb["pt_obs_frame"][o]], sb["pt_obs_f"][o]]).astype(np.float64).tofile(f)
+        for i in range(9):
+            o0, o1 = sb["seg_obs_off"][i], sb["seg_obs_off"][i + 1]
+            np.concatenate([sb["seg_spos"][i], sb["seg_epos"][i], [o1 - o0]]).astype(np.float64).tofile(f)
+            for o in range(o0, o1):
+                np.concatenate([[sb["seg_obs_frame"][o]], sb["seg_obs_sf"][o], sb["seg_obs_ef"][o]]).astype(np.float64).tofile(f)
     out = tmp_path / "out.txt"
-    subprocess.run([DRIVER, str(path), str(out)], check=True, timeout=120)
-    got = {l.split()[0]: l.split()[1:] for l in open(out).read().strip().splitlines()}
+    subprocess.run([DRIVER, str(path), str(out), str(spath)], check=True, timeout=120)
+    lines = open(out).read().strip().splitlines()
+    got = {l.split()[0]: l.split()[1:] for l in lines if not l.startswith(("spt", "sseg"))}
+    so = ob.structure_optimize(P.structopt_job_from_batch(sb))
+    spt = np.array([[float(x) for x in l.split()[1:]] for l in lines if l.startswith("spt")])
+    sseg = np.array([[float(x) for x in l.split()[1:]] for l in lines if l.startswith("sseg")])
+    assert np.array_equal(spt, so["pt_pos"]), "Point::pos_ after the adapter must equal the oracle bit for bit"
+    assert np.array_equal(sseg[:, :3], so["seg_spos"]) and np.array_equal(sseg[:, 3:], so["seg_epos"])
 
     # oracle on the same flattened inputs (first `ndead` segments have no landmark)
     alive_in = np.ones(nseg, np.uint8)
