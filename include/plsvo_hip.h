@@ -287,6 +287,62 @@ typedef struct plsvo_structopt_out {   /* caller buffers; any of them may be NUL
 int plsvo_structure_optimize(plsvo_ctx* ctx, const plsvo_structopt_in* in, plsvo_structopt_out* out);
 
 /* ------------------------------------------------------------------------------------------ */
+/* direct feature matching (hot-path contract row (f) "next" #2)                               */
+/* replaces plsvo::Matcher::findMatchDirect for points (src/matcher.cpp:157-208) and for line  */
+/* segments (:233-280), with everything they call: warp::getWarpMatrixAffine (:40-68),         */
+/* warp::getBestSearchLevel (:70-84), warp::warpAffine (:86-128),                              */
+/* Matcher::createPatchFromPatchWithBorder (:146-155), Matcher::precomputeRefPatch (:210-231), */
+/* feature_alignment::align1D (src/feature_alignment.cpp:41-157) and align2D (:159-283).       */
+/* Call sites: Reprojector::refineBestCandidate (src/reprojector.cpp:288, :348).               */
+/* ------------------------------------------------------------------------------------------ */
+
+#define PLSVO_FTR_CORNER  0         /* PointFeat::CORNER, and both end points of a LineFeat */
+#define PLSVO_FTR_EDGELET 1         /* PointFeat::EDGELET: 1-D alignment along the warped gradient */
+
+/* A batch of n independent match candidates.  One candidate = one 2-D position to refine in the image of
+ * frame cur_frame[i], starting from px_cur[i] (the landmark's projection, written by Reprojector), against the
+ * 8x8 patch around the landmark's closest-view observation (Point::getCloseViewObs, chosen by the host).
+ * A line segment contributes two candidates (start and end point, each with its own pos / px / f); the
+ * caller ANDs the two `found` flags like matcher.cpp:258-279.  Images are the ctx's pyramid slots.
+ *   frame_T      7*n_frames  Frame::T_f_w_ of every frame referenced
+ *   frame_slot   n_frames    pyramid slot holding that frame's Frame::img_pyr_
+ *   cur_frame    n           index of the frame matched into
+ *   ref_frame    n           index of ref_ftr_->frame
+ *   ref_px       2*n         ref_ftr_->px (level-0 pixels)       ref_f   3*n   ref_ftr_->f
+ *   ref_level    n           ref_ftr_->level                     ref_type n    PLSVO_FTR_*
+ *   ref_grad     2*n         PointFeat::grad (read for edgelets only; may be NULL when there are none)
+ *   pos          3*n         Point::pos_ (LineSeg::spos_ / epos_)
+ *   px_cur       2*n         initial estimate in level-0 pixels of the current image */
+typedef struct plsvo_match_in {
+  plsvo_pinhole cam;                /* ref_ftr_->frame->cam_ == cur_frame.cam_ (one camera) */
+  int32_t n_pyr_levels;             /* Config::nPyrLevels(): search level <= n_pyr_levels-1 (matcher.cpp:172) */
+  int32_t align_max_iter;           /* Matcher::Options::align_max_iter (10, include/plsvo/matcher.h:98) */
+  int32_t n_frames;
+  int32_t n;
+  const double* frame_T;
+  const int32_t* frame_slot;
+  const int32_t* cur_frame;
+  const int32_t* ref_frame;
+  const double* ref_px;
+  const double* ref_f;
+  const int32_t* ref_level;
+  const uint8_t* ref_type;
+  const double* ref_grad;
+  const double* pos;
+  const double* px_cur;
+} plsvo_match_in;
+
+typedef struct plsvo_match_out {    /* caller buffers; any of them may be NULL */
+  double* px_cur;                   /* 2*n  refined position (level-0 pixels); the input value when the
+                                       reference observation is too close to the border (matcher.cpp:166-168) */
+  uint8_t* found;                   /* n    findMatchDirect's return value */
+  int32_t* search_level;            /* n    Matcher::search_level_ (-1 when rejected before the warp) */
+  int32_t* n_iter;                  /* n    residual passes executed by align1D/align2D */
+} plsvo_match_out;
+
+int plsvo_match_direct(plsvo_ctx* ctx, const plsvo_match_in* in, plsvo_match_out* out);
+
+/* ------------------------------------------------------------------------------------------ */
 /* multi-GPU: gather of per-stream pose records (new; the reference is single-process)         */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -304,7 +360,8 @@ int plsvo_gather_poses(plsvo_ctx* ctx, void* rccl_comm, const double* d_local, i
 #define PLSVO_K_POSEOPT       2
 #define PLSVO_K_HALFSAMPLE    3
 #define PLSVO_K_STRUCTOPT     4
-#define PLSVO_K_COUNT         5
+#define PLSVO_K_MATCH         5
+#define PLSVO_K_COUNT         6
 int plsvo_hip_set_profiling(plsvo_ctx* ctx, int enable);
 /* accumulated GPU time and launch count of kernel family k since the last reset (synchronises) */
 int plsvo_hip_kernel_time(plsvo_ctx* ctx, int k, double* total_ms, int64_t* launches);

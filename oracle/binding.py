@@ -52,6 +52,8 @@ def lib():
                                                  C.POINTER(abi.PoseOptIterLog), C.c_int, C.POINTER(C.c_int)]
         L.plsvo_oracle_structure_optimize.restype = C.c_int
         L.plsvo_oracle_structure_optimize.argtypes = [C.POINTER(abi.StructOptIn), C.POINTER(abi.StructOptOut)]
+        L.plsvo_oracle_match_direct.restype = C.c_int
+        L.plsvo_oracle_match_direct.argtypes = [C.POINTER(abi.MatchIn), C.POINTER(OraclePyr), C.POINTER(abi.MatchOut)]
         L.plsvo_oracle_halfsample.restype = None
         L.plsvo_oracle_halfsample.argtypes = [abi.c_u8_p, C.c_int, C.c_int, C.c_int, abi.c_u8_p, C.c_int, C.c_int]
         d = abi.c_double_p
@@ -147,6 +149,21 @@ def structure_optimize(job):
     rc = lib().plsvo_oracle_structure_optimize(C.byref(job.c), C.byref(out))
     if rc != 0:
         raise RuntimeError(f"oracle structure_optimize failed rc={rc}")
+    return job.trim(bufs)
+
+
+def match_direct(job, frame_levels):
+    """job: abi.MatchJob; frame_levels[k] = list of pyramid levels (uint8 arrays) of frame index k."""
+    pyrs = (OraclePyr * len(frame_levels))()
+    keep = []
+    for k, levels in enumerate(frame_levels):
+        p, kk = make_pyr(levels)
+        pyrs[k] = p
+        keep.append(kk)
+    out, bufs = job.make_out()
+    rc = lib().plsvo_oracle_match_direct(C.byref(job.c), pyrs, C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"oracle match_direct failed rc={rc}")
     return job.trim(bufs)
 
 

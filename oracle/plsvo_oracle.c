@@ -804,7 +804,8 @@ int plsvo_oracle_pose_optimize(const plsvo_poseopt_in* in, plsvo_poseopt_out* ou
   }
   if (n_err == 0) { /* :88-89 early return, nothing else written */
     out->status = 1; se3_store(&p.T, out->T_f_w);
-    if (out->pt_keep) memset(out->pt_keep, 1, np); if (out->seg_keep) memset(out->seg_keep, 1, ns);
+    if (out->pt_keep && np > 0) memset(out->pt_keep, 1, (size_t)np);
+    if (out->seg_keep && ns > 0) memset(out->seg_keep, 1, (size_t)ns);
     goto done;
   }
   out->num_obs_ls = n_err_ls;
@@ -990,4 +991,274 @@ int plsvo_oracle_structure_optimize(const plsvo_structopt_in* in, plsvo_structop
   }
   free(T); free(Rm);
   return 0;
+}
+
+/* ============================================================================================ */
+/* direct feature matching: Matcher::findMatchDirect (src/matcher.cpp:157-280) and callees      */
+/* ============================================================================================ */
+/* Summation orders of the Eigen fixed-size float expressions below are restated from Eigen 3.2 (the
+ * release contemporary with the reference; no version is pinned, CMakeLists.txt:39): coefficient-based
+ * products accumulate left to right, `.sum()` of 3 terms is a0 + (a1 + a2) (redux_novec_unroller).   */
+
+/* float -> int conversion as x86 cvttss2si does it for NaN (what `int u_r = floor(u)` compiles to there);
+ * written out so that the restatement has no undefined behaviour and the device can do the same */
+static int f2i_trunc(float x) { return isnan(x) ? INT32_MIN : (int)x; }
+
+/* [ext] vk::interpolateMat_8u (vikit/vision.h): bilinear lookup in float; the caller guarantees
+ * 0 <= u < cols-1, 0 <= v < rows-1 (matcher.cpp:121) */
+static float interpolate_mat_8u(const uint8_t* img, int stride, float u, float v) {
+  const int x = (int)floorf(u), y = (int)floorf(v);
+  const float subpix_x = u - x, subpix_y = v - y;
+  const float w00 = (1.0f - subpix_x) * (1.0f - subpix_y);
+  const float w01 = (1.0f - subpix_x) * subpix_y;
+  const float w10 = subpix_x * (1.0f - subpix_y);
+  const float w11 = 1.0f - w00 - w01 - w10;
+  const uint8_t* ptr = img + (ptrdiff_t)y * stride + x;
+  return w00 * ptr[0] + w01 * ptr[stride] + w10 * ptr[1] + w11 * ptr[stride + 1];
+}
+
+/* warp::getWarpMatrixAffine (matcher.cpp:40-68).  A is row-major {a00, a01, a10, a11}. */
+static void warp_matrix_affine(const plsvo_pinhole* cam, const double px_ref[2], const double f_ref[3],
+                               double depth_ref, const se3_t* T_cur_ref, int level_ref, double A[4]) {
+  const int halfpatch_size = 5;
+  const double xyz_ref[3] = { f_ref[0] * depth_ref, f_ref[1] * depth_ref, f_ref[2] * depth_ref };
+  const double pdu[2] = { px_ref[0] + (double)halfpatch_size * (1 << level_ref), px_ref[1] + 0.0 * (1 << level_ref) };
+  const double pdv[2] = { px_ref[0] + 0.0 * (1 << level_ref), px_ref[1] + (double)halfpatch_size * (1 << level_ref) };
+  double xyz_du_ref[3], xyz_dv_ref[3];
+  plsvo_oracle_cam2world(cam, pdu, xyz_du_ref);
+  plsvo_oracle_cam2world(cam, pdv, xyz_dv_ref);
+  const double su = xyz_ref[2] / xyz_du_ref[2], sv = xyz_ref[2] / xyz_dv_ref[2];
+  for (int i = 0; i < 3; ++i) { xyz_du_ref[i] *= su; xyz_dv_ref[i] *= sv; }
+  double c[3], px_cur[2], px_du[2], px_dv[2];
+  se3_act(T_cur_ref, xyz_ref, c);    plsvo_oracle_world2cam(cam, c, px_cur);
+  se3_act(T_cur_ref, xyz_du_ref, c); plsvo_oracle_world2cam(cam, c, px_du);
+  se3_act(T_cur_ref, xyz_dv_ref, c); plsvo_oracle_world2cam(cam, c, px_dv);
+  A[0] = (px_du[0] - px_cur[0]) / halfpatch_size; A[2] = (px_du[1] - px_cur[1]) / halfpatch_size;  /* col(0) */
+  A[1] = (px_dv[0] - px_cur[0]) / halfpatch_size; A[3] = (px_dv[1] - px_cur[1]) / halfpatch_size;  /* col(1) */
+}
+
+/* warp::getBestSearchLevel (matcher.cpp:70-84) */
+static int best_search_level(const double A[4], int max_level) {
+  int search_level = 0;
+  double D = A[0] * A[3] - A[2] * A[1];   /* [ext] Eigen 2x2 determinant */
+  while (D > 3.0 && search_level < max_level) { search_level += 1; D *= 0.25; }
+  return search_level;
+}
+
+/* warp::warpAffine (matcher.cpp:86-128); returns 0 when the inverse warp is NaN (the reference then leaves
+ * the Matcher's previous patch in place, :96-100 -- state this restatement does not carry: such a candidate is
+ * reported as not found) */
+static int warp_affine(const double A_cur_ref[4], const uint8_t* img_ref, int cols, int rows, int stride,
+                       const double px_ref[2], int level_ref, int search_level, int halfpatch_size, uint8_t* patch) {
+  const int patch_size = halfpatch_size * 2;
+  const double det = A_cur_ref[0] * A_cur_ref[3] - A_cur_ref[2] * A_cur_ref[1];
+  const double invdet = 1.0 / det;                      /* [ext] Eigen compute_inverse_size2_helper */
+  const float a00 = (float)(A_cur_ref[3] * invdet), a01 = (float)(-A_cur_ref[1] * invdet);
+  const float a10 = (float)(-A_cur_ref[2] * invdet), a11 = (float)(A_cur_ref[0] * invdet);
+  if (isnan(a00)) return 0;
+  const float rx = (float)px_ref[0] / (float)(1 << level_ref), ry = (float)px_ref[1] / (float)(1 << level_ref);
+  uint8_t* patch_ptr = patch;
+  for (int y = 0; y < patch_size; ++y) {
+    for (int x = 0; x < patch_size; ++x, ++patch_ptr) {
+      float ppx = (float)(x - halfpatch_size), ppy = (float)(y - halfpatch_size);
+      ppx *= (float)(1 << search_level); ppy *= (float)(1 << search_level);
+      const float px0 = (a00 * ppx + a01 * ppy) + rx;
+      const float px1 = (a10 * ppx + a11 * ppy) + ry;
+      if (px0 < 0 || px1 < 0 || px0 >= cols - 1 || px1 >= rows - 1) *patch_ptr = 0;
+      else *patch_ptr = (uint8_t)interpolate_mat_8u(img_ref, stride, px0, px1);
+    }
+  }
+  return 1;
+}
+
+enum { M_PATCH = 8, M_HALF = 4, M_AREA = 64, M_STEP = 10 };
+
+/* feature_alignment::align2D (feature_alignment.cpp:159-283), scalar path */
+static int align_2d(const uint8_t* cur_img, int cols, int rows, int cur_step, const uint8_t* ref_patch_with_border,
+                    const uint8_t* ref_patch, int n_iter, double cur_px_estimate[2], int* iters) {
+  int converged = 0;
+  float ref_patch_dx[M_AREA], ref_patch_dy[M_AREA];
+  float H[3][3] = { { 0 } };
+  const int ref_step = M_STEP;
+  float *it_dx = ref_patch_dx, *it_dy = ref_patch_dy;
+  for (int y = 0; y < M_PATCH; ++y) {
+    const uint8_t* it = ref_patch_with_border + (y + 1) * ref_step + 1;
+    for (int x = 0; x < M_PATCH; ++x, ++it, ++it_dx, ++it_dy) {
+      float J[3];
+      J[0] = (float)(0.5 * (it[1] - it[-1]));
+      J[1] = (float)(0.5 * (it[ref_step] - it[-ref_step]));
+      J[2] = 1;
+      *it_dx = J[0]; *it_dy = J[1];
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) H[i][j] += J[i] * J[j];
+    }
+  }
+  /* [ext] Eigen::Matrix3f::inverse(): compute_inverse_size3_helper (cofactors, det = col0 . cofactors_col0) */
+#define COF(i, j) (H[((i) + 1) % 3][((j) + 1) % 3] * H[((i) + 2) % 3][((j) + 2) % 3] - H[((i) + 1) % 3][((j) + 2) % 3] * H[((i) + 2) % 3][((j) + 1) % 3])
+  float Hinv[3][3];
+  {
+    const float c00 = COF(0, 0), c10 = COF(1, 0), c20 = COF(2, 0);
+    const float det = c00 * H[0][0] + (c10 * H[1][0] + c20 * H[2][0]);
+    const float invdet = 1.0f / det;
+    Hinv[0][0] = c00 * invdet; Hinv[0][1] = c10 * invdet; Hinv[0][2] = c20 * invdet;
+    Hinv[1][0] = COF(0, 1) * invdet; Hinv[1][1] = COF(1, 1) * invdet; Hinv[1][2] = COF(2, 1) * invdet;
+    Hinv[2][0] = COF(0, 2) * invdet; Hinv[2][1] = COF(1, 2) * invdet; Hinv[2][2] = COF(2, 2) * invdet;
+  }
+#undef COF
+  float mean_diff = 0;
+  float u = (float)cur_px_estimate[0], v = (float)cur_px_estimate[1];
+  const float min_update_squared = (float)(0.03 * 0.03);
+  float update[3] = { 0, 0, 0 };
+  int iter = 0;
+  for (; iter < n_iter; ++iter) {
+    /* Patch::setPosition / isInFrame(halfsize) / computeInterpWeights / setRoi (feature.cpp:189-218) */
+    const float u_ref = (float)cur_px_estimate[0], v_ref = (float)cur_px_estimate[1];
+    const int u_ref_i = f2i_trunc(floorf(u_ref)), v_ref_i = f2i_trunc(floorf(v_ref));
+    if (u_ref_i < M_HALF || v_ref_i < M_HALF || u_ref_i >= cols - M_HALF || v_ref_i >= rows - M_HALF) break;
+    const float subpix_u_ref = u_ref - u_ref_i, subpix_v_ref = v_ref - v_ref_i;
+    const float wTL = (float)((1.0 - subpix_u_ref) * (1.0 - subpix_v_ref));
+    const float wTR = (float)(subpix_u_ref * (1.0 - subpix_v_ref));
+    const float wBL = (float)((1.0 - subpix_u_ref) * subpix_v_ref);
+    const float wBR = subpix_u_ref * subpix_v_ref;
+    const uint8_t* it_ref = ref_patch;
+    const float *it_ref_dx = ref_patch_dx, *it_ref_dy = ref_patch_dy;
+    float Jres[3] = { 0, 0, 0 };
+    for (int y = 0; y < M_PATCH; ++y) {
+      const uint8_t* ptr = cur_img + (ptrdiff_t)(v_ref_i - M_HALF + y) * cur_step + (u_ref_i - M_HALF);
+      for (int x = 0; x < M_PATCH; ++x, ++ptr, ++it_ref, ++it_ref_dx, ++it_ref_dy) {
+        const float search_pixel = wTL * ptr[0] + wTR * ptr[1] + wBL * ptr[cur_step] + wBR * ptr[cur_step + 1];
+        const float res = search_pixel - *it_ref + mean_diff;
+        Jres[0] -= res * (*it_ref_dx);
+        Jres[1] -= res * (*it_ref_dy);
+        Jres[2] -= res;
+      }
+    }
+    for (int i = 0; i < 3; ++i) update[i] = Hinv[i][0] * Jres[0] + Hinv[i][1] * Jres[1] + Hinv[i][2] * Jres[2];
+    u += update[0]; v += update[1];
+    cur_px_estimate[0] = u; cur_px_estimate[1] = v;
+    mean_diff += update[2];
+    if (update[0] * update[0] + update[1] * update[1] < min_update_squared) { converged = 1; ++iter; break; }
+  }
+  *iters = iter;
+  cur_px_estimate[0] = u; cur_px_estimate[1] = v;
+  return converged;
+}
+
+/* feature_alignment::align1D (feature_alignment.cpp:41-157) */
+static int align_1d(const uint8_t* cur_img, int cols, int rows, int cur_step, const float dir[2],
+                    const uint8_t* ref_patch_with_border, const uint8_t* ref_patch, int n_iter,
+                    double cur_px_estimate[2], int* iters) {
+  int converged = 0;
+  float ref_patch_dv[M_AREA];
+  float H[2][2] = { { 0 } };
+  const int ref_step = M_STEP;
+  float* it_dv = ref_patch_dv;
+  for (int y = 0; y < M_PATCH; ++y) {
+    const uint8_t* it = ref_patch_with_border + (y + 1) * ref_step + 1;
+    for (int x = 0; x < M_PATCH; ++x, ++it, ++it_dv) {
+      float J[2];
+      J[0] = (float)(0.5 * (dir[0] * (it[1] - it[-1]) + dir[1] * (it[ref_step] - it[-ref_step])));
+      J[1] = 1;
+      *it_dv = J[0];
+      for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) H[i][j] += J[i] * J[j];
+    }
+  }
+  float Hinv[2][2];
+  {
+    const float det = H[0][0] * H[1][1] - H[1][0] * H[0][1];
+    const float invdet = 1.0f / det;                  /* [ext] Eigen compute_inverse_size2_helper */
+    Hinv[0][0] = H[1][1] * invdet; Hinv[1][0] = -H[1][0] * invdet;
+    Hinv[0][1] = -H[0][1] * invdet; Hinv[1][1] = H[0][0] * invdet;
+  }
+  float mean_diff = 0;
+  float u = (float)cur_px_estimate[0], v = (float)cur_px_estimate[1];
+  const float min_update_squared = (float)(0.03 * 0.03);
+  float chi2 = 0;
+  float update[2] = { 0, 0 };
+  int iter = 0;
+  for (; iter < n_iter; ++iter) {
+    const int u_r = f2i_trunc(floorf(u)), v_r = f2i_trunc(floorf(v));
+    if (u_r < M_HALF || v_r < M_HALF || u_r >= cols - M_HALF || v_r >= rows - M_HALF) break;
+    if (isnan(u) || isnan(v)) { *iters = iter; return 0; }   /* :92-93 returns without writing cur_px_estimate */
+    const float subpix_x = u - u_r, subpix_y = v - v_r;
+    const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
+    const float wTR = (float)(subpix_x * (1.0 - subpix_y));
+    const float wBL = (float)((1.0 - subpix_x) * subpix_y);
+    const float wBR = subpix_x * subpix_y;
+    const uint8_t* it_ref = ref_patch;
+    const float* it_ref_dv = ref_patch_dv;
+    float new_chi2 = 0.0f;
+    float Jres[2] = { 0, 0 };
+    for (int y = 0; y < M_PATCH; ++y) {
+      const uint8_t* it = cur_img + (ptrdiff_t)(v_r + y - M_HALF) * cur_step + u_r - M_HALF;
+      for (int x = 0; x < M_PATCH; ++x, ++it, ++it_ref, ++it_ref_dv) {
+        const float search_pixel = wTL * it[0] + wTR * it[1] + wBL * it[cur_step] + wBR * it[cur_step + 1];
+        const float res = search_pixel - *it_ref + mean_diff;
+        Jres[0] -= res * (*it_ref_dv);
+        Jres[1] -= res;
+        new_chi2 += res * res;
+      }
+    }
+    if (iter > 0 && new_chi2 > chi2) { u -= update[0]; v -= update[1]; ++iter; break; }   /* :126-134, as written */
+    chi2 = new_chi2;
+    update[0] = Hinv[0][0] * Jres[0] + Hinv[0][1] * Jres[1];
+    update[1] = Hinv[1][0] * Jres[0] + Hinv[1][1] * Jres[1];
+    u += update[0] * dir[0];
+    v += update[0] * dir[1];
+    mean_diff += update[1];
+    if (update[0] * update[0] + update[1] * update[1] < min_update_squared) { converged = 1; ++iter; break; }
+  }
+  *iters = iter;
+  cur_px_estimate[0] = u; cur_px_estimate[1] = v;
+  return converged;
+}
+
+/* Matcher::findMatchDirect for one candidate: a point (matcher.cpp:157-208) or one end point of a line
+ * segment (:210-231 + :258-277).  The closest-view observation has been chosen by the caller (:163, :240). */
+int plsvo_oracle_match_direct(const plsvo_match_in* in, const plsvo_oracle_pyr* frames, plsvo_match_out* out) {
+  if (!in || !out || in->n < 0 || in->n_frames <= 0 || !frames) return PLSVO_E_INVALID;
+  const int halfpatch_size_ = 4;
+  for (int i = 0; i < in->n; ++i) {
+    const int rf = in->ref_frame[i], cf = in->cur_frame[i], level = in->ref_level[i];
+    double px_cur[2] = { in->px_cur[2 * i], in->px_cur[2 * i + 1] };
+    int found = 0, search_level = -1, iters = 0;
+    const double* rpx = in->ref_px + 2 * i;
+    /* :166-168  px.cast<int>() / (1<<level): truncation, then integer division */
+    if (cam_is_in_frame(&in->cam, (int)rpx[0] / (1 << level), (int)rpx[1] / (1 << level), halfpatch_size_ + 2, level)) {
+      const se3_t T_ref = se3_load(in->frame_T + 7 * rf), T_cur = se3_load(in->frame_T + 7 * cf);
+      const se3_t T_ref_inv = se3_inv(&T_ref);
+      const se3_t T_cur_ref = se3_mul(&T_cur, &T_ref_inv);
+      /* Frame::pos() = T_f_w_.inverse().translation() (frame.h:106); depth = |pos_ref - pos| */
+      const double d[3] = { T_ref_inv.t[0] - in->pos[3 * i], T_ref_inv.t[1] - in->pos[3 * i + 1], T_ref_inv.t[2] - in->pos[3 * i + 2] };
+      const double depth_ref = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+      double A[4];
+      warp_matrix_affine(&in->cam, rpx, in->ref_f + 3 * i, depth_ref, &T_cur_ref, level, A);
+      search_level = best_search_level(A, in->n_pyr_levels - 1);
+      uint8_t patch_with_border[M_STEP * M_STEP], patch[M_AREA];
+      const plsvo_oracle_pyr* rp = &frames[rf];
+      const plsvo_oracle_pyr* cp = &frames[cf];
+      if (warp_affine(A, rp->img[level], rp->width[level], rp->height[level], rp->stride[level], rpx, level, search_level,
+                      halfpatch_size_ + 1, patch_with_border)) {
+        for (int y = 1; y < M_PATCH + 1; ++y)          /* createPatchFromPatchWithBorder :146-155 */
+          for (int x = 0; x < M_PATCH; ++x) patch[(y - 1) * M_PATCH + x] = patch_with_border[y * M_STEP + 1 + x];
+        double px_scaled[2] = { px_cur[0] / (1 << search_level), px_cur[1] / (1 << search_level) };
+        if (in->ref_type[i] == PLSVO_FTR_EDGELET) {
+          double dc[2] = { A[0] * in->ref_grad[2 * i] + A[1] * in->ref_grad[2 * i + 1], A[2] * in->ref_grad[2 * i] + A[3] * in->ref_grad[2 * i + 1] };
+          const double nrm = sqrt(dc[0] * dc[0] + dc[1] * dc[1]);
+          dc[0] /= nrm; dc[1] /= nrm;
+          const float dir[2] = { (float)dc[0], (float)dc[1] };
+          found = align_1d(cp->img[search_level], cp->width[search_level], cp->height[search_level], cp->stride[search_level], dir,
+                           patch_with_border, patch, in->align_max_iter, px_scaled, &iters);
+        } else {
+          found = align_2d(cp->img[search_level], cp->width[search_level], cp->height[search_level], cp->stride[search_level],
+                           patch_with_border, patch, in->align_max_iter, px_scaled, &iters);
+        }
+        px_cur[0] = px_scaled[0] * (1 << search_level); px_cur[1] = px_scaled[1] * (1 << search_level);
+      }
+    }
+    if (out->px_cur) { out->px_cur[2 * i] = px_cur[0]; out->px_cur[2 * i + 1] = px_cur[1]; }
+    if (out->found) out->found[i] = (uint8_t)found;
+    if (out->search_level) out->search_level[i] = search_level;
+    if (out->n_iter) out->n_iter[i] = iters;
+  }
+  return PLSVO_OK;
 }

@@ -39,3 +39,8 @@ def poseopt_job_from_frame(fr, reproj_thresh=2.0, n_iter=10, n_iter_ref=-1):
 def structopt_job_from_batch(d, n_iter_pts=5, n_iter_segs=5):
     return abi.StructOptJob(d["frame_T"], d["pt_pos"], d["pt_obs_off"], d["pt_obs_frame"], d["pt_obs_f"], d["seg_spos"], d["seg_epos"],
                             d["seg_obs_off"], d["seg_obs_frame"], d["seg_obs_sf"], d["seg_obs_ef"], n_iter_pts, n_iter_segs)
+
+
+def match_job_from_batch(d, n_pyr_levels=3, align_max_iter=10):
+    return abi.MatchJob(d["cam"], d["frame_T"], d["frame_slot"], d["cur_frame"], d["ref_frame"], d["ref_px"], d["ref_f"],
+                        d["ref_level"], d["ref_type"], d["ref_grad"], d["pos"], d["px_cur"], n_pyr_levels, align_max_iter)

@@ -18,7 +18,8 @@ c_i32_p = C.POINTER(C.c_int32)
 OK, E_INVALID, E_NODEVICE, E_HIP, E_CAPACITY, E_STATE, E_RCCL = 0, -1, -2, -3, -4, -5, -6
 
 # kernel families for plsvo_hip_kernel_time
-K_ALIGN_INIT, K_ALIGN_LEVEL, K_POSEOPT, K_HALFSAMPLE, K_STRUCTOPT, K_COUNT = 0, 1, 2, 3, 4, 5
+K_ALIGN_INIT, K_ALIGN_LEVEL, K_POSEOPT, K_HALFSAMPLE, K_STRUCTOPT, K_MATCH, K_COUNT = 0, 1, 2, 3, 4, 5, 6
+FTR_CORNER, FTR_EDGELET = 0, 1
 
 
 class Pinhole(C.Structure):
@@ -80,6 +81,17 @@ class StructOptIn(C.Structure):
 class StructOptOut(C.Structure):
     _fields_ = [("pt_pos", c_double_p), ("seg_spos", c_double_p), ("seg_epos", c_double_p), ("pt_iters", c_i32_p),
                 ("seg_iters", c_i32_p)]
+
+
+class MatchIn(C.Structure):
+    _fields_ = [("cam", Pinhole), ("n_pyr_levels", C.c_int32), ("align_max_iter", C.c_int32), ("n_frames", C.c_int32),
+                ("n", C.c_int32), ("frame_T", c_double_p), ("frame_slot", c_i32_p), ("cur_frame", c_i32_p),
+                ("ref_frame", c_i32_p), ("ref_px", c_double_p), ("ref_f", c_double_p), ("ref_level", c_i32_p),
+                ("ref_type", c_u8_p), ("ref_grad", c_double_p), ("pos", c_double_p), ("px_cur", c_double_p)]
+
+
+class MatchOut(C.Structure):
+    _fields_ = [("px_cur", c_double_p), ("found", c_u8_p), ("search_level", c_i32_p), ("n_iter", c_i32_p)]
 
 
 def _f64(a, n=None):
@@ -232,3 +244,42 @@ class StructOptJob:
         return dict(pt_pos=bufs["pt_pos"][:self.n_pts].copy(), seg_spos=bufs["seg_spos"][:self.n_seg].copy(),
                     seg_epos=bufs["seg_epos"][:self.n_seg].copy(), pt_iters=bufs["pt_iters"][:self.n_pts].copy(),
                     seg_iters=bufs["seg_iters"][:self.n_seg].copy())
+
+
+class MatchJob:
+    """A batch of candidates for plsvo_match_direct; owns the numpy buffers and the output arrays."""
+
+    def __init__(self, cam, frame_T, frame_slot, cur_frame, ref_frame, ref_px, ref_f, ref_level, ref_type, ref_grad, pos,
+                 px_cur, n_pyr_levels=3, align_max_iter=10):
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32).reshape(-1)
+        self.frame_T = _f64(frame_T).reshape(-1, 7)
+        self.frame_slot = i32(frame_slot)
+        self.ref_px = _f64(ref_px).reshape(-1, 2)
+        n = self.n = self.ref_px.shape[0]
+        self.cur_frame, self.ref_frame, self.ref_level = i32(cur_frame), i32(ref_frame), i32(ref_level)
+        self.ref_f = _f64(ref_f, 3 * n).reshape(-1, 3)
+        self.ref_type = np.ascontiguousarray(ref_type, dtype=np.uint8).reshape(-1)
+        self.ref_grad = _f64(ref_grad, 2 * n).reshape(-1, 2)
+        self.pos = _f64(pos, 3 * n).reshape(-1, 3)
+        self.px_cur = _f64(px_cur, 2 * n).reshape(-1, 2)
+        c = MatchIn()
+        c.cam = cam if isinstance(cam, Pinhole) else Pinhole(*cam)
+        c.n_pyr_levels, c.align_max_iter, c.n_frames, c.n = n_pyr_levels, align_max_iter, self.frame_T.shape[0], n
+        c.frame_T, c.frame_slot = _ptr(self.frame_T, c_double_p), _ptr(self.frame_slot, c_i32_p)
+        c.cur_frame, c.ref_frame = _ptr(self.cur_frame, c_i32_p), _ptr(self.ref_frame, c_i32_p)
+        c.ref_px, c.ref_f = _ptr(self.ref_px, c_double_p), _ptr(self.ref_f, c_double_p)
+        c.ref_level, c.ref_type = _ptr(self.ref_level, c_i32_p), _ptr(self.ref_type, c_u8_p)
+        c.ref_grad, c.pos, c.px_cur = _ptr(self.ref_grad, c_double_p), _ptr(self.pos, c_double_p), _ptr(self.px_cur, c_double_p)
+        self.c = c
+
+    def make_out(self):
+        o = MatchOut()
+        m = max(self.n, 1)
+        bufs = dict(px_cur=np.zeros((m, 2)), found=np.zeros(m, np.uint8), search_level=np.zeros(m, np.int32),
+                    n_iter=np.zeros(m, np.int32))
+        o.px_cur, o.found = bufs["px_cur"].ctypes.data_as(c_double_p), bufs["found"].ctypes.data_as(c_u8_p)
+        o.search_level, o.n_iter = bufs["search_level"].ctypes.data_as(c_i32_p), bufs["n_iter"].ctypes.data_as(c_i32_p)
+        return o, bufs
+
+    def trim(self, bufs):
+        return {k: v[:self.n].copy() for k, v in bufs.items()}

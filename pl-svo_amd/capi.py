@@ -22,7 +22,7 @@ SYMBOLS = [
     "plsvo_align_set_trace", "plsvo_align_fetch_trace", "plsvo_align_poses_dev", "plsvo_align_copy_poses", "plsvo_align_work",
     "plsvo_pose_optimize", "plsvo_pose_optimize_batch", "plsvo_poseopt_stage", "plsvo_poseopt_run", "plsvo_poseopt_fetch",
     "plsvo_poseopt_set_trace", "plsvo_poseopt_fetch_trace", "plsvo_poseopt_poses_dev", "plsvo_poseopt_copy_poses", "plsvo_poseopt_work",
-    "plsvo_structure_optimize",
+    "plsvo_structure_optimize", "plsvo_match_direct",
     "plsvo_gather_poses",
     "plsvo_hip_set_profiling", "plsvo_hip_kernel_time", "plsvo_hip_reset_profiling",
     "plsvo_hip_version", "plsvo_hip_device_info",
@@ -81,6 +81,7 @@ def lib():
         "plsvo_poseopt_poses_dev": (vp, [ctxp]),
         "plsvo_poseopt_work": (C.c_int, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "plsvo_structure_optimize": (C.c_int, [ctxp, C.POINTER(abi.StructOptIn), C.POINTER(abi.StructOptOut)]),
+        "plsvo_match_direct": (C.c_int, [ctxp, C.POINTER(abi.MatchIn), C.POINTER(abi.MatchOut)]),
         "plsvo_gather_poses": (C.c_int, [ctxp, vp, vp, C.c_int, vp]),
         "plsvo_hip_set_profiling": (C.c_int, [ctxp, C.c_int]),
         "plsvo_hip_kernel_time": (C.c_int, [ctxp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -287,6 +288,12 @@ class Context:
     def structure_optimize(self, job):
         out, bufs = job.make_out()
         self._chk(self.L.plsvo_structure_optimize(self.h, C.byref(job.c), C.byref(out)))
+        return job.trim(bufs)
+
+    # ---- direct feature matching ----
+    def match_direct(self, job):
+        out, bufs = job.make_out()
+        self._chk(self.L.plsvo_match_direct(self.h, C.byref(job.c), C.byref(out)))
         return job.trim(bufs)
 
     def gather_poses(self, rccl_comm, d_local, n_local, d_all):

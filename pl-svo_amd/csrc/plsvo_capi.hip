@@ -25,6 +25,7 @@ hipError_t launch_align_finish(const AlignBatchDev& b, double* d_poses, hipStrea
 hipError_t launch_pose_opt(const PoseBatchDev& b, hipStream_t stream);
 hipError_t launch_pose_finish(const PoseBatchDev& b, double* d_poses, hipStream_t stream);
 hipError_t launch_structopt(const StructBatchDev& s, hipStream_t stream);
+hipError_t launch_match_direct(const MatchBatchDev& b, hipStream_t stream);
 hipError_t launch_halfsample(const uint8_t* src, size_t src_pitch, int in_w, int in_h, int in_stride, uint8_t* dst,
                              size_t dst_pitch, int n_slots, int rounding, hipStream_t stream);
 hipError_t launch_copy_level0(const uint8_t* src, size_t src_pitch, int w, int h, int stride, uint8_t* dst, size_t dst_pitch,
@@ -791,6 +792,73 @@ extern "C" int plsvo_structure_optimize(plsvo_ctx* c, const plsvo_structopt_in* 
   if (out->seg_epos && ns) memcpy(out->seg_epos, hd.data() + (size_t)(np + ns) * 3, (size_t)ns * 3 * sizeof(double));
   if (out->pt_iters && np) memcpy(out->pt_iters, hi.data(), (size_t)np * sizeof(int));
   if (out->seg_iters && ns) memcpy(out->seg_iters, hi.data() + np, (size_t)ns * sizeof(int));
+  return PLSVO_OK;
+}
+
+// ---- direct feature matching -------------------------------------------------------------------------
+extern "C" int plsvo_match_direct(plsvo_ctx* c, const plsvo_match_in* in, plsvo_match_out* out) {
+  CTX_CHECK(c);
+  if (!in || !out || in->n < 0 || in->n_frames < 0 || in->n_pyr_levels < 1 || in->align_max_iter < 0)
+    return fail(c, PLSVO_E_INVALID, "match_direct: bad arguments");
+  const int n = in->n, nf = in->n_frames;
+  if (n == 0) return PLSVO_OK;
+  if (!c->pyr.base) return fail(c, PLSVO_E_STATE, "match_direct: pyramids not configured");
+  if (nf <= 0 || !in->frame_T || !in->frame_slot || !in->cur_frame || !in->ref_frame || !in->ref_px || !in->ref_f || !in->ref_level ||
+      !in->ref_type || !in->pos || !in->px_cur)
+    return fail(c, PLSVO_E_INVALID, "match_direct: null input array");
+  if (in->n_pyr_levels > c->pyr.n_levels) return fail(c, PLSVO_E_INVALID, "match_direct: n_pyr_levels exceeds the configured pyramid");
+  if (in->cam.width != c->pyr.w[0] || in->cam.height != c->pyr.h[0]) return fail(c, PLSVO_E_INVALID, "match_direct: camera size does not match the configured pyramid");
+  for (int k = 0; k < nf; ++k) if (in->frame_slot[k] < 0 || in->frame_slot[k] >= c->pyr.n_slots) return fail(c, PLSVO_E_CAPACITY, "match_direct: pyramid slot out of range");
+  bool any_edgelet = false;
+  for (int i = 0; i < n; ++i) {
+    if (in->cur_frame[i] < 0 || in->cur_frame[i] >= nf || in->ref_frame[i] < 0 || in->ref_frame[i] >= nf) return fail(c, PLSVO_E_INVALID, "match_direct: frame index out of range");
+    if (in->ref_level[i] < 0 || in->ref_level[i] >= c->pyr.n_levels) return fail(c, PLSVO_E_INVALID, "match_direct: ref_level outside the configured pyramid");
+    if (in->ref_type[i] == PLSVO_FTR_EDGELET) any_edgelet = true;
+    else if (in->ref_type[i] != PLSVO_FTR_CORNER) return fail(c, PLSVO_E_INVALID, "match_direct: unknown feature type");
+  }
+  if (any_edgelet && !in->ref_grad) return fail(c, PLSVO_E_INVALID, "match_direct: edgelets without ref_grad");
+  HIP_TRY(c, hipSetDevice(c->device));
+  // one packed upload: doubles, then ints, then bytes
+  std::vector<double> d;
+  auto putd = [&](const double* p, size_t k) { const size_t o = d.size(); if (p) d.insert(d.end(), p, p + k); else d.resize(d.size() + k, 0.0); return o; };
+  const size_t o_T = putd(in->frame_T, (size_t)nf * 7), o_px = putd(in->ref_px, (size_t)n * 2), o_f = putd(in->ref_f, (size_t)n * 3);
+  const size_t o_g = putd(in->ref_grad, (size_t)n * 2), o_pos = putd(in->pos, (size_t)n * 3), o_pc = putd(in->px_cur, (size_t)n * 2);
+  std::vector<int> iv;
+  auto puti = [&](const int32_t* p, size_t k) { const size_t o = iv.size(); iv.insert(iv.end(), p, p + k); return o; };
+  const size_t o_slot = puti(in->frame_slot, (size_t)nf), o_cf = puti(in->cur_frame, (size_t)n), o_rf = puti(in->ref_frame, (size_t)n), o_lv = puti(in->ref_level, (size_t)n);
+  const size_t dbytes = d.size() * sizeof(double), ibytes = ((iv.size() * sizeof(int) + 15) / 16) * 16, bbytes = (size_t)n;
+  HIP_TRY(c, c->s_d_in.ensure(dbytes + ibytes + bbytes + 16));
+  char* din = reinterpret_cast<char*>(c->s_d_in.p);
+  HIP_TRY(c, hipMemcpyAsync(din, d.data(), dbytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(din + dbytes, iv.data(), iv.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(din + dbytes + ibytes, in->ref_type, bbytes, hipMemcpyHostToDevice, c->stream));
+  const size_t out_d = (size_t)n * 2 * sizeof(double), out_i = (size_t)n * 2 * sizeof(int), out_b = (size_t)n;
+  HIP_TRY(c, c->s_d_out.ensure(out_d + out_i + out_b + 16));
+  char* dout = reinterpret_cast<char*>(c->s_d_out.p);
+  const double* dd = reinterpret_cast<const double*>(din);
+  const int* di = reinterpret_cast<const int*>(din + dbytes);
+  MatchBatchDev b{};
+  b.pyr_base = c->pyr.base; b.slot_bytes = c->pyr.slot_bytes; b.width = c->pyr.w[0]; b.height = c->pyr.h[0];
+  b.fx = in->cam.fx; b.fy = in->cam.fy; b.cx = in->cam.cx; b.cy = in->cam.cy; b.cam_width = in->cam.width; b.cam_height = in->cam.height;
+  b.n = n; b.n_pyr_levels = in->n_pyr_levels; b.align_max_iter = in->align_max_iter;
+  b.frame_T = dd + o_T; b.ref_px = dd + o_px; b.ref_f = dd + o_f; b.ref_grad = dd + o_g; b.pos = dd + o_pos; b.px_cur = dd + o_pc;
+  b.frame_slot = di + o_slot; b.cur_frame = di + o_cf; b.ref_frame = di + o_rf; b.ref_level = di + o_lv;
+  b.ref_type = reinterpret_cast<const uint8_t*>(din + dbytes + ibytes);
+  b.px_out = reinterpret_cast<double*>(dout);
+  b.search_level = reinterpret_cast<int*>(dout + out_d); b.n_iter = b.search_level + n;
+  b.found = reinterpret_cast<uint8_t*>(dout + out_d + out_i);
+  {
+    EventPair ep{}; prof_begin(c, PLSVO_K_MATCH, &ep);
+    HIP_TRY(c, launch_match_direct(b, c->stream));
+    prof_end(c, PLSVO_K_MATCH, &ep);
+  }
+  std::vector<char> h(out_d + out_i + out_b);
+  HIP_TRY(c, hipMemcpyAsync(h.data(), dout, h.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (out->px_cur) memcpy(out->px_cur, h.data(), out_d);
+  if (out->search_level) memcpy(out->search_level, h.data() + out_d, (size_t)n * sizeof(int));
+  if (out->n_iter) memcpy(out->n_iter, h.data() + out_d + (size_t)n * sizeof(int), (size_t)n * sizeof(int));
+  if (out->found) memcpy(out->found, h.data() + out_d + out_i, out_b);
   return PLSVO_OK;
 }
 

@@ -129,4 +129,16 @@ struct StructBatchDev {
   int n_pts, n_seg, n_iter_pts, n_iter_segs;
 };
 
+// direct feature matching: flat candidate arrays (include/plsvo_hip.h plsvo_match_in), one lane per candidate
+struct MatchBatchDev {
+  const uint8_t* pyr_base; unsigned long long slot_bytes;
+  int width, height;                // level-0 size of every pyramid slot
+  double fx, fy, cx, cy; int cam_width, cam_height;
+  int n, n_pyr_levels, align_max_iter;
+  const double* frame_T; const int* frame_slot; const int* cur_frame; const int* ref_frame;
+  const double* ref_px; const double* ref_f; const int* ref_level; const uint8_t* ref_type; const double* ref_grad;
+  const double* pos; const double* px_cur;
+  double* px_out; uint8_t* found; int* search_level; int* n_iter;
+};
+
 }  // namespace plsvo_hip

@@ -355,3 +355,42 @@ def make_structure_batch(seed, n_pts=20, n_seg=20, n_frames=6, W=640, H=480, noi
                 seg_epos=e_true + rng.normal(0, pert, e_true.shape), seg_obs_off=np.array(sg_off, np.int32),
                 seg_obs_frame=np.array(sg_fr, np.int32), seg_obs_sf=np.array(sg_sf).reshape(-1, 3) if sg_sf else z3,
                 seg_obs_ef=np.array(sg_ef).reshape(-1, 3) if sg_ef else z3)
+
+
+# ------------------------------------------------------------------------------------------------
+# direct feature matching: candidates of one (keyframe, current frame) pair
+# ------------------------------------------------------------------------------------------------
+
+def make_match_batch(seed, W=640, H=480, n_pts=120, n_seg=40, zoom=0.0, motion_scale=2.0, edgelet_frac=0.25, px_noise=1.5,
+                     levels=(0, 1, 2, 3), level_p=(0.5, 0.3, 0.15, 0.05)):
+    """A keyframe (frame 0) and a current frame (frame 1) looking at the textured plane of make_align_stream, plus the
+    match candidates Reprojector would hand to Matcher::findMatchDirect: every landmark's closest-view observation is
+    the keyframe's, its initial px_cur is the true projection displaced by up to `px_noise` pixels.  `zoom` moves the
+    current camera that fraction of the scene depth towards the plane (det(A_cur_ref) > 3 selects search level 1 from
+    zoom ~ 0.43).  Returns (stream, dict of plsvo_match_in arrays); render the two images with render_streams([stream]).
+    Candidate order: points, segment start points, segment end points."""
+    st = make_align_stream(seed, W, H, n_pts, n_seg, 3, motion_scale)
+    rng = np.random.default_rng(seed + 700000)
+    if zoom != 0.0:
+        d0 = st.plane_d / st.plane_n[2]
+        xi = np.concatenate([rng.uniform(-0.02, 0.02, 2) * d0, [-zoom * d0], rng.uniform(-0.01, 0.01, 3)])
+        # cur_from_ref: a camera moved forward by z sees the scene shifted by -z ... sign chosen so that depth shrinks
+        st.T_true = se3_exp(xi)
+    T_cur_w = se3_mul(st.T_true, st.T_ref_w)
+    fx, fy, cx, cy = st.cam[:4]
+    ref_px = np.concatenate([st.pt_px, st.seg_spx, st.seg_epx])
+    ref_f = np.concatenate([st.pt_f, st.seg_sf, st.seg_ef])
+    pos = np.concatenate([st.pt_pos_w, st.seg_spos_w, st.seg_epos_w])
+    n = ref_px.shape[0]
+    p_cur = se3_act(T_cur_w, pos)
+    px_true = np.stack([fx * p_cur[:, 0] / p_cur[:, 2] + cx, fy * p_cur[:, 1] / p_cur[:, 2] + cy], axis=1)
+    px_cur = px_true + rng.uniform(-px_noise, px_noise, (n, 2))
+    ref_level = rng.choice(np.asarray(levels), size=n, p=np.asarray(level_p)).astype(np.int32)
+    ref_type = np.zeros(n, np.uint8)
+    ref_type[:n_pts] = (rng.uniform(size=n_pts) < edgelet_frac).astype(np.uint8)
+    ga = rng.uniform(0.0, 2 * math.pi, n)
+    ref_grad = np.stack([np.cos(ga), np.sin(ga)], axis=1)
+    d = dict(cam=st.cam, frame_T=np.stack([st.T_ref_w, T_cur_w]), frame_slot=np.array([0, 1], np.int32),
+             cur_frame=np.ones(n, np.int32), ref_frame=np.zeros(n, np.int32), ref_px=ref_px, ref_f=ref_f, ref_level=ref_level,
+             ref_type=ref_type, ref_grad=ref_grad, pos=pos, px_cur=px_cur, px_true=px_true, n_pts=n_pts, n_seg=n_seg)
+    return st, d
