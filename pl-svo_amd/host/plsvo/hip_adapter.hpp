@@ -74,7 +74,24 @@ struct mat66_traits {  // default: Eigen-like operator()(row, col)
 struct Context {
   plsvo_ctx* ctx = nullptr;
   int width = 0, height = 0, levels = 0;
+  // pyramid slots: 0/1 belong to SparseImgAlign::run (ref/cur); slots 2.. cache the pyramids of the frames the
+  // direct matcher reads (keyframes are immutable once created, so (address, id_) identifies the pixels)
+  struct CachedFrame { const void* frame; long id; unsigned long stamp; };
+  std::vector<CachedFrame> cache;
+  unsigned long clock = 0;
   ~Context() { if (ctx) plsvo_hip_destroy(ctx); }
+  static int cache_slots() { const char* e = std::getenv("PLSVO_KF_SLOTS"); const int n = e ? std::atoi(e) : 16; return n > 1 ? n : 2; }
+  /// slot holding `frame`'s pyramid, or -1 on a miss; on a miss *victim gets the least recently used slot not stamped
+  /// in the current batch (or -1 when every slot is in use by this batch)
+  int lookup(const void* frame, long id, unsigned long batch_start, int* victim) {
+    int lru = -1;
+    for (size_t k = 0; k < cache.size(); ++k) {
+      if (cache[k].frame == frame && cache[k].id == id) { cache[k].stamp = ++clock; return 2 + (int)k; }
+      if (cache[k].stamp < batch_start && (lru < 0 || cache[k].stamp < cache[(size_t)lru].stamp)) lru = (int)k;
+    }
+    *victim = lru;
+    return -1;
+  }
   bool ensure(int w, int h, int n_levels) {
     if (!ctx) {
       const char* dev = std::getenv("PLSVO_DEVICE");
@@ -84,12 +101,14 @@ struct Context {
         return false;
       }
     }
-    if (w != width || h != height || n_levels != levels) {
-      if (plsvo_hip_config_pyramids(ctx, 2, w, h, n_levels) != PLSVO_OK) {
+    if (w != width || h != height || n_levels > levels) {   // n_levels is a minimum: fewer levels never reconfigure
+      const int n_cache = cache_slots();
+      if (plsvo_hip_config_pyramids(ctx, 2 + n_cache, w, h, n_levels) != PLSVO_OK) {
         std::fprintf(stderr, "[plsvo_hip] %s\n", plsvo_hip_last_error(ctx));
         return false;
       }
       width = w; height = h; levels = n_levels;
+      cache.assign((size_t)n_cache, CachedFrame{nullptr, 0, 0ul});   // reconfiguring drops the slab
     }
     return true;
   }
@@ -392,6 +411,151 @@ bool optimize(PointIt pts_begin, PointIt pts_end, size_t n_iter, SegIt segs_begi
 }
 
 }  // namespace structure_optimizer
+}  // namespace plsvo
+
+namespace plsvo {
+
+/// Batched replacement of Matcher::findMatchDirect (include/plsvo/matcher.h:120-131, src/matcher.cpp:157-280), the
+/// call Reprojector::refineBestCandidate makes once per candidate (src/reprojector.cpp:288, :348):
+///
+///     DirectMatcher m(Config::nPyrLevels());                       // options_.align_max_iter = 10
+///     for every candidate:   if (pt->getCloseViewObs(frame->pos(), ref_ftr))  h = m.addPoint(pt->pos_, ref_ftr, *frame, px_est);
+///                            ... m.addSegment(ls->spos_, ls->epos_, ref_ftr, *frame, spx_est, epx_est);
+///     m.run();                                                     // ONE kernel launch for all of them
+///     for every candidate, in the original order:  if (m.found(h)) { m.px(h, px_est); ... }
+///
+/// The closest-view choice (Point::getCloseViewObs, map logic) and the per-cell "first success wins" bookkeeping stay
+/// with the caller: evaluating every queued candidate and then walking them in the reference's order gives the
+/// reference's result, because candidates do not influence one another.  Reads, duck-typed: Feature::frame / px / f /
+/// level, PointFeat::type / grad, LineFeat::spx / epx / sf / ef, Frame::T_f_w_ / cam_ / img_pyr_ / id_.
+class DirectMatcher {
+ public:
+  explicit DirectMatcher(int n_pyr_levels, int align_max_iter = 10) : n_pyr_levels_(n_pyr_levels), align_max_iter_(align_max_iter), ok_(true), batch_start_(0) {}
+
+  void clear() {
+    frames_.clear(); frame_T_.clear(); frame_slot_.clear(); cur_frame_.clear(); ref_frame_.clear(); ref_px_.clear(); ref_f_.clear();
+    ref_level_.clear(); ref_type_.clear(); ref_grad_.clear(); pos_.clear(); px_cur_.clear(); items_.clear(); out_px_.clear(); out_found_.clear();
+    out_level_.clear(); ok_ = true; batch_start_ = 0;
+  }
+
+  /// queue findMatchDirect(pt, cur_frame, px_cur); ref_ftr is what pt.getCloseViewObs(cur_frame.pos(), ref_ftr) returned
+  template <class Pos, class PointFeatT, class FrameT, class Px>
+  int addPoint(const Pos& pos, const PointFeatT* ref_ftr, const FrameT& cur_frame, const Px& px_cur) {
+    const int cf = frame_index(&cur_frame), rf = frame_index(ref_ftr->frame);
+    const bool edgelet = (int)ref_ftr->type == (int)PointFeatT::EDGELET;
+    push(cf, rf, ref_ftr->px, ref_ftr->f, ref_ftr->level, edgelet ? PLSVO_FTR_EDGELET : PLSVO_FTR_CORNER, ref_ftr->grad[0], ref_ftr->grad[1], pos, px_cur);
+    items_.push_back(Item{(int)ref_level_.size() - 1, 1});
+    return (int)items_.size() - 1;
+  }
+  /// queue findMatchDirect(ls, cur_frame, spx_cur, epx_cur)
+  template <class Pos, class LineFeatT, class FrameT, class Px>
+  int addSegment(const Pos& spos, const Pos& epos, const LineFeatT* ref_ftr, const FrameT& cur_frame, const Px& spx_cur, const Px& epx_cur) {
+    const int cf = frame_index(&cur_frame), rf = frame_index(ref_ftr->frame);
+    push(cf, rf, ref_ftr->spx, ref_ftr->sf, ref_ftr->level, PLSVO_FTR_CORNER, 0.0, 0.0, spos, spx_cur);
+    push(cf, rf, ref_ftr->epx, ref_ftr->ef, ref_ftr->level, PLSVO_FTR_CORNER, 0.0, 0.0, epos, epx_cur);
+    items_.push_back(Item{(int)ref_level_.size() - 2, 2});
+    return (int)items_.size() - 1;
+  }
+
+  /// one launch over everything queued; false (and found() == false everywhere) when the device path failed
+  bool run() {
+    using namespace plsvo_hip_adapter;
+    const size_t n = ref_level_.size();
+    out_px_.assign(px_cur_.begin(), px_cur_.end()); out_found_.assign(n ? n : 1, 0); out_level_.assign(n ? n : 1, -1);
+    if (n == 0) return true;
+    if (!ok_) return false;
+    plsvo_match_in in;
+    in.cam = cam_; in.n_pyr_levels = n_pyr_levels_; in.align_max_iter = align_max_iter_;
+    in.n_frames = (int32_t)frames_.size(); in.n = (int32_t)n;
+    in.frame_T = frame_T_.data(); in.frame_slot = frame_slot_.data(); in.cur_frame = cur_frame_.data(); in.ref_frame = ref_frame_.data();
+    in.ref_px = ref_px_.data(); in.ref_f = ref_f_.data(); in.ref_level = ref_level_.data(); in.ref_type = ref_type_.data();
+    in.ref_grad = ref_grad_.data(); in.pos = pos_.data(); in.px_cur = px_cur_.data();
+    plsvo_match_out out;
+    out.px_cur = out_px_.data(); out.found = out_found_.data(); out.search_level = out_level_.data(); out.n_iter = nullptr;
+    Context& c = default_context();
+    if (plsvo_match_direct(c.ctx, &in, &out) != PLSVO_OK) {
+      std::fprintf(stderr, "[plsvo_hip] match_direct failed: %s\n", plsvo_hip_last_error(c.ctx));
+      out_px_.assign(px_cur_.begin(), px_cur_.end()); out_found_.assign(n, 0);
+      return false;
+    }
+    return true;
+  }
+
+  /// findMatchDirect's return value: a point's flag, or start & end for a segment (matcher.cpp:258-279)
+  bool found(int h) const {
+    const Item& it = items_[(size_t)h];
+    bool f = true;
+    for (int k = 0; k < it.n; ++k) f = f & (out_found_[(size_t)(it.first + k)] != 0);
+    return f;
+  }
+  /// refined position of a point candidate (px_cur on return from findMatchDirect)
+  template <class Px> void px(int h, Px& out) const { const size_t i = (size_t)items_[(size_t)h].first; out[0] = out_px_[2 * i]; out[1] = out_px_[2 * i + 1]; }
+  /// refined end points of a segment candidate (spx_cur / epx_cur)
+  template <class Px> void segment_px(int h, Px& spx, Px& epx) const {
+    const size_t i = (size_t)items_[(size_t)h].first;
+    spx[0] = out_px_[2 * i]; spx[1] = out_px_[2 * i + 1]; epx[0] = out_px_[2 * i + 2]; epx[1] = out_px_[2 * i + 3];
+  }
+  /// Matcher::search_level_ after the call (for a segment: of its end point, like the member the reference leaves behind)
+  int search_level(int h) const { const Item& it = items_[(size_t)h]; return out_level_[(size_t)(it.first + it.n - 1)]; }
+  size_t size() const { return items_.size(); }
+
+ private:
+  struct Item { int first, n; };
+
+  template <class FrameT>
+  int frame_index(const FrameT* fr) {
+    using namespace plsvo_hip_adapter;
+    for (size_t k = 0; k < frames_.size(); ++k) if (frames_[k] == (const void*)fr) return (int)k;
+    Context& c = default_context();
+    typedef typename std::remove_reference<decltype(*fr->cam_)>::type Cam;
+    const plsvo_pinhole cam = camera_traits<Cam>::get(*fr->cam_);
+    const int n_levels = (int)fr->img_pyr_.size();
+    if (frames_.empty()) cam_ = cam;
+    if (!c.ensure(cam.width, cam.height, n_levels)) ok_ = false;
+    int slot = 0;
+    if (ok_) {
+      if (batch_start_ == 0) batch_start_ = c.clock + 1;
+      int victim = -1;
+      slot = c.lookup((const void*)fr, (long)fr->id_, batch_start_, &victim);
+      if (slot < 0) {
+        if (victim < 0) {
+          std::fprintf(stderr, "[plsvo_hip] DirectMatcher: more than %d distinct frames in one batch (raise PLSVO_KF_SLOTS)\n", (int)c.cache.size());
+          ok_ = false; slot = 0;
+        } else {
+          slot = 2 + victim;
+          if (!upload_frame_pyramid(c, slot, *fr, n_levels)) { ok_ = false; c.cache[(size_t)victim] = Context::CachedFrame{nullptr, 0, 0ul}; }
+          else c.cache[(size_t)victim] = Context::CachedFrame{(const void*)fr, (long)fr->id_, ++c.clock};
+        }
+      }
+    }
+    frames_.push_back((const void*)fr);
+    double T[7];
+    typedef typename std::remove_cv<typename std::remove_reference<decltype(fr->T_f_w_)>::type>::type SE3T;
+    se3_traits<SE3T>::get(fr->T_f_w_, T);
+    frame_T_.insert(frame_T_.end(), T, T + 7);
+    frame_slot_.push_back(slot);
+    return (int)frames_.size() - 1;
+  }
+  template <class V2, class V3, class Pos, class Px>
+  void push(int cf, int rf, const V2& px, const V3& f, int level, uint8_t type, double g0, double g1, const Pos& pos, const Px& px_cur) {
+    cur_frame_.push_back(cf); ref_frame_.push_back(rf); ref_level_.push_back(level); ref_type_.push_back(type);
+    ref_px_.push_back(px[0]); ref_px_.push_back(px[1]);
+    for (int k = 0; k < 3; ++k) { ref_f_.push_back(f[k]); pos_.push_back(pos[k]); }
+    ref_grad_.push_back(g0); ref_grad_.push_back(g1);
+    px_cur_.push_back(px_cur[0]); px_cur_.push_back(px_cur[1]);
+  }
+
+  int n_pyr_levels_, align_max_iter_;
+  bool ok_;
+  unsigned long batch_start_;
+  plsvo_pinhole cam_;
+  std::vector<const void*> frames_;
+  std::vector<double> frame_T_, ref_px_, ref_f_, ref_grad_, pos_, px_cur_, out_px_;
+  std::vector<int32_t> frame_slot_, cur_frame_, ref_frame_, ref_level_, out_level_;
+  std::vector<uint8_t> ref_type_, out_found_;
+  std::vector<Item> items_;
+};
+
 }  // namespace plsvo
 
 namespace svo = plsvo;  // BASELINE.json spells the upstream name svo::SparseImgAlign

@@ -45,7 +45,7 @@ struct LineFeat;
 struct Point { Vec3 pos_; std::list<PointFeat*> obs_; };              // Feature3D<PointFeat>::obs_
 struct LineSeg { Vec3 spos_, epos_; std::list<LineFeat*> obs_; };     // Feature3D<LineFeat>::obs_
 struct Feature { Frame* frame = nullptr; Vec2 px; Vec3 f; int level = 0; };
-struct PointFeat : Feature { Point* feat3D = nullptr; };
+struct PointFeat : Feature { enum FeatureType { CORNER, EDGELET }; FeatureType type = CORNER; Vec2 grad; Point* feat3D = nullptr; };
 struct LineFeat : Feature { Vec2 spx, epx; Vec3 sf, ef, line; LineSeg* feat3D = nullptr; double length = 0; };
 struct Frame {
   int id_ = 0;

@@ -81,3 +81,44 @@ def test_adapter_reproduces_reference_mutations(P, ob, tmp_path):
     assert (int(sc[3]), int(sc[4])) == (po.num_obs_pt, po.num_obs_ls)
     assert float(sc[5]) == pytest.approx(po.cov[0, 0], rel=1e-6)
     assert [int(x) for x in got["pt_keep"]] == list(po.pt_keep) and [int(x) for x in got["seg_keep"]] == list(po.seg_keep)
+
+
+def test_direct_matcher_adapter_reproduces_find_match_direct(P, ob, tmp_path):
+    """plsvo::DirectMatcher: PointFeat / LineFeat objects in, one batched run, Matcher::findMatchDirect's outputs
+    (return value, px_cur / spx_cur / epx_cur, search_level_) out -- bit for bit the oracle's, twice (the second pass
+    is served from the adapter's keyframe-pyramid cache)."""
+    driver = os.path.join(ROOT, "pl-svo_amd", "host", "match_driver")
+    assert os.path.exists(driver), "build it with __graft_entry__.build()"
+    W, H, nlev, npts, nseg = 320, 240, 4, 50, 14
+    st, d = P.synth.make_match_batch(881, W, H, npts, nseg, zoom=0.2, edgelet_frac=0.3)
+    imgs = P.synth.render_streams([st]).numpy()[0]
+    frames = [ob.build_pyramid(imgs[0], nlev), ob.build_pyramid(imgs[1], nlev)]
+    path = tmp_path / "match.bin"
+    s0, e0 = npts, npts + nseg
+    with open(path, "wb") as f:
+        np.array([W, H, nlev, npts, nseg, 3], float).tofile(f)
+        np.array(st.cam[:4], float).tofile(f)
+        d["frame_T"].astype(np.float64).tofile(f)
+        for pyr in frames:
+            for l in pyr:
+                np.ascontiguousarray(l, np.uint8).tofile(f)
+        np.hstack([d["ref_px"][:npts], d["ref_f"][:npts], d["ref_level"][:npts, None].astype(float), d["ref_type"][:npts, None].astype(float),
+                   d["ref_grad"][:npts], d["pos"][:npts], d["px_cur"][:npts]]).astype(np.float64).tofile(f)
+        # a segment's two end points share the observation's level (Feature::level)
+        d["ref_level"][e0:] = d["ref_level"][s0:e0]
+        np.hstack([d["ref_px"][s0:e0], d["ref_px"][e0:], d["ref_f"][s0:e0], d["ref_f"][e0:], d["ref_level"][s0:e0, None].astype(float),
+                   d["pos"][s0:e0], d["pos"][e0:], d["px_cur"][s0:e0], d["px_cur"][e0:]]).astype(np.float64).tofile(f)
+    out = tmp_path / "match.txt"
+    subprocess.run([driver, str(path), str(out)], check=True, timeout=120)
+    ro = ob.match_direct(P.match_job_from_batch(d), frames)
+    rows = [l.split() for l in open(out).read().strip().splitlines()]
+    for p in ("0", "1"):
+        pt = np.array([[float(x) for x in r[1:]] for r in rows if r[0] == "pt" + p])
+        sg = np.array([[float(x) for x in r[1:]] for r in rows if r[0] == "seg" + p])
+        assert pt.shape == (npts, 4) and sg.shape == (nseg, 6)
+        assert np.array_equal(pt[:, 0], ro["found"][:npts]) and np.array_equal(pt[:, 1], ro["search_level"][:npts])
+        assert np.array_equal(np.nan_to_num(pt[:, 2:], nan=-1), np.nan_to_num(ro["px_cur"][:npts], nan=-1))
+        assert np.array_equal(sg[:, 0], ro["found"][s0:e0] & ro["found"][e0:]) and np.array_equal(sg[:, 1], ro["search_level"][e0:])
+        assert np.array_equal(np.nan_to_num(sg[:, 2:4], nan=-1), np.nan_to_num(ro["px_cur"][s0:e0], nan=-1))
+        assert np.array_equal(np.nan_to_num(sg[:, 4:6], nan=-1), np.nan_to_num(ro["px_cur"][e0:], nan=-1))
+    assert ro["found"].mean() > 0.3

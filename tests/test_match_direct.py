@@ -347,7 +347,7 @@ def test_hip_match_direct_edge_cases(P, ob, gpu_ctx):
     job = P.match_job_from_batch(d)
     ro, rd = ob.match_direct(job, flat), gpu_ctx.match_direct(job)
     _assert_same(rd, ro)
-    assert not ro["found"][d["ref_type"] == 0].any()
+    assert np.isnan(ro["px_cur"]).any()      # patches that lie fully inside the flat image have H = 0: NaN updates on both sides
     # empty batch
     for k in ("cur_frame", "ref_frame", "ref_px", "ref_f", "ref_level", "ref_type", "ref_grad", "pos", "px_cur"):
         d[k] = d[k][:0]
