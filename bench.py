@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PLSVO_BENCH_BATCH", "4096")), help="streams per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PLSVO_BENCH_BATCH", "32768")), help="streams per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

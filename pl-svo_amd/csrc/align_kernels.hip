@@ -10,14 +10,11 @@
 // Design (not a translation of the CPU loops):
 //   * features of a level are flattened into a PATCH TABLE (points: 1 patch, segments: N samples),
 //     built on the device by a block-wide scan; a patch is 4x4 pixels;
-//   * small level images (<= lds_img_cap bytes, i.e. the coarse levels) are staged once per level into LDS
-//     with coalesced 16-byte loads; larger ones are gathered through L2.  Either way a 5x5 window costs two
-//     dword reads + v_alignbyte per patch row.  Keeping LDS below ~40 KB per workgroup lets four 256-thread
-//     workgroups share a CU, which hides each other's serial solve/update tails (measured: +13 % over
-//     staging the 77 KB level-1 image and running one workgroup per CU);
-//   * phase 1 is software-pipelined: the cache lines and image dwords of the next patch round are requested
-//     before the current round is computed;
-//   * 4 lanes per patch (one lane per patch row).  The 6-vector Jacobian of a pixel is
+//   * the level image is gathered through L2 (a 5x5 window costs two aligned dword reads + v_alignbyte per image
+//     row); LDS holds only the per-patch tables (~15 KB per 128-thread workgroup), so four workgroups share a CU and
+//     hide each other's serial solve/update tails.  Staging the level image in LDS (77 KB at level 1 -> one
+//     workgroup per CU) and software-pipelining the phase-1 loads were both measured and lost;
+//   * phase 1: 2 lanes per patch, two adjacent patch rows (8 pixels) per lane.  The 6-vector Jacobian of a pixel is
 //     J = fs * (dx * r0 + dy * r1) with r0, r1 the two rows of the 2x6 projection Jacobian of the PATCH,
 //     so sum_pix w J J^T = fs^2 (A r0 r0^T + B (r0 r1^T + r1 r0^T) + C r1 r1^T) with
 //     A = sum w dx^2, B = sum w dx dy, C = sum w dy^2, and sum_pix w res J = fs (D r0 + E r1).
@@ -32,6 +29,8 @@
 // Numerics: image interpolation and residuals in float with the reference's operation order and NO
 // fma contraction (__fmul_rn/__fadd_rn); geometry and all accumulators in double.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "plsvo_dev.hpp"
 #include "plsvo_math.hpp"
@@ -157,13 +156,15 @@ __global__ void align_init_kernel(AlignBatchDev b) {
 
 #define RED_N 32  // doubles per wave in the block reduction (21 H + 6 Jres + chi2 + 2 counters + pad)
 
-// what phase 1 requests one patch round ahead
-struct P1Fetch {
+// what one lane of phase 1 loads for its half patch (2 lanes per patch, two adjacent patch rows = 8 pixels each: the
+// middle image row is shared, one cross-lane step instead of two, address and weight work amortised over 8 pixels;
+// measured 11 % faster than 4 lanes per patch with one row each)
+struct P1Fetch2 {
   float2 uv;
-  uint32_t t0, t1, b0, b1;   // the two aligned dword pairs covering 5 bytes of the top / bottom image row
-  int sh;                    // byte shift inside the first dword
-  float4 vr, vx, vy;         // cached reference intensity and gradient of this patch row
-  int flags;                 // bit 0: live (in frame, line alive), bit 1: point patch
+  uint32_t r0a, r0b, r1a, r1b, r2a, r2b;   // aligned dword pairs covering 5 bytes of image rows 2h, 2h+1, 2h+2 of the 5x5 window
+  int off;                                 // byte offset of the first of them (the shifts follow from it)
+  float4 vr0, vx0, vy0, vr1, vx1, vy1;     // cached reference intensity and gradient of patch rows 2h, 2h+1
+  int flags;                               // bit 0: live (in frame, line alive), bit 1: point patch
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   if (lv_first < lv_last) return;
   AlignStateDev* st = b.state + job_id;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int G = T / 4;  // 4-lane patch groups per workgroup
+  constexpr int G = T / 4;  // 4-lane patch groups per workgroup (reference-patch precompute: one patch row per lane)
   const int grp = tid >> 2, row = tid & 3;
 
   extern __shared__ __align__(16) unsigned char smem[];
@@ -198,7 +199,6 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   float* s_abs = reinterpret_cast<float*>(s_meta + cap);                 // cap
   int* s_dead = reinterpret_cast<int*>(s_abs + cap);                     // cap
   int* s_cnt = s_dead + cap;                                             // cap + 4: per-feature patch count / offset (nfeat <= cap)
-  uint8_t* s_img = reinterpret_cast<uint8_t*>(s_cnt + cap + 4);          // lds_img_cap (16-byte aligned: cap % 4 == 0)
 
 #ifdef PLSVO_TIMING
   __shared__ unsigned long long s_time[8];
@@ -223,18 +223,8 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     const unsigned int lvl_off = pyr_level_offset(job.width, job.height, level);
     const uint8_t* ref_img = b.pyr.base + (size_t)job.ref_slot * b.pyr.slot_bytes + lvl_off;
     const uint8_t* cur_img = b.pyr.base + (size_t)job.cur_slot * b.pyr.slot_bytes + lvl_off;
-    const int img_bytes = W * Hh;
-    const bool lds_img = img_bytes + 16 <= lds_img_cap;   // wave-uniform
     __syncthreads();  // previous level done with every LDS table
 
-    // ---- stage the current level image into LDS when it is small (coalesced 16 B per lane) ----
-    if (lds_img) {
-      const int n16 = img_bytes >> 4;
-      for (int i = tid; i < n16; i += T)
-        reinterpret_cast<uint4*>(s_img)[i] = reinterpret_cast<const uint4*>(cur_img)[i];
-      for (int i = (n16 << 4) + tid; i < img_bytes + 16; i += T)
-        s_img[i] = (i < img_bytes) ? cur_img[i] : (uint8_t)0;
-    }
     if (tid == 0) { s_ctl[0] = 0; s_ctl[2] = 0; s_pose[27] = 0.0; }
 
     // ---- patch table: count, scan, emit ----
@@ -376,93 +366,112 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       __syncthreads();
       TICK(1);
 
-      // -- phase 1: 4 lanes per patch, one patch row each: residuals and the five patch sums.
-      //    Software-pipelined: the loads of round r+1 are issued before round r is computed.
+      // -- phase 1: 2 lanes per patch, two patch rows (8 pixels) each: residuals and the five patch sums.
       int evals = 0;
-      auto fetch = [&](int pb) -> P1Fetch {
-        P1Fetch f;
-        f.flags = 0; f.uv = make_float2(-1.0f, -1.0f); f.t0 = f.t1 = f.b0 = f.b1 = 0u; f.sh = 0;
-        f.vr = f.vx = f.vy = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int p = pb + grp;
-        if (p < n_patch) {
-          f.uv = s_uv[p];
-          if (f.uv.x >= 0.0f) {
-            f.flags = 1 | ((s_meta[p].x >= 0) ? 2 : 0);
-            const int ui = (int)floorf(f.uv.x), vi = (int)floorf(f.uv.y);
-            const int off = (vi - 2 + row) * W + (ui - 2);
-            const int a = off & ~3, ab = (off + W) & ~3;
-            f.sh = off & 3;
-            if (lds_img) {
-              f.t0 = *reinterpret_cast<const uint32_t*>(s_img + a); f.t1 = *reinterpret_cast<const uint32_t*>(s_img + a + 4);
-              f.b0 = *reinterpret_cast<const uint32_t*>(s_img + ab); f.b1 = *reinterpret_cast<const uint32_t*>(s_img + ab + 4);
-            } else {
-              f.t0 = *reinterpret_cast<const uint32_t*>(cur_img + a); f.t1 = *reinterpret_cast<const uint32_t*>(cur_img + a + 4);
-              f.b0 = *reinterpret_cast<const uint32_t*>(cur_img + ab); f.b1 = *reinterpret_cast<const uint32_t*>(cur_img + ab + 4);
+      {
+        constexpr int G2 = T / 2;
+        const int grp2 = tid >> 1, half = tid & 1;
+        auto fetch2 = [&](int pb) -> P1Fetch2 {
+          P1Fetch2 f;
+          f.flags = 0; f.uv = make_float2(-1.0f, -1.0f); f.r0a = f.r0b = f.r1a = f.r1b = f.r2a = f.r2b = 0u; f.off = 0;
+          f.vr0 = f.vx0 = f.vy0 = f.vr1 = f.vx1 = f.vy1 = make_float4(0.f, 0.f, 0.f, 0.f);
+          const int p = pb + grp2;
+          if (p < n_patch) {
+            f.uv = s_uv[p];
+            if (f.uv.x >= 0.0f) {
+              f.flags = 1 | ((s_meta[p].x >= 0) ? 2 : 0);
+              const int ui = (int)floorf(f.uv.x), vi = (int)floorf(f.uv.y);
+              const int off = (vi - 2 + 2 * half) * W + (ui - 2);
+              f.off = off;
+              const int a0 = off & ~3, a1 = (off + W) & ~3, a2 = (off + 2 * W) & ~3;
+              f.r0a = *reinterpret_cast<const uint32_t*>(cur_img + a0); f.r0b = *reinterpret_cast<const uint32_t*>(cur_img + a0 + 4);
+              f.r1a = *reinterpret_cast<const uint32_t*>(cur_img + a1); f.r1b = *reinterpret_cast<const uint32_t*>(cur_img + a1 + 4);
+              f.r2a = *reinterpret_cast<const uint32_t*>(cur_img + a2); f.r2b = *reinterpret_cast<const uint32_t*>(cur_img + a2 + 4);
+              const size_t q = (pbase + p) * 4 + 2 * half;
+              f.vr0 = reinterpret_cast<const float4*>(b.cache_ref)[q]; f.vr1 = reinterpret_cast<const float4*>(b.cache_ref)[q + 1];
+              f.vx0 = reinterpret_cast<const float4*>(b.cache_dx)[q];  f.vx1 = reinterpret_cast<const float4*>(b.cache_dx)[q + 1];
+              f.vy0 = reinterpret_cast<const float4*>(b.cache_dy)[q];  f.vy1 = reinterpret_cast<const float4*>(b.cache_dy)[q + 1];
             }
-            const size_t q = (pbase + p) * 4 + row;
-            f.vr = reinterpret_cast<const float4*>(b.cache_ref)[q];
-            f.vx = reinterpret_cast<const float4*>(b.cache_dx)[q];
-            f.vy = reinterpret_cast<const float4*>(b.cache_dy)[q];
           }
-        }
-        return f;
-      };
-#ifdef PLSVO_NO_PREFETCH
-      P1Fetch cur;
-      for (int pb = 0; pb < n_patch; pb += G) {
-        cur = fetch(pb);
-        const P1Fetch nxt = cur;
+          return f;
+        };
+        auto unpack5 = [](uint32_t lo, uint32_t hi, int sh, float* o) {
+          const uint32_t w0 = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh);
+          o[0] = (float)(w0 & 0xffu); o[1] = (float)((w0 >> 8) & 0xffu); o[2] = (float)((w0 >> 16) & 0xffu); o[3] = (float)(w0 >> 24);
+          o[4] = (float)((hi >> (8 * sh)) & 0xffu);
+        };
+#ifndef PLSVO_PREFETCH
+        P1Fetch2 cur;
+        for (int pb = 0; pb < n_patch; pb += G2) {
+          cur = fetch2(pb);
 #else
-      P1Fetch cur = fetch(0);
-      for (int pb = 0; pb < n_patch; pb += G) {
-        const P1Fetch nxt = fetch(pb + G);
+        P1Fetch2 cur = fetch2(0);
+        for (int pb = 0; pb < n_patch; pb += G2) {
+          const P1Fetch2 nxt = fetch2(pb + G2);
 #endif
-        const int p = pb + grp;
-        double sA = 0, sB = 0, sC = 0, sD = 0, sE = 0, sChi = 0;
-        float sAbs = 0.0f;
-        const bool live = (cur.flags & 1) != 0;
-        if (live) {
-          const bool is_point = (cur.flags & 2) != 0;
-          const PatchW pw = patch_weights(cur.uv.x, cur.uv.y);
-          const int sh_t = cur.sh, sh_b = (cur.sh + W) & 3;   // byte shifts of the top / bottom row inside their dword pairs
-          float top[5], bot[5];
-          {
-            const uint32_t w0 = __builtin_amdgcn_alignbyte(cur.t1, cur.t0, sh_t);
-            top[0] = (float)(w0 & 0xffu); top[1] = (float)((w0 >> 8) & 0xffu); top[2] = (float)((w0 >> 16) & 0xffu); top[3] = (float)(w0 >> 24);
-            top[4] = (float)((cur.t1 >> (8 * sh_t)) & 0xffu);
-          }
-          {
-            const uint32_t w0 = __builtin_amdgcn_alignbyte(cur.b1, cur.b0, sh_b);
-            bot[0] = (float)(w0 & 0xffu); bot[1] = (float)((w0 >> 8) & 0xffu); bot[2] = (float)((w0 >> 16) & 0xffu); bot[3] = (float)(w0 >> 24);
-            bot[4] = (float)((cur.b1 >> (8 * sh_b)) & 0xffu);
-          }
-          const float* pr = reinterpret_cast<const float*>(&cur.vr);
-          const float* pxp = reinterpret_cast<const float*>(&cur.vx);
-          const float* pyp = reinterpret_cast<const float*>(&cur.vy);
+          const int p = pb + grp2;
+          double sA = 0, sB = 0, sC = 0, sD = 0, sE = 0, sChi = 0;
+          float sAbs = 0.0f;
+          const bool live = (cur.flags & 1) != 0;
+          const bool any_point = __any((cur.flags & 3) == 3) != 0;   // wave-uniform
+          if (live) {
+            const bool is_point = (cur.flags & 2) != 0;
+            const PatchW pw = patch_weights(cur.uv.x, cur.uv.y);
+            float r0[5], r1[5], r2[5];
+            unpack5(cur.r0a, cur.r0b, cur.off & 3, r0);
+            unpack5(cur.r1a, cur.r1b, (cur.off + W) & 3, r1);
+            unpack5(cur.r2a, cur.r2b, (cur.off + 2 * W) & 3, r2);
+            // (a packed-FP32 form of this loop, two pixels per v_pk_* instruction, was measured 12 % slower: the operand
+            //  pairs need extra moves and the scalar form already issues at full rate)
+            // WEIGHTED is decided per wave: the patch table lists points first, then line samples, so most rounds are
+            // homogeneous and the line-only ones skip the robust weight (11 instructions per pixel) and the chi2 term
+            auto row4 = [&](auto WEIGHTED, const float* top, const float* bot, const float4& vr, const float4& vx, const float4& vy) {
+              constexpr bool weighted = decltype(WEIGHTED)::value;
+              const float* pr = reinterpret_cast<const float*>(&vr);
+              const float* pxp = reinterpret_cast<const float*>(&vx);
+              const float* pyp = reinterpret_cast<const float*>(&vy);
 #pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            const float c = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, top[x], top[x + 1], bot[x], bot[x + 1]);
-            const float res = __fsub_rn(c, pr[x]);
-            const float ares = fabsf(res);
-            // points: w = 1/(1+|r|) (:479); line pixels are accumulated unweighted (:627-629)
-            const float w = is_point ? robust_weight(ares) : 1.0f;
-            const double wd = (double)w, rd = (double)res, dx = (double)pxp[x], dy = (double)pyp[x];
-            const double wdx = wd * dx, wdy = wd * dy;
-            sA += wdx * dx; sB += wdx * dy; sC += wdy * dy;
-            sD += wdx * rd; sE += wdy * rd;
-            sChi += (double)__fmul_rn(__fmul_rn(res, res), w);
-            sAbs += ares;
+              for (int x = 0; x < 4; ++x) {
+                const float c = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, top[x], top[x + 1], bot[x], bot[x + 1]);
+                const float res = __fsub_rn(c, pr[x]);
+                const float ares = fabsf(res);
+                const double rd = (double)res, dx = (double)pxp[x], dy = (double)pyp[x];
+                if (weighted) {
+                  // points: w = 1/(1+|r|) (:479); line pixels are accumulated unweighted (:627-629)
+                  const float w = is_point ? robust_weight(ares) : 1.0f;
+                  const double wd = (double)w;
+                  const double wdx = wd * dx, wdy = wd * dy;
+                  sA += wdx * dx; sB += wdx * dy; sC += wdy * dy;
+                  sD += wdx * rd; sE += wdy * rd;
+                  sChi += (double)__fmul_rn(__fmul_rn(res, res), w);
+                } else {
+                  sA += dx * dx; sB += dx * dy; sC += dy * dy;
+                  sD += dx * rd; sE += dy * rd;
+                }
+                sAbs += ares;
+              }
+            };
+            if (any_point) {
+              row4(std::true_type{}, r0, r1, cur.vr0, cur.vx0, cur.vy0);
+              row4(std::true_type{}, r1, r2, cur.vr1, cur.vx1, cur.vy1);
+            } else {
+              row4(std::false_type{}, r0, r1, cur.vr0, cur.vx0, cur.vy0);
+              row4(std::false_type{}, r1, r2, cur.vr1, cur.vx1, cur.vy1);
+            }
           }
+          sA += dpp_mov_f64<DPP_QUAD_XOR1>(sA); sB += dpp_mov_f64<DPP_QUAD_XOR1>(sB); sC += dpp_mov_f64<DPP_QUAD_XOR1>(sC);
+          sD += dpp_mov_f64<DPP_QUAD_XOR1>(sD); sE += dpp_mov_f64<DPP_QUAD_XOR1>(sE); sChi += dpp_mov_f64<DPP_QUAD_XOR1>(sChi);
+          sAbs += dpp_mov_f32<DPP_QUAD_XOR1>(sAbs);
+          if (p < n_patch && half == 0) {
+            double* dst = part + 6 * p;
+            dst[0] = sA; dst[1] = sB; dst[2] = sC; dst[3] = sD; dst[4] = sE; dst[5] = sChi;
+            s_abs[p] = live ? sAbs : -1.0f;
+            evals += live ? 1 : 0;
+          }
+#ifdef PLSVO_PREFETCH
+          cur = nxt;   // software pipelining one round ahead: measured no faster than letting the two waves per SIMD overlap
+#endif
         }
-        sA = quad_sum(sA); sB = quad_sum(sB); sC = quad_sum(sC); sD = quad_sum(sD); sE = quad_sum(sE);
-        sChi = quad_sum(sChi); sAbs = quad_sum(sAbs);
-        if (p < n_patch && row == 0) {
-          double* dst = part + 6 * p;
-          dst[0] = sA; dst[1] = sB; dst[2] = sC; dst[3] = sD; dst[4] = sE; dst[5] = sChi;
-          s_abs[p] = live ? sAbs : -1.0f;
-          evals += live ? 1 : 0;
-        }
-        cur = nxt;
       }
       __syncthreads();
       TICK(2);
@@ -636,7 +645,7 @@ size_t align_level_lds_bytes(int threads, int cap, int lds_img_cap, int lds_px) 
   if (lds_px & 1) o += (size_t)cap * 6 * sizeof(double);
   if (lds_px & 2) o += (size_t)cap * 3 * sizeof(double);
   o += (size_t)cap * (sizeof(float2) + sizeof(int2) + sizeof(float) + sizeof(int) + sizeof(int)) + 16;
-  o += (size_t)lds_img_cap;
+  (void)lds_img_cap;   // LDS staging of the level image was retired (gathers through L2 with more workgroups per CU won)
   return o;
 }
 
