@@ -54,6 +54,10 @@ def lib():
         L.plsvo_oracle_structure_optimize.argtypes = [C.POINTER(abi.StructOptIn), C.POINTER(abi.StructOptOut)]
         L.plsvo_oracle_match_direct.restype = C.c_int
         L.plsvo_oracle_match_direct.argtypes = [C.POINTER(abi.MatchIn), C.POINTER(OraclePyr), C.POINTER(abi.MatchOut)]
+        L.plsvo_oracle_reproject.restype = C.c_int
+        L.plsvo_oracle_reproject.argtypes = [C.POINTER(abi.ReprojectIn), C.POINTER(abi.ReprojectOut)]
+        L.plsvo_oracle_trajectory_record.restype = C.c_int
+        L.plsvo_oracle_trajectory_record.argtypes = [abi.c_double_p, abi.c_double_p, abi.c_double_p]
         L.plsvo_oracle_halfsample.restype = None
         L.plsvo_oracle_halfsample.argtypes = [abi.c_u8_p, C.c_int, C.c_int, C.c_int, abi.c_u8_p, C.c_int, C.c_int]
         d = abi.c_double_p
@@ -165,6 +169,22 @@ def match_direct(job, frame_levels):
     if rc != 0:
         raise RuntimeError(f"oracle match_direct failed rc={rc}")
     return job.trim(bufs)
+
+
+def reproject(job):
+    out, bufs = job.make_out()
+    rc = lib().plsvo_oracle_reproject(C.byref(job.c), C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"oracle reproject failed rc={rc}")
+    return job.trim(bufs)
+
+
+def trajectory_record(T_f_w, cov):
+    T = np.ascontiguousarray(T_f_w, dtype=np.float64)
+    Cv = np.ascontiguousarray(cov, dtype=np.float64).reshape(36)
+    out = np.empty(7)
+    ok = lib().plsvo_oracle_trajectory_record(_dp(T), _dp(Cv), _dp(out))
+    return bool(ok), out
 
 
 # --- small helpers for unit tests -------------------------------------------------------------

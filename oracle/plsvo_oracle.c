@@ -1262,3 +1262,36 @@ int plsvo_oracle_match_direct(const plsvo_match_in* in, const plsvo_oracle_pyr* 
   }
   return PLSVO_OK;
 }
+
+/* Reprojector::reproject for points and segment end points (src/reprojector.cpp:387-423) */
+int plsvo_oracle_reproject(const plsvo_reproject_in* in, plsvo_reproject_out* out) {
+  if (!in || !out || in->n < 0 || in->cell_size <= 0) return PLSVO_E_INVALID;
+  for (int i = 0; i < in->n; ++i) {
+    const se3_t T = se3_load(in->frame_T + 7 * in->frame[i]);
+    double c[3], px[2];
+    se3_act(&T, in->pos + 3 * i, c);                  /* Frame::w2c: cam_->world2cam(T_f_w_ * xyz_w), frame.h:113 */
+    plsvo_oracle_world2cam(&in->cam, c, px);
+    int cell = -1;
+    /* isInFrame(cur_px.cast<int>(), 8): level-0 overload, [ext] vk::AbstractCamera.  A NaN / out-of-range cast is
+     * undefined in C; the device and this restatement both treat it as "not in frame". */
+    if (px[0] == px[0] && px[1] == px[1] && fabs(px[0]) < 1e9 && fabs(px[1]) < 1e9) {
+      const int ox = (int)px[0], oy = (int)px[1];
+      if (ox >= in->boundary && ox < in->cam.width - in->boundary && oy >= in->boundary && oy < in->cam.height - in->boundary)
+        cell = (int)(px[1] / in->cell_size) * in->grid_n_cols + (int)(px[0] / in->cell_size);   /* :393-394 */
+    }
+    if (out->px) { out->px[2 * i] = px[0]; out->px[2 * i + 1] = px[1]; }
+    if (out->cell) out->cell[i] = cell;
+  }
+  return PLSVO_OK;
+}
+
+/* trajectory record of app/run_pipeline.cpp:425-451 */
+int plsvo_oracle_trajectory_record(const double T_f_w[7], const double cov[36], double out7[7]) {
+  int skip_frame = 0;
+  for (int i = 0; i < 36; ++i) if (!((1.e-16 < fabs(cov[i])) && (fabs(cov[i]) < 1.e+16))) skip_frame = 1;
+  const se3_t T = se3_load(T_f_w);
+  const se3_t W = se3_inv(&T);
+  if ((W.t[0] == 0. && W.t[1] == 0. && W.t[2] == 0.) && (W.q.x == -0. && W.q.y == -0. && W.q.z == -0. && W.q.w == 1.)) skip_frame = 1;
+  out7[0] = W.t[0]; out7[1] = W.t[1]; out7[2] = W.t[2]; out7[3] = W.q.x; out7[4] = W.q.y; out7[5] = W.q.z; out7[6] = W.q.w;
+  return skip_frame ? 0 : 1;
+}

@@ -16,8 +16,8 @@ synth = _il.import_module(__name__ + ".synth")
 
 
 def __getattr__(name):
-    if name == "capi":
-        return _il.import_module(__name__ + ".capi")
+    if name in ("capi", "trajectory", "dist"):
+        return _il.import_module(__name__ + "." + name)
     raise AttributeError(name)
 
 

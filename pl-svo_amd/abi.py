@@ -94,6 +94,15 @@ class MatchOut(C.Structure):
     _fields_ = [("px_cur", c_double_p), ("found", c_u8_p), ("search_level", c_i32_p), ("n_iter", c_i32_p)]
 
 
+class ReprojectIn(C.Structure):
+    _fields_ = [("cam", Pinhole), ("n_frames", C.c_int32), ("n", C.c_int32), ("cell_size", C.c_int32), ("grid_n_cols", C.c_int32),
+                ("boundary", C.c_int32), ("reserved0", C.c_int32), ("frame_T", c_double_p), ("frame", c_i32_p), ("pos", c_double_p)]
+
+
+class ReprojectOut(C.Structure):
+    _fields_ = [("px", c_double_p), ("cell", c_i32_p)]
+
+
 def _f64(a, n=None):
     a = np.ascontiguousarray(a, dtype=np.float64)
     if n is not None and a.size != n:
@@ -279,6 +288,32 @@ class MatchJob:
                     n_iter=np.zeros(m, np.int32))
         o.px_cur, o.found = bufs["px_cur"].ctypes.data_as(c_double_p), bufs["found"].ctypes.data_as(c_u8_p)
         o.search_level, o.n_iter = bufs["search_level"].ctypes.data_as(c_i32_p), bufs["n_iter"].ctypes.data_as(c_i32_p)
+        return o, bufs
+
+    def trim(self, bufs):
+        return {k: v[:self.n].copy() for k, v in bufs.items()}
+
+
+class ReprojectJob:
+    """Landmark positions to project into frames (plsvo_reproject); owns the buffers."""
+
+    def __init__(self, cam, frame_T, frame, pos, cell_size=30, boundary=8):
+        self.frame_T = _f64(frame_T).reshape(-1, 7)
+        self.pos = _f64(pos).reshape(-1, 3)
+        self.n = self.pos.shape[0]
+        self.frame = np.ascontiguousarray(frame, dtype=np.int32).reshape(-1)
+        c = ReprojectIn()
+        c.cam = cam if isinstance(cam, Pinhole) else Pinhole(*cam)
+        c.n_frames, c.n, c.cell_size, c.boundary = self.frame_T.shape[0], self.n, cell_size, boundary
+        c.grid_n_cols = -(-int(c.cam.width) // cell_size)          # ceil(width / cell_size), reprojector.cpp:59
+        c.frame_T, c.frame, c.pos = _ptr(self.frame_T, c_double_p), _ptr(self.frame, c_i32_p), _ptr(self.pos, c_double_p)
+        self.c = c
+
+    def make_out(self):
+        o = ReprojectOut()
+        m = max(self.n, 1)
+        bufs = dict(px=np.zeros((m, 2)), cell=np.zeros(m, np.int32))
+        o.px, o.cell = bufs["px"].ctypes.data_as(c_double_p), bufs["cell"].ctypes.data_as(c_i32_p)
         return o, bufs
 
     def trim(self, bufs):

@@ -22,7 +22,7 @@ SYMBOLS = [
     "plsvo_align_set_trace", "plsvo_align_fetch_trace", "plsvo_align_poses_dev", "plsvo_align_copy_poses", "plsvo_align_work",
     "plsvo_pose_optimize", "plsvo_pose_optimize_batch", "plsvo_poseopt_stage", "plsvo_poseopt_run", "plsvo_poseopt_fetch",
     "plsvo_poseopt_set_trace", "plsvo_poseopt_fetch_trace", "plsvo_poseopt_poses_dev", "plsvo_poseopt_copy_poses", "plsvo_poseopt_work",
-    "plsvo_structure_optimize", "plsvo_match_direct",
+    "plsvo_structure_optimize", "plsvo_match_direct", "plsvo_reproject", "plsvo_trajectory_record",
     "plsvo_gather_poses",
     "plsvo_hip_set_profiling", "plsvo_hip_kernel_time", "plsvo_hip_reset_profiling",
     "plsvo_hip_version", "plsvo_hip_device_info",
@@ -82,6 +82,8 @@ def lib():
         "plsvo_poseopt_work": (C.c_int, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "plsvo_structure_optimize": (C.c_int, [ctxp, C.POINTER(abi.StructOptIn), C.POINTER(abi.StructOptOut)]),
         "plsvo_match_direct": (C.c_int, [ctxp, C.POINTER(abi.MatchIn), C.POINTER(abi.MatchOut)]),
+        "plsvo_reproject": (C.c_int, [ctxp, C.POINTER(abi.ReprojectIn), C.POINTER(abi.ReprojectOut)]),
+        "plsvo_trajectory_record": (C.c_int, [abi.c_double_p, abi.c_double_p, abi.c_double_p]),
         "plsvo_gather_poses": (C.c_int, [ctxp, vp, vp, C.c_int, vp]),
         "plsvo_hip_set_profiling": (C.c_int, [ctxp, C.c_int]),
         "plsvo_hip_kernel_time": (C.c_int, [ctxp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -296,5 +298,19 @@ class Context:
         self._chk(self.L.plsvo_match_direct(self.h, C.byref(job.c), C.byref(out)))
         return job.trim(bufs)
 
+    def reproject(self, job):
+        out, bufs = job.make_out()
+        self._chk(self.L.plsvo_reproject(self.h, C.byref(job.c), C.byref(out)))
+        return job.trim(bufs)
+
     def gather_poses(self, rccl_comm, d_local, n_local, d_all):
         self._chk(self.L.plsvo_gather_poses(self.h, C.c_void_p(rccl_comm), C.c_void_p(d_local), n_local, C.c_void_p(d_all)))
+
+
+def trajectory_record(T_f_w, cov):
+    """plsvo_trajectory_record: (write?, [tx ty tz qx qy qz qw] of T_f_w^-1) -- host-only, no ctx needed"""
+    T = np.ascontiguousarray(T_f_w, dtype=np.float64)
+    Cv = np.ascontiguousarray(cov, dtype=np.float64).reshape(36)
+    out = np.empty(7)
+    ok = lib().plsvo_trajectory_record(T.ctypes.data_as(abi.c_double_p), Cv.ctypes.data_as(abi.c_double_p), out.ctypes.data_as(abi.c_double_p))
+    return bool(ok), out

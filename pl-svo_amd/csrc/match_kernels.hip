@@ -318,6 +318,31 @@ __global__ void __launch_bounds__(MT) match_direct_kernel(const MatchBatchDev b)
   b.n_iter[i] = iters;
 }
 
+// Reprojector::reproject (src/reprojector.cpp:387-423): one lane per landmark position
+__global__ void __launch_bounds__(256) reproject_kernel(const ReprojBatchDev b) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= b.n) return;
+  const SE3d T = se3_load(b.frame_T + 7 * b.frame[i]);
+  double c[3];
+  se3_act(T, b.pos + 3 * i, c);
+  const double u = c[0] / c[2], v = c[1] / c[2];
+  const double px0 = b.fx * u + b.cx, px1 = b.fy * v + b.cy;
+  int cell = -1;
+  if (px0 == px0 && px1 == px1 && fabs(px0) < 1e9 && fabs(px1) < 1e9) {
+    const int ox = (int)px0, oy = (int)px1;
+    if (ox >= b.boundary && ox < b.cam_width - b.boundary && oy >= b.boundary && oy < b.cam_height - b.boundary)
+      cell = (int)(px1 / b.cell_size) * b.grid_n_cols + (int)(px0 / b.cell_size);
+  }
+  b.px[2 * i] = px0; b.px[2 * i + 1] = px1;
+  b.cell[i] = cell;
+}
+
+hipError_t launch_reproject(const ReprojBatchDev& b, hipStream_t stream) {
+  if (b.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(reproject_kernel, dim3((b.n + 255) / 256), dim3(256), 0, stream, b);
+  return hipGetLastError();
+}
+
 hipError_t launch_match_direct(const MatchBatchDev& b, hipStream_t stream) {
   if (b.n <= 0) return hipSuccess;
   const int blocks = (b.n + MT - 1) / MT;

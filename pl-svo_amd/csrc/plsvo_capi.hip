@@ -26,6 +26,7 @@ hipError_t launch_pose_opt(const PoseBatchDev& b, hipStream_t stream);
 hipError_t launch_pose_finish(const PoseBatchDev& b, double* d_poses, hipStream_t stream);
 hipError_t launch_structopt(const StructBatchDev& s, hipStream_t stream);
 hipError_t launch_match_direct(const MatchBatchDev& b, hipStream_t stream);
+hipError_t launch_reproject(const ReprojBatchDev& b, hipStream_t stream);
 hipError_t launch_halfsample(const uint8_t* src, size_t src_pitch, int in_w, int in_h, int in_stride, uint8_t* dst,
                              size_t dst_pitch, int n_slots, int rounding, hipStream_t stream);
 hipError_t launch_copy_level0(const uint8_t* src, size_t src_pitch, int w, int h, int stride, uint8_t* dst, size_t dst_pitch,
@@ -860,6 +861,55 @@ extern "C" int plsvo_match_direct(plsvo_ctx* c, const plsvo_match_in* in, plsvo_
   if (out->n_iter) memcpy(out->n_iter, h.data() + out_d + (size_t)n * sizeof(int), (size_t)n * sizeof(int));
   if (out->found) memcpy(out->found, h.data() + out_d + out_i, out_b);
   return PLSVO_OK;
+}
+
+// ---- reprojection of landmarks (candidates for the direct matcher) ------------------------------------
+extern "C" int plsvo_reproject(plsvo_ctx* c, const plsvo_reproject_in* in, plsvo_reproject_out* out) {
+  CTX_CHECK(c);
+  if (!in || !out || in->n < 0 || in->n_frames < 0 || in->cell_size <= 0 || in->grid_n_cols <= 0 || in->boundary < 0)
+    return fail(c, PLSVO_E_INVALID, "reproject: bad arguments");
+  const int n = in->n, nf = in->n_frames;
+  if (n == 0) return PLSVO_OK;
+  if (nf <= 0 || !in->frame_T || !in->frame || !in->pos) return fail(c, PLSVO_E_INVALID, "reproject: null input array");
+  for (int i = 0; i < n; ++i) if (in->frame[i] < 0 || in->frame[i] >= nf) return fail(c, PLSVO_E_INVALID, "reproject: frame index out of range");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t dT = (size_t)nf * 7, dP = (size_t)n * 3;
+  const size_t dbytes = (dT + dP) * sizeof(double), ibytes = (size_t)n * sizeof(int);
+  HIP_TRY(c, c->s_d_in.ensure(dbytes + ibytes + 16));
+  char* din = reinterpret_cast<char*>(c->s_d_in.p);
+  HIP_TRY(c, hipMemcpyAsync(din, in->frame_T, dT * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(din + dT * sizeof(double), in->pos, dP * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(din + dbytes, in->frame, ibytes, hipMemcpyHostToDevice, c->stream));
+  const size_t out_d = (size_t)n * 2 * sizeof(double), out_i = (size_t)n * sizeof(int);
+  HIP_TRY(c, c->s_d_out.ensure(out_d + out_i + 16));
+  char* dout = reinterpret_cast<char*>(c->s_d_out.p);
+  ReprojBatchDev b{};
+  b.fx = in->cam.fx; b.fy = in->cam.fy; b.cx = in->cam.cx; b.cy = in->cam.cy; b.cam_width = in->cam.width; b.cam_height = in->cam.height;
+  b.n = n; b.cell_size = in->cell_size; b.grid_n_cols = in->grid_n_cols; b.boundary = in->boundary;
+  b.frame_T = reinterpret_cast<const double*>(din); b.pos = b.frame_T + dT; b.frame = reinterpret_cast<const int*>(din + dbytes);
+  b.px = reinterpret_cast<double*>(dout); b.cell = reinterpret_cast<int*>(dout + out_d);
+  {
+    EventPair ep{}; prof_begin(c, PLSVO_K_MATCH, &ep);
+    HIP_TRY(c, launch_reproject(b, c->stream));
+    prof_end(c, PLSVO_K_MATCH, &ep);
+  }
+  std::vector<char> h(out_d + out_i);
+  HIP_TRY(c, hipMemcpyAsync(h.data(), dout, h.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (out->px) memcpy(out->px, h.data(), out_d);
+  if (out->cell) memcpy(out->cell, h.data() + out_d, out_i);
+  return PLSVO_OK;
+}
+
+// ---- trajectory record (host only; app/run_pipeline.cpp:425-451) ---------------------------------------
+extern "C" int plsvo_trajectory_record(const double T_f_w[7], const double cov[36], double out7[7]) {
+  if (!T_f_w || !cov || !out7) return 0;
+  bool skip_frame = false;
+  for (int i = 0; i < 36; ++i) if (!((1.e-16 < std::fabs(cov[i])) && (std::fabs(cov[i]) < 1.e+16))) skip_frame = true;
+  const SE3d W = se3_inv(se3_load(T_f_w));   // world_transf = T_f_w_.inverse()
+  if ((W.t[0] == 0. && W.t[1] == 0. && W.t[2] == 0.) && (W.q.x == -0. && W.q.y == -0. && W.q.z == -0. && W.q.w == 1.)) skip_frame = true;
+  out7[0] = W.t[0]; out7[1] = W.t[1]; out7[2] = W.t[2]; out7[3] = W.q.x; out7[4] = W.q.y; out7[5] = W.q.z; out7[6] = W.q.w;
+  return skip_frame ? 0 : 1;
 }
 
 // ---- multi-GPU gather ------------------------------------------------------------------------------

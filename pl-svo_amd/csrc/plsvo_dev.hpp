@@ -141,4 +141,11 @@ struct MatchBatchDev {
   double* px_out; uint8_t* found; int* search_level; int* n_iter;
 };
 
+struct ReprojBatchDev {
+  double fx, fy, cx, cy; int cam_width, cam_height;
+  int n, cell_size, grid_n_cols, boundary;
+  const double* frame_T; const int* frame; const double* pos;
+  double* px; int* cell;
+};
+
 }  // namespace plsvo_hip

@@ -1,0 +1,63 @@
+"""The widened path chained as FrameHandlerMono::processFrame chains it (pl-svo_amd/sequence.py): sparse alignment ->
+reprojection -> direct matching -> pose optimisation -> trajectory record, on a synthetic sequence with a known map.
+CPU: the chain on the oracle tracks the true trajectory.  GPU: the same chain through the C ABI stays within the parity
+bar of the oracle's chain on every frame, and the trajectory file has the reference harness's format."""
+import importlib
+
+import numpy as np
+import pytest
+
+import helpers as Hh
+
+
+class OracleBackend:
+    """test infrastructure: the same duck-typed backend as sequence.HipBackend, on the CPU oracle"""
+
+    def __init__(self, ob, n_levels=4):
+        self.ob, self.n_levels = ob, n_levels
+
+    def load_frames(self, images):
+        self.pyr = [self.ob.build_pyramid(im, self.n_levels) for im in images]
+
+    def sparse_align(self, job):
+        return self.ob.sparse_align(job, self.pyr[job.c.ref_slot], self.pyr[job.c.cur_slot])[0]
+
+    def reproject(self, job):
+        return self.ob.reproject(job)
+
+    def match_direct(self, job):
+        return self.ob.match_direct(job, [self.pyr[s] for s in job.frame_slot])
+
+    def pose_optimize(self, job):
+        return self.ob.pose_optimize(job)[0]
+
+
+@pytest.fixture(scope="module")
+def seqm():
+    return importlib.import_module("pl-svo_amd.sequence")
+
+
+def test_oracle_chain_tracks_the_true_trajectory(P, ob, seqm):
+    seq = seqm.make_sequence(3, n_frames=5, W=320, H=240, n_pts=100, n_seg=24)
+    res = seqm.run_sequence(OracleBackend(ob), seq)
+    err = seqm.pose_errors(res, seq)
+    assert max(e[0] for e in err) < 6e-3 and max(e[1] for e in err) < 3e-2, err      # ~1 px at 320x240 (fx = 208)
+    assert all(r["n_matched_pt"] > 40 for r in res[1:])
+    assert all(r["n_matched_seg"] >= 3 for r in res[1:])
+
+
+@pytest.mark.gpu
+def test_hip_chain_matches_the_oracle_chain(P, ob, gpu_ctx, seqm, tmp_path):
+    seq = seqm.make_sequence(4, n_frames=6, W=320, H=240, n_pts=100, n_seg=24)
+    ro = seqm.run_sequence(OracleBackend(ob), seq)
+    rd = seqm.run_sequence(seqm.HipBackend(gpu_ctx), seq)
+    for k, (a, b) in enumerate(zip(rd, ro)):
+        ang, tr, ok = Hh.pose_close(a["T"], b["T"])
+        assert ok, (k, ang, tr)
+        assert abs(a["n_matched_pt"] - b["n_matched_pt"]) <= 2 and abs(a["n_matched_seg"] - b["n_matched_seg"]) <= 1
+    path = tmp_path / "traj.txt"
+    n = P.trajectory.write_trajectory(path, [f"{0.05 * k:.6f}" for k in range(len(rd))], [r["T"] for r in rd], [r["cov"] for r in rd])
+    lines = open(path).read().strip().splitlines()
+    assert n == len(lines) == len(rd) and all(len(l.split()) == 8 for l in lines)
+    q = np.array([[float(x) for x in l.split()[4:]] for l in lines])
+    assert np.allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-5)
