@@ -176,7 +176,7 @@ struct P1Fetch2 {
 // LDS_PX: keep the per-iteration patch sums (6 doubles per patch) and the patches' 3-D points in LDS instead of
 // round-tripping them through L2/HBM every iteration (measured with FETCH_SIZE/WRITE_SIZE: ~36 % of the traffic)
 template <int T, int LDS_PX>   // LDS_PX bit 0: patch sums in LDS, bit 1: patch 3-D points in LDS
-__global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBatchDev b, int cap, int lds_img_cap, int level_hi, int level_lo) {
+__global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBatchDev b, int cap, int level_hi, int level_lo) {
   const int job_id = blockIdx.x;
   const AlignJobDev job = b.jobs[job_id];
   if (job.skip) return;
@@ -640,40 +640,39 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 }
 
 // LDS bytes the kernel needs for a given patch capacity and staged-image capacity (host side helper)
-size_t align_level_lds_bytes(int threads, int cap, int lds_img_cap, int lds_px) {
+size_t align_level_lds_bytes(int threads, int cap, int lds_px) {
   size_t o = sizeof(double) * RED_N * (threads / 64) + sizeof(double) * 64 + sizeof(int) * 32;
   if (lds_px & 1) o += (size_t)cap * 6 * sizeof(double);
   if (lds_px & 2) o += (size_t)cap * 3 * sizeof(double);
   o += (size_t)cap * (sizeof(float2) + sizeof(int2) + sizeof(float) + sizeof(int) + sizeof(int)) + 16;
-  (void)lds_img_cap;   // LDS staging of the level image was retired (gathers through L2 with more workgroups per CU won)
   return o;
 }
 
 template <int T, int PX>
-static hipError_t launch_fused_T(const AlignBatchDev& b, int cap, int lds_img_cap, int level_hi, int level_lo, size_t lds, hipStream_t stream) {
+static hipError_t launch_fused_T(const AlignBatchDev& b, int cap, int level_hi, int level_lo, size_t lds, hipStream_t stream) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_fused_kernel<T, PX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((align_fused_kernel<T, PX>), dim3(b.n_jobs), dim3(T), lds, stream, b, cap, lds_img_cap, level_hi, level_lo);
+  hipLaunchKernelGGL((align_fused_kernel<T, PX>), dim3(b.n_jobs), dim3(T), lds, stream, b, cap, level_hi, level_lo);
   return hipGetLastError();
 }
 
 template <int T>
-static hipError_t launch_fused_px(const AlignBatchDev& b, int cap, int lds_img_cap, int lds_px, int level_hi, int level_lo, size_t lds, hipStream_t stream) {
+static hipError_t launch_fused_px(const AlignBatchDev& b, int cap, int lds_px, int level_hi, int level_lo, size_t lds, hipStream_t stream) {
   switch (lds_px) {
-    case 0: return launch_fused_T<T, 0>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
-    case 1: return launch_fused_T<T, 1>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
-    case 3: return launch_fused_T<T, 3>(b, cap, lds_img_cap, level_hi, level_lo, lds, stream);
+    case 0: return launch_fused_T<T, 0>(b, cap, level_hi, level_lo, lds, stream);
+    case 1: return launch_fused_T<T, 1>(b, cap, level_hi, level_lo, lds, stream);
+    case 3: return launch_fused_T<T, 3>(b, cap, level_hi, level_lo, lds, stream);
     default: return hipErrorInvalidValue;
   }
 }
 
-hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int lds_img_cap, int lds_px, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream) {
+hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int lds_px, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream) {
   switch (threads) {
-    case 64: return launch_fused_px<64>(b, cap, lds_img_cap, lds_px, level_hi, level_lo, lds, stream);
-    case 128: return launch_fused_px<128>(b, cap, lds_img_cap, lds_px, level_hi, level_lo, lds, stream);
-    case 256: return launch_fused_px<256>(b, cap, lds_img_cap, lds_px, level_hi, level_lo, lds, stream);
-    case 512: return launch_fused_px<512>(b, cap, lds_img_cap, lds_px, level_hi, level_lo, lds, stream);
-    case 1024: return launch_fused_px<1024>(b, cap, lds_img_cap, lds_px, level_hi, level_lo, lds, stream);
+    case 64: return launch_fused_px<64>(b, cap, lds_px, level_hi, level_lo, lds, stream);
+    case 128: return launch_fused_px<128>(b, cap, lds_px, level_hi, level_lo, lds, stream);
+    case 256: return launch_fused_px<256>(b, cap, lds_px, level_hi, level_lo, lds, stream);
+    case 512: return launch_fused_px<512>(b, cap, lds_px, level_hi, level_lo, lds, stream);
+    case 1024: return launch_fused_px<1024>(b, cap, lds_px, level_hi, level_lo, lds, stream);
     default: return hipErrorInvalidValue;
   }
 }

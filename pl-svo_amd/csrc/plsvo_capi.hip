@@ -18,8 +18,8 @@
 
 namespace plsvo_hip {
 // kernels (align_kernels.hip, poseopt_kernels.hip, pyramid_kernels.hip)
-size_t align_level_lds_bytes(int threads, int cap, int lds_img_cap, int lds_px);
-hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int lds_img_cap, int lds_px, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream);
+size_t align_level_lds_bytes(int threads, int cap, int lds_px);
+hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int lds_px, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream);
 hipError_t launch_align_init(const AlignBatchDev& b, hipStream_t stream);
 hipError_t launch_align_finish(const AlignBatchDev& b, double* d_poses, hipStream_t stream);
 hipError_t launch_pose_opt(const PoseBatchDev& b, hipStream_t stream);
@@ -409,35 +409,21 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   return PLSVO_OK;
 }
 
-// Launch configuration of the alignment kernel.
-//   threads      256 (default): four workgroups share a CU when LDS stays below ~40 KB and VGPRs at 128, which
-//                hides the serial solve/update tail of one frame behind the pixel phases of the others.
-//   lds_img_cap  level images up to this many bytes are staged in LDS (default 20 KB: level >= 2 of 640x480),
-//                larger levels are gathered through L2.
-// Environment overrides (experiments only): PLSVO_ALIGN_THREADS, PLSVO_LDS_IMG_CAP, PLSVO_ALIGN_PER_LEVEL.
-static void pick_align_config(plsvo_ctx* c, int cap, int* threads, int* lds_img_cap, int* lds_px, size_t* lds) {
-  int t = 128, icap = 0;   // measured (round 1): staging even the small levels in LDS is ~2 % slower than gathering through L2
+// Launch configuration of the fused alignment kernel (measured on MI355X):
+//   threads  128 per workgroup (two waves per frame pair; four workgroups share a CU at ~230 VGPRs)
+//   lds_px   per-iteration patch sums (bit 0) and the patches' 3-D points (bit 1) live in LDS as long as the CU still
+//            holds as many workgroups as the VGPR budget allows: 160 KiB / (8 / waves-per-workgroup)
+// Environment overrides (experiments only): PLSVO_ALIGN_THREADS, PLSVO_ALIGN_LDS_PX, PLSVO_ALIGN_PER_LEVEL.
+static void pick_align_config(plsvo_ctx* c, int cap, int* threads, int* lds_px, size_t* lds) {
+  int t = 128;
   if (const char* s = getenv("PLSVO_ALIGN_THREADS")) { const int v = atoi(s); if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) t = v; }
-  if (const char* s = getenv("PLSVO_LDS_IMG_CAP")) icap = atoi(s);
-  if (const char* s = getenv("PLSVO_ALIGN_NO_LDS_IMG")) { if (atoi(s) != 0) icap = 0; }
-  icap = (std::max(icap, 0) + 15) & ~15;
-  // never stage more than the largest level that is actually used, and never exceed the LDS limit
-  int biggest = 0;
-  for (int l = c->a_gmin; l <= c->a_gmax && l >= 0; ++l) {
-    const int bytes = c->pyr.w[l] * c->pyr.h[l] + 16;
-    if (bytes <= icap) biggest = std::max(biggest, bytes);
-  }
-  icap = (biggest + 15) & ~15;
-  while (icap > 0 && align_level_lds_bytes(t, cap, icap, 0) > c->lds_per_block) icap = 0;
-  // Per-iteration patch sums (bit 0) and 3-D points (bit 1) go to LDS as long as the CU still holds as many
-  // workgroups as the VGPR budget allows (8 waves per CU at ~230 VGPRs): 160 KiB / (8 / waves-per-workgroup).
   const int wg_per_cu = std::max(1, 8 / std::max(1, t / 64));
   const size_t budget = (size_t)160 * 1024 / (size_t)wg_per_cu;
   int px = 0;
-  if (align_level_lds_bytes(t, cap, icap, 3) <= budget) px = 3;
-  else if (align_level_lds_bytes(t, cap, icap, 1) <= budget) px = 1;
-  if (const char* s = getenv("PLSVO_ALIGN_LDS_PX")) { const int v = atoi(s); if ((v == 0 || v == 1 || v == 3) && align_level_lds_bytes(t, cap, icap, v) <= c->lds_per_block) px = v; }
-  *threads = t; *lds_img_cap = icap; *lds_px = px; *lds = align_level_lds_bytes(t, cap, icap, px);
+  if (align_level_lds_bytes(t, cap, 3) <= budget) px = 3;
+  else if (align_level_lds_bytes(t, cap, 1) <= budget) px = 1;
+  if (const char* s = getenv("PLSVO_ALIGN_LDS_PX")) { const int v = atoi(s); if ((v == 0 || v == 1 || v == 3) && align_level_lds_bytes(t, cap, v) <= c->lds_per_block) px = v; }
+  *threads = t; *lds_px = px; *lds = align_level_lds_bytes(t, cap, px);
 }
 
 extern "C" int plsvo_align_run(plsvo_ctx* c) {
@@ -452,19 +438,19 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
   if (c->a_gmax >= c->a_gmin && c->a_gmax >= 0) {
     int cap = 4;
     for (int l = c->a_gmin; l <= c->a_gmax; ++l) cap = std::max(cap, c->a_cap[l]);
-    int threads, lds_img_cap, lds_px; size_t lds;
-    pick_align_config(c, cap, &threads, &lds_img_cap, &lds_px, &lds);
+    int threads, lds_px; size_t lds;
+    pick_align_config(c, cap, &threads, &lds_px, &lds);
     if (lds > c->lds_per_block) return fail(c, PLSVO_E_CAPACITY, "align_run: patch tables do not fit in LDS (too many features in one job)");
     bool per_level = false;
     if (const char* s = getenv("PLSVO_ALIGN_PER_LEVEL")) per_level = atoi(s) != 0;
     if (!per_level) {
       EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
-      HIP_TRY(c, launch_align_levels(c->a_b, cap, lds_img_cap, lds_px, c->a_gmax, c->a_gmin, threads, lds, c->stream));
+      HIP_TRY(c, launch_align_levels(c->a_b, cap, lds_px, c->a_gmax, c->a_gmin, threads, lds, c->stream));
       prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
     } else {
       for (int level = c->a_gmax; level >= c->a_gmin; --level) {
         EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
-        HIP_TRY(c, launch_align_levels(c->a_b, cap, lds_img_cap, lds_px, level, level, threads, lds, c->stream));
+        HIP_TRY(c, launch_align_levels(c->a_b, cap, lds_px, level, level, threads, lds, c->stream));
         prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
       }
     }

@@ -104,7 +104,6 @@ for T in (256, 512, 1024):
     ms, n = ctx.kernel_time(P.abi.K_ALIGN_LEVEL)
     print("threads %d: wall %.2f ms level kernels %.3f ms -> %.0f frames/s" % (T, dt * 1e3, ms, B / dt))
 del os.environ["PLSVO_ALIGN_THREADS"]
-os.environ["PLSVO_ALIGN_NO_LDS_IMG"] = "1"
 ctx.reset_profiling(); t0 = time.time(); ctx.align_run(); ctx.synchronize(); dt = time.time() - t0
 print("no LDS image: wall %.2f ms -> %.0f frames/s" % (dt * 1e3, B / dt))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

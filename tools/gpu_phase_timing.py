@@ -1,4 +1,4 @@
-"""Per-phase cycle breakdown of align_level_kernel (needs the instrumented build: make -C pl-svo_amd/csrc timing).
+"""Per-phase cycle breakdown of align_fused_kernel (needs the instrumented build: make -C pl-svo_amd/csrc timing).
 Runs BASELINE config 2 streams one pyramid level at a time and prints s_memtime ticks per phase, per iteration."""
 import ctypes as C, importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
