@@ -24,7 +24,10 @@ namespace plsvo_hip {
 #define PO_T 64    // one wave per frame: measured 0.46 ms vs 0.83 ms (256 threads) per 4096-frame batch -- no cross-wave work, 8 frames per CU
 #endif
 #define PO_RED 32
-#define PO_BINS 2048
+#ifndef PO_RADIX_BITS
+#define PO_RADIX_BITS 8    // bits per radix-select pass (measured on MI355X: 8 -> 0.72 ms, 11 -> 0.81 ms, 6 -> 0.74 ms per 8192 frames)
+#endif
+#define PO_BINS (1 << PO_RADIX_BITS)
 
 // k-th smallest (0-based) of n non-negative IEEE values given as unsigned bit patterns of BITS bits.
 // get(i) returns the pattern of element i (invalid elements must return all-ones).
@@ -34,7 +37,7 @@ __device__ U block_radix_select(GET get, int n, int k, int* s_hist, int* s_sel) 
   U prefix = 0, mask = 0;
   int shift = BITS;
   while (shift > 0) {
-    const int bits = shift >= 11 ? 11 : shift;
+    const int bits = shift >= PO_RADIX_BITS ? PO_RADIX_BITS : shift;
     shift -= bits;
     const int nb = 1 << bits;
     for (int i = tid; i < PO_BINS; i += PO_T) s_hist[i] = 0;
