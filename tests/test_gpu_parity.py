@@ -234,3 +234,32 @@ def test_full_size_properties(P, gpu_ctx):
     for a, c in zip(r1, r3):
         ang, dist = P.synth.se3_log_angle_dist(a.T, c.T)
         assert ang < 2e-4 and dist < 2e-3
+
+
+@pytest.mark.gpu
+def test_gather_poses_over_a_single_rank_rccl_communicator(P, gpu_ctx):
+    """plsvo_gather_poses (C ABI, ncclAllGather on the ctx stream) with a world of one rank: the only configuration a
+    1-GPU box can run.  The communicator comes straight from librccl through ctypes, as a C host would create it."""
+    import ctypes as C
+    import torch
+    rccl = C.CDLL("/opt/rocm/lib/librccl.so")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        local = torch.arange(5 * 7, dtype=torch.float64, device="cuda:0").reshape(5, 7) * 0.25
+        out = torch.zeros_like(local)
+        torch.cuda.synchronize()
+        gpu_ctx.gather_poses(comm.value, local.data_ptr(), 5, out.data_ptr())
+        gpu_ctx.synchronize()
+        assert torch.equal(out, local)
+        with pytest.raises(P.capi.PlsvoError):
+            gpu_ctx.gather_poses(None, local.data_ptr(), 5, out.data_ptr())
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
