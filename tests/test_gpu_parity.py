@@ -242,7 +242,12 @@ def test_gather_poses_over_a_single_rank_rccl_communicator(P, gpu_ctx):
     1-GPU box can run.  The communicator comes straight from librccl through ctypes, as a C host would create it."""
     import ctypes as C
     import torch
-    rccl = C.CDLL("/opt/rocm/lib/librccl.so")
+    # by SONAME: the instance the dynamic loader already bound libplsvo_hip.so to (torch ships its own librccl.so.1 and
+    # loads it first; a communicator made by a second copy of the library would be rejected as an invalid argument)
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        rccl = C.CDLL("/opt/rocm/lib/librccl.so")
 
     class UniqueId(C.Structure):
         _fields_ = [("internal", C.c_char * 128)]
