@@ -376,6 +376,78 @@ int plsvo_reproject(plsvo_ctx* ctx, const plsvo_reproject_in* in, plsvo_reprojec
 int plsvo_trajectory_record(const double T_f_w[7], const double cov[36], double out7[7]);
 
 /* ------------------------------------------------------------------------------------------ */
+/* depth-filter seed update (hot-path contract row (f) "next" #4, last item)                   */
+/* replaces the per-seed bodies of DepthFilter::updatePointSeeds / updateLineSeeds             */
+/* (src/depth_filter.cpp:270-368, :370-471) with everything they call:                         */
+/* Matcher::findEpipolarMatchDirect (src/matcher.cpp:276-416) and                              */
+/* findEpipolarMatchDirectSegmentEndpoint (:418-611), depthFromTriangulation (:132-145),       */
+/* [ext] vk::patch_score::ZMSSD<4>, DepthFilter::computeTau (src/depth_filter.cpp:604-620),    */
+/* updatePointSeed (:489-515), updateLineSeed (:517-576).                                      */
+/* The seed lists, the batch-age test (:290-293), the converged-seed callbacks and the         */
+/* detector's grid occupancy stay on the host; this call maps seed state -> seed state.        */
+/* ------------------------------------------------------------------------------------------ */
+
+#define PLSVO_SEED_NOT_VISIBLE 0    /* behind the camera or outside the image: unchanged (:298-305) */
+#define PLSVO_SEED_NO_MATCH    1    /* epipolar search failed: b += 1 (:313-319) */
+#define PLSVO_SEED_UPDATED     2    /* Bayesian update applied, seed stays */
+#define PLSVO_SEED_CONVERGED   3    /* updated and sqrt(sigma2) < z_range/thresh: the host creates the landmark from xyz_world and removes the seed (:335-358) */
+#define PLSVO_SEED_NAN         4    /* updated but z_inv_min was NaN: the host removes the seed (:359-363) */
+
+/* float fields are the reference's float members of PointSeed / LineSeed (include/plsvo/depth_filter.h:61-100).
+ * Point seed i: ref feature (frame pt_ref_frame[i], px, f, level, type, grad) + Beta/normal parameters.
+ * Line seed i: Feature::px / f (what the reference hands to the end-point search for BOTH end points, :404-407),
+ * LineFeat::sf / ef (used for visibility, tau and the landmark), level, and the two-ended parameters. */
+typedef struct plsvo_seeds_in {
+  plsvo_pinhole cam;
+  int32_t n_pyr_levels;             /* Config::nPyrLevels() */
+  int32_t align_max_iter;           /* Matcher::Options::align_max_iter (10) */
+  int32_t max_epi_search_steps;     /* Matcher::Options::max_epi_search_steps (1000) */
+  int32_t edgelet_filtering;        /* Matcher::Options::epi_search_edgelet_filtering (1) */
+  double edgelet_max_angle;         /* Matcher::Options::epi_search_edgelet_max_angle (0.7) */
+  double px_noise;                  /* 1.0 (:279) */
+  double convergence_sigma2_thresh; /* DepthFilter::Options::seed_convergence_sigma2_thresh (200.0) */
+  int32_t n_frames;
+  int32_t n_pt;
+  int32_t n_seg;
+  int32_t reserved0;
+  const double* frame_T;            /* 7*n_frames */
+  const int32_t* frame_slot;        /* n_frames */
+  /* point seeds */
+  const int32_t* pt_ref_frame;      /* n_pt: it->ftr->frame */
+  const int32_t* pt_cur_frame;      /* n_pt: the frame the seed is updated with */
+  const double* pt_px;              /* 2*n_pt */
+  const double* pt_f;               /* 3*n_pt */
+  const int32_t* pt_level;          /* n_pt */
+  const uint8_t* pt_type;           /* n_pt PLSVO_FTR_* */
+  const double* pt_grad;            /* 2*n_pt (edgelets; may be NULL without edgelets) */
+  const float* pt_a; const float* pt_b; const float* pt_mu; const float* pt_z_range; const float* pt_sigma2;
+  /* line seeds */
+  const int32_t* seg_ref_frame;
+  const int32_t* seg_cur_frame;
+  const double* seg_px;             /* 2*n_seg Feature::px */
+  const double* seg_f;              /* 3*n_seg Feature::f  */
+  const double* seg_sf;             /* 3*n_seg */
+  const double* seg_ef;             /* 3*n_seg */
+  const int32_t* seg_level;
+  const float* seg_a; const float* seg_b; const float* seg_mu_s; const float* seg_mu_e;
+  const float* seg_z_range_s; const float* seg_z_range_e; const float* seg_sigma2_s; const float* seg_sigma2_e;
+} plsvo_seeds_in;
+
+typedef struct plsvo_seeds_out {     /* caller buffers; any of them may be NULL */
+  int32_t* pt_status;               /* n_pt PLSVO_SEED_* */
+  float* pt_a; float* pt_b; float* pt_mu; float* pt_sigma2;
+  double* pt_xyz_world;             /* 3*n_pt, valid for PLSVO_SEED_CONVERGED */
+  double* pt_px_cur;                /* 2*n_pt Matcher::px_cur_ after a successful match (for setGridOccpuancy, :330-333) */
+  double* pt_depth;                 /* n_pt   the triangulated depth z of a successful match */
+  int32_t* seg_status;
+  float* seg_a; float* seg_b; float* seg_mu_s; float* seg_mu_e; float* seg_sigma2_s; float* seg_sigma2_e;
+  double* seg_xyz_world_s; double* seg_xyz_world_e;   /* 3*n_seg each */
+  double* seg_depth_s; double* seg_depth_e;           /* n_seg each */
+} plsvo_seeds_out;
+
+int plsvo_update_seeds(plsvo_ctx* ctx, const plsvo_seeds_in* in, plsvo_seeds_out* out);
+
+/* ------------------------------------------------------------------------------------------ */
 /* multi-GPU: gather of per-stream pose records (new; the reference is single-process)         */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -394,7 +466,8 @@ int plsvo_gather_poses(plsvo_ctx* ctx, void* rccl_comm, const double* d_local, i
 #define PLSVO_K_HALFSAMPLE    3
 #define PLSVO_K_STRUCTOPT     4
 #define PLSVO_K_MATCH         5
-#define PLSVO_K_COUNT         6
+#define PLSVO_K_SEEDS         6
+#define PLSVO_K_COUNT         7
 int plsvo_hip_set_profiling(plsvo_ctx* ctx, int enable);
 /* accumulated GPU time and launch count of kernel family k since the last reset (synchronises) */
 int plsvo_hip_kernel_time(plsvo_ctx* ctx, int k, double* total_ms, int64_t* launches);

@@ -58,6 +58,8 @@ def lib():
         L.plsvo_oracle_reproject.argtypes = [C.POINTER(abi.ReprojectIn), C.POINTER(abi.ReprojectOut)]
         L.plsvo_oracle_trajectory_record.restype = C.c_int
         L.plsvo_oracle_trajectory_record.argtypes = [abi.c_double_p, abi.c_double_p, abi.c_double_p]
+        L.plsvo_oracle_update_seeds.restype = C.c_int
+        L.plsvo_oracle_update_seeds.argtypes = [C.POINTER(abi.SeedsIn), C.POINTER(OraclePyr), C.POINTER(abi.SeedsOut)]
         L.plsvo_oracle_halfsample.restype = None
         L.plsvo_oracle_halfsample.argtypes = [abi.c_u8_p, C.c_int, C.c_int, C.c_int, abi.c_u8_p, C.c_int, C.c_int]
         d = abi.c_double_p
@@ -185,6 +187,20 @@ def trajectory_record(T_f_w, cov):
     out = np.empty(7)
     ok = lib().plsvo_oracle_trajectory_record(_dp(T), _dp(Cv), _dp(out))
     return bool(ok), out
+
+
+def update_seeds(job, frame_levels):
+    pyrs = (OraclePyr * len(frame_levels))()
+    keep = []
+    for k, levels in enumerate(frame_levels):
+        p, kk = make_pyr(levels)
+        pyrs[k] = p
+        keep.append(kk)
+    out, bufs = job.make_out()
+    rc = lib().plsvo_oracle_update_seeds(C.byref(job.c), pyrs, C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"oracle update_seeds failed rc={rc}")
+    return job.trim(bufs)
 
 
 # --- small helpers for unit tests -------------------------------------------------------------

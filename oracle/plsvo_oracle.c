@@ -1295,3 +1295,346 @@ int plsvo_oracle_trajectory_record(const double T_f_w[7], const double cov[36], 
   out7[0] = W.t[0]; out7[1] = W.t[1]; out7[2] = W.t[2]; out7[3] = W.q.x; out7[4] = W.q.y; out7[5] = W.q.z; out7[6] = W.q.w;
   return skip_frame ? 0 : 1;
 }
+
+/* ============================================================================================ */
+/* depth-filter seed update: DepthFilter::updatePointSeeds / updateLineSeeds (src/depth_filter.cpp:270-471) */
+/* ============================================================================================ */
+
+/* [ext] vk::patch_score::ZMSSD<4> (vikit/patch_score.h): zero-mean SSD of two 8x8 u8 patches, all integer */
+typedef struct { const uint8_t* ref_patch; int sumA, sumAA; } zmssd_t;
+static void zmssd_init(zmssd_t* z, const uint8_t* ref_patch) {
+  uint32_t sumA_uint = 0, sumAA_uint = 0;
+  for (int r = 0; r < M_AREA; ++r) { const uint8_t n = ref_patch[r]; sumA_uint += n; sumAA_uint += n * n; }
+  z->ref_patch = ref_patch; z->sumA = (int)sumA_uint; z->sumAA = (int)sumAA_uint;
+}
+static int zmssd_threshold(void) { return 2000 * M_AREA; }
+static int zmssd_score(const zmssd_t* z, const uint8_t* cur_patch, int stride) {
+  uint32_t sumB_uint = 0, sumBB_uint = 0, sumAB_uint = 0;
+  for (int y = 0, r = 0; y < M_PATCH; ++y) {
+    const uint8_t* cur_patch_ptr = cur_patch + (ptrdiff_t)y * stride;
+    for (int x = 0; x < M_PATCH; ++x, ++r) {
+      const uint8_t cur_px = cur_patch_ptr[x];
+      sumB_uint += cur_px; sumBB_uint += cur_px * cur_px; sumAB_uint += cur_px * z->ref_patch[r];
+    }
+  }
+  const int sumB = (int)sumB_uint, sumBB = (int)sumBB_uint, sumAB = (int)sumAB_uint;
+  return z->sumAA - 2 * sumAB + sumBB - (z->sumA * z->sumA - 2 * z->sumA * sumB + sumB * sumB) / M_AREA;
+}
+
+/* depthFromTriangulation (src/matcher.cpp:132-145) */
+static int depth_from_triangulation(const se3_t* T_search_ref, const double f_ref[3], const double f_cur[3], double* depth) {
+  double R[9], c0[3];
+  quat_to_matrix(T_search_ref->q, R);                       /* rotation_matrix() * f_ref */
+  for (int i = 0; i < 3; ++i) c0[i] = R[3 * i] * f_ref[0] + R[3 * i + 1] * f_ref[1] + R[3 * i + 2] * f_ref[2];
+  /* AtA = A^T A with A = [c0, f_cur] */
+  const double a00 = c0[0] * c0[0] + c0[1] * c0[1] + c0[2] * c0[2];
+  const double a01 = c0[0] * f_cur[0] + c0[1] * f_cur[1] + c0[2] * f_cur[2];
+  const double a11 = f_cur[0] * f_cur[0] + f_cur[1] * f_cur[1] + f_cur[2] * f_cur[2];
+  const double a10 = a01;
+  const double det = a00 * a11 - a10 * a01;
+  if (det < 0.000001) return 0;
+  const double invdet = 1.0 / det;
+  /* (-AtA.inverse()) * A^T * t : row 0 of the 2x3 product, then the dot product with the translation */
+  const double i00 = -(a11 * invdet), i01 = -(-a01 * invdet);
+  const double m0 = i00 * c0[0] + i01 * f_cur[0], m1 = i00 * c0[1] + i01 * f_cur[1], m2 = i00 * c0[2] + i01 * f_cur[2];
+  const double d0 = m0 * T_search_ref->t[0] + m1 * T_search_ref->t[1] + m2 * T_search_ref->t[2];
+  *depth = fabs(d0);
+  return 1;
+}
+
+/* Matcher::findEpipolarMatchDirect (src/matcher.cpp:276-416; segment_endpoint == 0) and
+ * findEpipolarMatchDirectSegmentEndpoint (:418-611; segment_endpoint == 1).  Returns 1 on success. */
+typedef struct { double px_cur[2]; int search_level; int reject; int n_evals; } epi_out_t;
+static int find_epipolar_match_direct(const plsvo_seeds_in* in, const plsvo_oracle_pyr* frames, int rf, int cf, const double px_ref[2],
+                                      const double f_ref[3], int level, int type, const double grad[2], double d_estimate,
+                                      double d_min, double d_max, int segment_endpoint, double* depth, epi_out_t* eo) {
+  const int halfpatch_size_ = 4, patch_size_ = 8;
+  eo->px_cur[0] = eo->px_cur[1] = 0.0; eo->search_level = -1; eo->reject = 0; eo->n_evals = 0;
+  const se3_t T_ref = se3_load(in->frame_T + 7 * rf), T_cur = se3_load(in->frame_T + 7 * cf);
+  const se3_t T_ref_inv = se3_inv(&T_ref);
+  const se3_t T_cur_ref = se3_mul(&T_cur, &T_ref_inv);
+  int zmssd_best = zmssd_threshold();
+  double uv_best[2] = { 0.0, 0.0 };
+  if (segment_endpoint && (isnan(d_min) || isnan(d_max))) { eo->reject = 1; return 0; }         /* :433-437 */
+  /* epipolar segment on the unit plane: A = project2d(T * (f*d_min)), B = project2d(T * (f*d_max)) */
+  double pa[3] = { f_ref[0] * d_min, f_ref[1] * d_min, f_ref[2] * d_min }, pb[3] = { f_ref[0] * d_max, f_ref[1] * d_max, f_ref[2] * d_max };
+  double ca[3], cb[3], A[2], B[2];
+  se3_act(&T_cur_ref, pa, ca); se3_act(&T_cur_ref, pb, cb);
+  project2d(ca, A); project2d(cb, B);
+  const double epi_dir[2] = { A[0] - B[0], A[1] - B[1] };
+  double Aw[4];
+  warp_matrix_affine(&in->cam, px_ref, f_ref, d_estimate, &T_cur_ref, level, Aw);
+  if (!segment_endpoint && type == PLSVO_FTR_EDGELET && in->edgelet_filtering) {                 /* :300-310 */
+    double g[2] = { Aw[0] * grad[0] + Aw[1] * grad[1], Aw[2] * grad[0] + Aw[3] * grad[1] };
+    const double gn = sqrt(g[0] * g[0] + g[1] * g[1]);
+    g[0] /= gn; g[1] /= gn;
+    const double en = sqrt(epi_dir[0] * epi_dir[0] + epi_dir[1] * epi_dir[1]);
+    const double cosangle = fabs(g[0] * (epi_dir[0] / en) + g[1] * (epi_dir[1] / en));
+    if (cosangle < in->edgelet_max_angle) { eo->reject = 1; return 0; }
+  }
+  const int search_level = best_search_level(Aw, in->n_pyr_levels - 1);
+  eo->search_level = search_level;
+  double uvA[3] = { A[0], A[1], 1.0 }, uvB[3] = { B[0], B[1], 1.0 }, px_A[2], px_B[2];
+  plsvo_oracle_world2cam(&in->cam, uvA, px_A);          /* world2cam(Vector2d uv) = (fx*u + cx, fy*v + cy) */
+  plsvo_oracle_world2cam(&in->cam, uvB, px_B);
+  const double dA[2] = { px_A[0] - px_B[0], px_A[1] - px_B[1] };
+  const double epi_length = sqrt(dA[0] * dA[0] + dA[1] * dA[1]) / (1 << search_level);
+  /* :460-464 (segments) reject NaN/inf before the warp; for points the reference runs into the step loop with an
+   * undefined n_steps (:352) -- both are reported as "no match" here */
+  if (isnan(epi_length) || isinf(epi_length)) { if (segment_endpoint) eo->reject = 1; return 0; }
+  uint8_t patch_with_border[M_STEP * M_STEP], patch[M_AREA];
+  const plsvo_oracle_pyr* rp = &frames[rf];
+  const plsvo_oracle_pyr* cp = &frames[cf];
+  if (!warp_affine(Aw, rp->img[level], rp->width[level], rp->height[level], rp->stride[level], px_ref, level, search_level,
+                   halfpatch_size_ + 1, patch_with_border)) return 0;
+  for (int y = 1; y < M_PATCH + 1; ++y) for (int x = 0; x < M_PATCH; ++x) patch[(y - 1) * M_PATCH + x] = patch_with_border[y * M_STEP + 1 + x];
+  const uint8_t* cimg = cp->img[search_level];
+  const int ccols = cp->width[search_level], crows = cp->height[search_level], cstride = cp->stride[search_level];
+  const double sc = (double)(1 << search_level);
+  int iters = 0;
+  if (epi_length < 2.0) {                                                                        /* :331-350 */
+    double px_scaled[2] = { ((px_A[0] + px_B[0]) / 2.0) / sc, ((px_A[1] + px_B[1]) / 2.0) / sc };
+    eo->px_cur[0] = (px_A[0] + px_B[0]) / 2.0; eo->px_cur[1] = (px_A[1] + px_B[1]) / 2.0;
+    if (align_2d(cimg, ccols, crows, cstride, patch_with_border, patch, in->align_max_iter, px_scaled, &iters)) {
+      eo->px_cur[0] = px_scaled[0] * sc; eo->px_cur[1] = px_scaled[1] * sc;
+      double f_cur[3];
+      plsvo_oracle_cam2world(&in->cam, eo->px_cur, f_cur);
+      if (depth_from_triangulation(&T_cur_ref, f_ref, f_cur, depth)) return 1;
+    }
+    return 0;
+  }
+  size_t n_steps = (size_t)(epi_length / 0.7);                                                    /* :352 */
+  const double step[2] = { epi_dir[0] / (double)n_steps, epi_dir[1] / (double)n_steps };
+  if (n_steps > (size_t)in->max_epi_search_steps) return 0;                                       /* :355-360 */
+  zmssd_t score;
+  zmssd_init(&score, patch);
+  double uv[2] = { B[0] - step[0], B[1] - step[1] };
+  int last_x = 0, last_y = 0;
+  ++n_steps;
+  for (size_t i = 0; i < n_steps; ++i, uv[0] += step[0], uv[1] += step[1]) {
+    const double px0 = in->cam.fx * uv[0] + in->cam.cx, px1 = in->cam.fy * uv[1] + in->cam.cy;
+    const double q0 = px0 / (1 << search_level) + 0.5, q1 = px1 / (1 << search_level) + 0.5;
+    if (!(fabs(q0) < 1e9 && fabs(q1) < 1e9)) continue;       /* the int cast of NaN / huge values is undefined: treated as out of frame */
+    const int pxi0 = (int)q0, pxi1 = (int)q1;
+    if (pxi0 == last_x && pxi1 == last_y) continue;
+    last_x = pxi0; last_y = pxi1;
+    if (!cam_is_in_frame(&in->cam, pxi0, pxi1, patch_size_, search_level)) continue;
+    /* the reference indexes with img.cols (:383-385); the pyramids here are tight (cols == step) */
+    const uint8_t* cur_patch_ptr = cimg + (ptrdiff_t)(pxi1 - halfpatch_size_) * cstride + (pxi0 - halfpatch_size_);
+    const int z = zmssd_score(&score, cur_patch_ptr, cstride);
+    eo->n_evals += 1;
+    if (z < zmssd_best) { zmssd_best = z; uv_best[0] = uv[0]; uv_best[1] = uv[1]; }
+  }
+  if (zmssd_best < zmssd_threshold()) {                                                           /* :394-414 subpix_refinement = true */
+    eo->px_cur[0] = in->cam.fx * uv_best[0] + in->cam.cx; eo->px_cur[1] = in->cam.fy * uv_best[1] + in->cam.cy;
+    double px_scaled[2] = { eo->px_cur[0] / sc, eo->px_cur[1] / sc };
+    if (align_2d(cimg, ccols, crows, cstride, patch_with_border, patch, in->align_max_iter, px_scaled, &iters)) {
+      eo->px_cur[0] = px_scaled[0] * sc; eo->px_cur[1] = px_scaled[1] * sc;
+      double f_cur[3];
+      plsvo_oracle_cam2world(&in->cam, eo->px_cur, f_cur);
+      if (depth_from_triangulation(&T_cur_ref, f_ref, f_cur, depth)) return 1;
+    }
+    return 0;
+  }
+  return 0;
+}
+
+/* DepthFilter::computeTau (src/depth_filter.cpp:604-620) */
+static double compute_tau(const se3_t* T_ref_cur, const double f[3], double z, double px_error_angle) {
+  const double* t = T_ref_cur->t;
+  const double a[3] = { f[0] * z - t[0], f[1] * z - t[1], f[2] * z - t[2] };
+  const double t_norm = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+  const double a_norm = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+  const double alpha = acos((f[0] * t[0] + f[1] * t[1] + f[2] * t[2]) / t_norm);
+  const double beta = acos((a[0] * -t[0] + a[1] * -t[1] + a[2] * -t[2]) / (t_norm * a_norm));
+  const double beta_plus = beta + px_error_angle;
+  const double gamma_plus = 3.14159265 - alpha - beta_plus;    /* PI as defined in include/plsvo/global.h */
+  const double z_plus = t_norm * sin(beta_plus) / sin(gamma_plus);
+  return z_plus - z;
+}
+
+/* [ext] boost::math::pdf(normal_distribution<float>(mean, sd), x) */
+static float normal_pdf_f(float mean, float sd, float x) {
+  if (isinf(x)) return 0.0f;
+  float exponent = x - mean;
+  exponent *= -exponent;
+  exponent /= 2 * sd * sd;
+  float result = expf(exponent);
+  result /= sd * sqrtf(2 * 3.14159265358979323846f);
+  return result;
+}
+
+/* one end of the Vogiatzis-Hernandez update: the common text of updatePointSeed (:489-515) and of the two halves of
+ * updateLineSeed (:517-560).  Returns f and e through pointers; mu/sigma2 are updated in place. */
+static void seed_update_end(float x, float tau2, float a, float b, float z_range, float* mu, float* sigma2, float norm_scale, float* f_out, float* e_out) {
+  const float pdf = normal_pdf_f(*mu, norm_scale, x);
+  float s2 = 1. / (1. / *sigma2 + 1. / tau2);
+  float m = s2 * (*mu / *sigma2 + x / tau2);
+  float C1 = a / (a + b) * pdf;
+  float C2 = b / (a + b) * 1. / z_range;
+  float normalization_constant = C1 + C2;
+  C1 /= normalization_constant;
+  C2 /= normalization_constant;
+  float f = C1 * (a + 1.) / (a + b + 1.) + C2 * a / (a + b + 1.);
+  float e = C1 * (a + 1.) * (a + 2.) / ((a + b + 1.) * (a + b + 2.)) + C2 * a * (a + 1.0f) / ((a + b + 1.0f) * (a + b + 2.0f));
+  float mu_new = C1 * m + C2 * *mu;
+  *sigma2 = C1 * (s2 + m * m) + C2 * (*sigma2 + *mu * *mu) - mu_new * mu_new;
+  *mu = mu_new;
+  *f_out = f; *e_out = e;
+}
+
+int plsvo_oracle_update_seeds(const plsvo_seeds_in* in, const plsvo_oracle_pyr* frames, plsvo_seeds_out* out) {
+  if (!in || !out || !frames || in->n_pt < 0 || in->n_seg < 0 || in->n_frames <= 0) return PLSVO_E_INVALID;
+  const double focal_length = fabs(in->cam.fx);                                  /* errorMultiplier2() */
+  const double px_error_angle = atan(in->px_noise / (2.0 * focal_length)) * 2.0; /* :279-280 */
+  for (int i = 0; i < in->n_pt; ++i) {
+    float a = in->pt_a[i], b = in->pt_b[i], mu = in->pt_mu[i], sigma2 = in->pt_sigma2[i];
+    const float z_range = in->pt_z_range[i];
+    int status = PLSVO_SEED_NOT_VISIBLE;
+    double xyz_world[3] = { 0, 0, 0 }, z = 0.0;
+    epi_out_t eo; eo.px_cur[0] = eo.px_cur[1] = 0.0;
+    const int rf = in->pt_ref_frame[i], cf = in->pt_cur_frame[i];
+    const double* f = in->pt_f + 3 * i;
+    const se3_t T_ref = se3_load(in->frame_T + 7 * rf), T_cur = se3_load(in->frame_T + 7 * cf);
+    const se3_t T_cur_inv = se3_inv(&T_cur);
+    const se3_t T_ref_cur = se3_mul(&T_ref, &T_cur_inv);                         /* :296 */
+    const se3_t T_cur_ref = se3_inv(&T_ref_cur);
+    const double s = 1.0 / mu;
+    const double p[3] = { s * f[0], s * f[1], s * f[2] };
+    double xyz_f[3], px[2];
+    se3_act(&T_cur_ref, p, xyz_f);                                               /* :297 */
+    int visible = !(xyz_f[2] < 0.0);
+    if (visible) {
+      plsvo_oracle_world2cam(&in->cam, xyz_f, px);
+      visible = px[0] == px[0] && px[1] == px[1] && fabs(px[0]) < 1e9 && fabs(px[1]) < 1e9 && cam_is_in_frame(&in->cam, (int)px[0], (int)px[1], 0, 0);
+    }
+    if (visible) {
+      const float z_inv_min = mu + sqrtf(sigma2);
+      const float t_ = mu - sqrtf(sigma2);
+      const float z_inv_max = t_ > 0.00000001f ? t_ : 0.00000001f;               /* max(a, b) = (a < b) ? b : a */
+      const double g0[2] = { 0, 0 };
+      if (!find_epipolar_match_direct(in, frames, rf, cf, in->pt_px + 2 * i, f, in->pt_level[i], in->pt_type[i],
+                                      in->pt_grad ? in->pt_grad + 2 * i : g0, 1.0 / mu, 1.0 / z_inv_min, 1.0 / z_inv_max, 0, &z, &eo)) {
+        b += 1.0f;                                                               /* it->b++ :315 */
+        status = PLSVO_SEED_NO_MATCH;
+      } else {
+        const double tau = compute_tau(&T_ref_cur, f, z, px_error_angle);
+        const double zm = z - tau;
+        const double tau_inverse = 0.5 * (1.0 / (0.0000001 < zm ? zm : 0.0000001) - 1.0 / (z + tau));
+        /* updatePointSeed(1./z, tau_inverse*tau_inverse, &*it) :489-515 */
+        const float x = (float)(1. / z), tau2 = (float)(tau_inverse * tau_inverse);
+        const float norm_scale = sqrtf(sigma2 + tau2);
+        if (!isnan(norm_scale)) {
+          float fq, eq;
+          seed_update_end(x, tau2, a, b, z_range, &mu, &sigma2, norm_scale, &fq, &eq);
+          a = (eq - fq) / (fq - eq / fq);
+          b = a * (1.0f - fq) / fq;
+        }
+        status = PLSVO_SEED_UPDATED;
+        if (sqrtf(sigma2) < z_range / in->convergence_sigma2_thresh) {            /* :335 */
+          const double sw = 1.0 / mu;
+          const double pw[3] = { f[0] * sw, f[1] * sw, f[2] * sw };
+          const se3_t T_ref_inv = se3_inv(&T_ref);                              /* :338 */
+          se3_act(&T_ref_inv, pw, xyz_world);
+          status = PLSVO_SEED_CONVERGED;
+        } else if (isnan(z_inv_min)) {
+          status = PLSVO_SEED_NAN;
+        }
+      }
+    }
+    if (out->pt_status) out->pt_status[i] = status;
+    if (out->pt_a) out->pt_a[i] = a;
+    if (out->pt_b) out->pt_b[i] = b;
+    if (out->pt_mu) out->pt_mu[i] = mu;
+    if (out->pt_sigma2) out->pt_sigma2[i] = sigma2;
+    if (out->pt_xyz_world) for (int k = 0; k < 3; ++k) out->pt_xyz_world[3 * i + k] = xyz_world[k];
+    if (out->pt_px_cur) { out->pt_px_cur[2 * i] = eo.px_cur[0]; out->pt_px_cur[2 * i + 1] = eo.px_cur[1]; }
+    if (out->pt_depth) out->pt_depth[i] = z;
+  }
+  /* ---- line seeds: updateLineSeeds :370-471 ---- */
+  for (int i = 0; i < in->n_seg; ++i) {
+    float a = in->seg_a[i], b = in->seg_b[i], mu_s = in->seg_mu_s[i], mu_e = in->seg_mu_e[i];
+    float sigma2_s = in->seg_sigma2_s[i], sigma2_e = in->seg_sigma2_e[i];
+    const float z_range_s = in->seg_z_range_s[i], z_range_e = in->seg_z_range_e[i];
+    int status = PLSVO_SEED_NOT_VISIBLE;
+    double xw_s[3] = { 0, 0, 0 }, xw_e[3] = { 0, 0, 0 }, z_s = 0.0, z_e = 0.0;
+    const int rf = in->seg_ref_frame[i], cf = in->seg_cur_frame[i];
+    const double* sf = in->seg_sf + 3 * i;
+    const double* ef = in->seg_ef + 3 * i;
+    const se3_t T_ref = se3_load(in->frame_T + 7 * rf), T_cur = se3_load(in->frame_T + 7 * cf);
+    const se3_t T_cur_inv = se3_inv(&T_cur);
+    const se3_t T_ref_cur = se3_mul(&T_ref, &T_cur_inv);
+    const se3_t T_cur_ref = se3_inv(&T_ref_cur);
+    const double ss = 1.0 / mu_s, se = 1.0 / mu_e;
+    const double ps[3] = { ss * sf[0], ss * sf[1], ss * sf[2] }, pe[3] = { se * ef[0], se * ef[1], se * ef[2] };
+    double xs[3], xe[3], pxs[2], pxe[2];
+    se3_act(&T_cur_ref, ps, xs); se3_act(&T_cur_ref, pe, xe);                    /* :393-394 */
+    int visible = !(xs[2] < 0.0 || xe[2] < 0.0);
+    if (visible) {
+      plsvo_oracle_world2cam(&in->cam, xs, pxs); plsvo_oracle_world2cam(&in->cam, xe, pxe);
+      visible = pxs[0] == pxs[0] && pxs[1] == pxs[1] && fabs(pxs[0]) < 1e9 && fabs(pxs[1]) < 1e9 && cam_is_in_frame(&in->cam, (int)pxs[0], (int)pxs[1], 0, 0) &&
+                pxe[0] == pxe[0] && pxe[1] == pxe[1] && fabs(pxe[0]) < 1e9 && fabs(pxe[1]) < 1e9 && cam_is_in_frame(&in->cam, (int)pxe[0], (int)pxe[1], 0, 0);
+    }
+    if (visible) {
+      const float z_inv_min_s = mu_s + sqrtf(sigma2_s);
+      const float ts_ = mu_s - sqrtf(sigma2_s);
+      const float z_inv_max_s = ts_ > 0.00000001f ? ts_ : 0.00000001f;
+      const float z_inv_min_e = mu_e + sqrtf(sigma2_e);
+      const float te_ = mu_e - sqrtf(sigma2_e);
+      const float z_inv_max_e = te_ > 0.00000001f ? te_ : 0.00000001f;
+      const double g0[2] = { 0, 0 };
+      epi_out_t eo;
+      /* both searches take Feature::px / Feature::f of the segment feature (*it->ftr), :404-407; the second is not
+       * evaluated when the first fails */
+      if (!find_epipolar_match_direct(in, frames, rf, cf, in->seg_px + 2 * i, in->seg_f + 3 * i, in->seg_level[i], PLSVO_FTR_CORNER, g0,
+                                      1.0 / mu_s, 1.0 / z_inv_min_s, 1.0 / z_inv_max_s, 1, &z_s, &eo) ||
+          !find_epipolar_match_direct(in, frames, rf, cf, in->seg_px + 2 * i, in->seg_f + 3 * i, in->seg_level[i], PLSVO_FTR_CORNER, g0,
+                                      1.0 / mu_e, 1.0 / z_inv_min_e, 1.0 / z_inv_max_e, 1, &z_e, &eo)) {
+        b += 1.0f;
+        status = PLSVO_SEED_NO_MATCH;
+      } else {
+        const double tau_s = compute_tau(&T_ref_cur, sf, z_s, px_error_angle);
+        const double zms = z_s - tau_s;
+        const double tau_inverse_s = 0.5 * (1.0 / (0.0000001 < zms ? zms : 0.0000001) - 1.0 / (z_s + tau_s));
+        const double tau_e = compute_tau(&T_ref_cur, ef, z_e, px_error_angle);
+        const double zme = z_e - tau_e;
+        const double tau_inverse_e = 0.5 * (1.0 / (0.0000001 < zme ? zme : 0.0000001) - 1.0 / (z_e + tau_e));
+        /* updateLineSeed :517-576 */
+        const float x_s = (float)(1. / z_s), tau2_s = (float)(tau_inverse_s * tau_inverse_s);
+        const float x_e = (float)(1. / z_e), tau2_e = (float)(tau_inverse_e * tau_inverse_e);
+        const float norm_scale_s = sqrtf(sigma2_s + tau2_s), norm_scale_e = sqrtf(sigma2_e + tau2_e);
+        if (!(isnan(norm_scale_s) || isnan(norm_scale_e))) {
+          float f_s, e_s, f_e, e_e;
+          seed_update_end(x_s, tau2_s, a, b, z_range_s, &mu_s, &sigma2_s, norm_scale_s, &f_s, &e_s);
+          seed_update_end(x_e, tau2_e, a, b, z_range_e, &mu_e, &sigma2_e, norm_scale_e, &f_e, &e_e);
+          const float a_s = (e_s - f_s) / (f_s - e_s / f_s), a_e = (e_e - f_e) / (f_e - e_e / f_e);
+          const float b_s = a_s * (1.f - f_s) / f_s, b_e = a_e * (1.f - f_e) / f_e;
+          a = (a_s < a_e) ? a_e : a_s;                                           /* std::max(a_s, a_e) */
+          b = (b_e < b_s) ? b_e : b_s;                                           /* std::min(b_s, b_e) */
+        }
+        status = PLSVO_SEED_UPDATED;
+        if (sqrtf(sigma2_s) < z_range_s / in->convergence_sigma2_thresh && sqrtf(sigma2_e) < z_range_e / in->convergence_sigma2_thresh) {
+          const se3_t T_ref_inv = se3_inv(&T_ref);
+          const double ws = 1.0 / mu_s, we = 1.0 / mu_e;
+          const double pws[3] = { sf[0] * ws, sf[1] * ws, sf[2] * ws }, pwe[3] = { ef[0] * we, ef[1] * we, ef[2] * we };
+          se3_act(&T_ref_inv, pws, xw_s); se3_act(&T_ref_inv, pwe, xw_e);
+          status = PLSVO_SEED_CONVERGED;
+        } else if (isnan(z_inv_min_s) || isnan(z_inv_min_e)) {
+          status = PLSVO_SEED_NAN;
+        }
+      }
+    }
+    if (out->seg_status) out->seg_status[i] = status;
+    if (out->seg_a) out->seg_a[i] = a;
+    if (out->seg_b) out->seg_b[i] = b;
+    if (out->seg_mu_s) out->seg_mu_s[i] = mu_s;
+    if (out->seg_mu_e) out->seg_mu_e[i] = mu_e;
+    if (out->seg_sigma2_s) out->seg_sigma2_s[i] = sigma2_s;
+    if (out->seg_sigma2_e) out->seg_sigma2_e[i] = sigma2_e;
+    if (out->seg_xyz_world_s) for (int k = 0; k < 3; ++k) out->seg_xyz_world_s[3 * i + k] = xw_s[k];
+    if (out->seg_xyz_world_e) for (int k = 0; k < 3; ++k) out->seg_xyz_world_e[3 * i + k] = xw_e[k];
+    if (out->seg_depth_s) out->seg_depth_s[i] = z_s;
+    if (out->seg_depth_e) out->seg_depth_e[i] = z_e;
+  }
+  return PLSVO_OK;
+}

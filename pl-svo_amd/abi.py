@@ -18,7 +18,8 @@ c_i32_p = C.POINTER(C.c_int32)
 OK, E_INVALID, E_NODEVICE, E_HIP, E_CAPACITY, E_STATE, E_RCCL = 0, -1, -2, -3, -4, -5, -6
 
 # kernel families for plsvo_hip_kernel_time
-K_ALIGN_INIT, K_ALIGN_LEVEL, K_POSEOPT, K_HALFSAMPLE, K_STRUCTOPT, K_MATCH, K_COUNT = 0, 1, 2, 3, 4, 5, 6
+K_ALIGN_INIT, K_ALIGN_LEVEL, K_POSEOPT, K_HALFSAMPLE, K_STRUCTOPT, K_MATCH, K_SEEDS, K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
+SEED_NOT_VISIBLE, SEED_NO_MATCH, SEED_UPDATED, SEED_CONVERGED, SEED_NAN = 0, 1, 2, 3, 4
 FTR_CORNER, FTR_EDGELET = 0, 1
 
 
@@ -101,6 +102,31 @@ class ReprojectIn(C.Structure):
 
 class ReprojectOut(C.Structure):
     _fields_ = [("px", c_double_p), ("cell", c_i32_p)]
+
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class SeedsIn(C.Structure):
+    _fields_ = [("cam", Pinhole), ("n_pyr_levels", C.c_int32), ("align_max_iter", C.c_int32), ("max_epi_search_steps", C.c_int32),
+                ("edgelet_filtering", C.c_int32), ("edgelet_max_angle", C.c_double), ("px_noise", C.c_double),
+                ("convergence_sigma2_thresh", C.c_double), ("n_frames", C.c_int32), ("n_pt", C.c_int32), ("n_seg", C.c_int32),
+                ("reserved0", C.c_int32), ("frame_T", c_double_p), ("frame_slot", c_i32_p),
+                ("pt_ref_frame", c_i32_p), ("pt_cur_frame", c_i32_p), ("pt_px", c_double_p), ("pt_f", c_double_p), ("pt_level", c_i32_p),
+                ("pt_type", c_u8_p), ("pt_grad", c_double_p), ("pt_a", c_float_p), ("pt_b", c_float_p), ("pt_mu", c_float_p),
+                ("pt_z_range", c_float_p), ("pt_sigma2", c_float_p),
+                ("seg_ref_frame", c_i32_p), ("seg_cur_frame", c_i32_p), ("seg_px", c_double_p), ("seg_f", c_double_p), ("seg_sf", c_double_p),
+                ("seg_ef", c_double_p), ("seg_level", c_i32_p), ("seg_a", c_float_p), ("seg_b", c_float_p), ("seg_mu_s", c_float_p),
+                ("seg_mu_e", c_float_p), ("seg_z_range_s", c_float_p), ("seg_z_range_e", c_float_p), ("seg_sigma2_s", c_float_p),
+                ("seg_sigma2_e", c_float_p)]
+
+
+class SeedsOut(C.Structure):
+    _fields_ = [("pt_status", c_i32_p), ("pt_a", c_float_p), ("pt_b", c_float_p), ("pt_mu", c_float_p), ("pt_sigma2", c_float_p),
+                ("pt_xyz_world", c_double_p), ("pt_px_cur", c_double_p), ("pt_depth", c_double_p),
+                ("seg_status", c_i32_p), ("seg_a", c_float_p), ("seg_b", c_float_p), ("seg_mu_s", c_float_p), ("seg_mu_e", c_float_p),
+                ("seg_sigma2_s", c_float_p), ("seg_sigma2_e", c_float_p), ("seg_xyz_world_s", c_double_p), ("seg_xyz_world_e", c_double_p),
+                ("seg_depth_s", c_double_p), ("seg_depth_e", c_double_p)]
 
 
 def _f64(a, n=None):
@@ -318,3 +344,74 @@ class ReprojectJob:
 
     def trim(self, bufs):
         return {k: v[:self.n].copy() for k, v in bufs.items()}
+
+
+class SeedsJob:
+    """Depth-filter seeds to update against one frame each (plsvo_update_seeds); owns the buffers.
+    `pt` / `seg` are dicts of arrays named like the plsvo_seeds_in fields without the prefix."""
+    PT_F32 = ("a", "b", "mu", "z_range", "sigma2")
+    SEG_F32 = ("a", "b", "mu_s", "mu_e", "z_range_s", "z_range_e", "sigma2_s", "sigma2_e")
+
+    def __init__(self, cam, frame_T, frame_slot, pt, seg, n_pyr_levels=3, align_max_iter=10, max_epi_search_steps=1000,
+                 edgelet_filtering=True, edgelet_max_angle=0.7, px_noise=1.0, convergence_sigma2_thresh=200.0):
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32).reshape(-1)
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+        self.frame_T = _f64(frame_T).reshape(-1, 7)
+        self.frame_slot = i32(frame_slot)
+        c = SeedsIn()
+        c.cam = cam if isinstance(cam, Pinhole) else Pinhole(*cam)
+        c.n_pyr_levels, c.align_max_iter, c.max_epi_search_steps = n_pyr_levels, align_max_iter, max_epi_search_steps
+        c.edgelet_filtering, c.edgelet_max_angle, c.px_noise = int(edgelet_filtering), edgelet_max_angle, px_noise
+        c.convergence_sigma2_thresh = convergence_sigma2_thresh
+        c.n_frames = self.frame_T.shape[0]
+        c.frame_T, c.frame_slot = _ptr(self.frame_T, c_double_p), _ptr(self.frame_slot, c_i32_p)
+        self.pt, self.seg = {}, {}
+        npt = self.n_pt = len(pt["px"]) if pt else 0
+        nsg = self.n_seg = len(seg["px"]) if seg else 0
+        c.n_pt, c.n_seg = npt, nsg
+        if npt:
+            P_ = self.pt
+            P_["ref_frame"], P_["cur_frame"], P_["level"] = i32(pt["ref_frame"]), i32(pt["cur_frame"]), i32(pt["level"])
+            P_["px"], P_["f"] = _f64(pt["px"], 2 * npt).reshape(-1, 2), _f64(pt["f"], 3 * npt).reshape(-1, 3)
+            P_["type"] = np.ascontiguousarray(pt.get("type", np.zeros(npt)), dtype=np.uint8).reshape(-1)
+            P_["grad"] = _f64(pt.get("grad", np.zeros((npt, 2))), 2 * npt).reshape(-1, 2)
+            for k in self.PT_F32:
+                P_[k] = f32(pt[k])
+            c.pt_ref_frame, c.pt_cur_frame, c.pt_level = (_ptr(P_[k], c_i32_p) for k in ("ref_frame", "cur_frame", "level"))
+            c.pt_px, c.pt_f, c.pt_grad, c.pt_type = _ptr(P_["px"], c_double_p), _ptr(P_["f"], c_double_p), _ptr(P_["grad"], c_double_p), _ptr(P_["type"], c_u8_p)
+            c.pt_a, c.pt_b, c.pt_mu, c.pt_z_range, c.pt_sigma2 = (_ptr(P_[k], c_float_p) for k in self.PT_F32)
+        if nsg:
+            S_ = self.seg
+            S_["ref_frame"], S_["cur_frame"], S_["level"] = i32(seg["ref_frame"]), i32(seg["cur_frame"]), i32(seg["level"])
+            for k, w in (("px", 2), ("f", 3), ("sf", 3), ("ef", 3)):
+                S_[k] = _f64(seg[k], w * nsg).reshape(-1, w)
+            for k in self.SEG_F32:
+                S_[k] = f32(seg[k])
+            c.seg_ref_frame, c.seg_cur_frame, c.seg_level = (_ptr(S_[k], c_i32_p) for k in ("ref_frame", "cur_frame", "level"))
+            c.seg_px, c.seg_f, c.seg_sf, c.seg_ef = (_ptr(S_[k], c_double_p) for k in ("px", "f", "sf", "ef"))
+            (c.seg_a, c.seg_b, c.seg_mu_s, c.seg_mu_e, c.seg_z_range_s, c.seg_z_range_e, c.seg_sigma2_s,
+             c.seg_sigma2_e) = (_ptr(S_[k], c_float_p) for k in self.SEG_F32)
+        self.c = c
+
+    OUT_PT = (("pt_status", np.int32, 1), ("pt_a", np.float32, 1), ("pt_b", np.float32, 1), ("pt_mu", np.float32, 1), ("pt_sigma2", np.float32, 1),
+              ("pt_xyz_world", np.float64, 3), ("pt_px_cur", np.float64, 2), ("pt_depth", np.float64, 1))
+    OUT_SEG = (("seg_status", np.int32, 1), ("seg_a", np.float32, 1), ("seg_b", np.float32, 1), ("seg_mu_s", np.float32, 1), ("seg_mu_e", np.float32, 1),
+               ("seg_sigma2_s", np.float32, 1), ("seg_sigma2_e", np.float32, 1), ("seg_xyz_world_s", np.float64, 3), ("seg_xyz_world_e", np.float64, 3),
+               ("seg_depth_s", np.float64, 1), ("seg_depth_e", np.float64, 1))
+
+    def make_out(self):
+        o = SeedsOut()
+        bufs = {}
+        ptr_t = {np.int32: c_i32_p, np.float32: c_float_p, np.float64: c_double_p}
+        for spec, n in ((self.OUT_PT, self.n_pt), (self.OUT_SEG, self.n_seg)):
+            for name, dt, w in spec:
+                bufs[name] = np.zeros((max(n, 1), w) if w > 1 else max(n, 1), dtype=dt)
+                setattr(o, name, bufs[name].ctypes.data_as(ptr_t[dt]))
+        return o, bufs
+
+    def trim(self, bufs):
+        out = {}
+        for spec, n in ((self.OUT_PT, self.n_pt), (self.OUT_SEG, self.n_seg)):
+            for name, _, _ in spec:
+                out[name] = bufs[name][:n].copy()
+        return out

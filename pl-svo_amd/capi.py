@@ -22,7 +22,7 @@ SYMBOLS = [
     "plsvo_align_set_trace", "plsvo_align_fetch_trace", "plsvo_align_poses_dev", "plsvo_align_copy_poses", "plsvo_align_work",
     "plsvo_pose_optimize", "plsvo_pose_optimize_batch", "plsvo_poseopt_stage", "plsvo_poseopt_run", "plsvo_poseopt_fetch",
     "plsvo_poseopt_set_trace", "plsvo_poseopt_fetch_trace", "plsvo_poseopt_poses_dev", "plsvo_poseopt_copy_poses", "plsvo_poseopt_work",
-    "plsvo_structure_optimize", "plsvo_match_direct", "plsvo_reproject", "plsvo_trajectory_record",
+    "plsvo_structure_optimize", "plsvo_match_direct", "plsvo_reproject", "plsvo_trajectory_record", "plsvo_update_seeds",
     "plsvo_gather_poses",
     "plsvo_hip_set_profiling", "plsvo_hip_kernel_time", "plsvo_hip_reset_profiling",
     "plsvo_hip_version", "plsvo_hip_device_info",
@@ -83,6 +83,7 @@ def lib():
         "plsvo_structure_optimize": (C.c_int, [ctxp, C.POINTER(abi.StructOptIn), C.POINTER(abi.StructOptOut)]),
         "plsvo_match_direct": (C.c_int, [ctxp, C.POINTER(abi.MatchIn), C.POINTER(abi.MatchOut)]),
         "plsvo_reproject": (C.c_int, [ctxp, C.POINTER(abi.ReprojectIn), C.POINTER(abi.ReprojectOut)]),
+        "plsvo_update_seeds": (C.c_int, [ctxp, C.POINTER(abi.SeedsIn), C.POINTER(abi.SeedsOut)]),
         "plsvo_trajectory_record": (C.c_int, [abi.c_double_p, abi.c_double_p, abi.c_double_p]),
         "plsvo_gather_poses": (C.c_int, [ctxp, vp, vp, C.c_int, vp]),
         "plsvo_hip_set_profiling": (C.c_int, [ctxp, C.c_int]),
@@ -301,6 +302,11 @@ class Context:
     def reproject(self, job):
         out, bufs = job.make_out()
         self._chk(self.L.plsvo_reproject(self.h, C.byref(job.c), C.byref(out)))
+        return job.trim(bufs)
+
+    def update_seeds(self, job):
+        out, bufs = job.make_out()
+        self._chk(self.L.plsvo_update_seeds(self.h, C.byref(job.c), C.byref(out)))
         return job.trim(bufs)
 
     def gather_poses(self, rccl_comm, d_local, n_local, d_all):

@@ -6,6 +6,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,6 +28,7 @@ hipError_t launch_pose_finish(const PoseBatchDev& b, double* d_poses, hipStream_
 hipError_t launch_structopt(const StructBatchDev& s, hipStream_t stream);
 hipError_t launch_match_direct(const MatchBatchDev& b, hipStream_t stream);
 hipError_t launch_reproject(const ReprojBatchDev& b, hipStream_t stream);
+hipError_t launch_update_seeds(const SeedsBatchDev& b, hipStream_t stream);
 hipError_t launch_halfsample(const uint8_t* src, size_t src_pitch, int in_w, int in_h, int in_stride, uint8_t* dst,
                              size_t dst_pitch, int n_slots, int rounding, hipStream_t stream);
 hipError_t launch_copy_level0(const uint8_t* src, size_t src_pitch, int w, int h, int stride, uint8_t* dst, size_t dst_pitch,
@@ -896,6 +898,115 @@ extern "C" int plsvo_trajectory_record(const double T_f_w[7], const double cov[3
   if ((W.t[0] == 0. && W.t[1] == 0. && W.t[2] == 0.) && (W.q.x == -0. && W.q.y == -0. && W.q.z == -0. && W.q.w == 1.)) skip_frame = true;
   out7[0] = W.t[0]; out7[1] = W.t[1]; out7[2] = W.t[2]; out7[3] = W.q.x; out7[4] = W.q.y; out7[5] = W.q.z; out7[6] = W.q.w;
   return skip_frame ? 0 : 1;
+}
+
+// ---- depth-filter seed update ----------------------------------------------------------------------------
+extern "C" int plsvo_update_seeds(plsvo_ctx* c, const plsvo_seeds_in* in, plsvo_seeds_out* out) {
+  CTX_CHECK(c);
+  if (!in || !out || in->n_pt < 0 || in->n_seg < 0 || in->n_frames < 0 || in->n_pyr_levels < 1 || in->align_max_iter < 0 || in->max_epi_search_steps < 0)
+    return fail(c, PLSVO_E_INVALID, "update_seeds: bad arguments");
+  const int np = in->n_pt, ns = in->n_seg, nf = in->n_frames;
+  if (np + ns == 0) return PLSVO_OK;
+  if (!c->pyr.base) return fail(c, PLSVO_E_STATE, "update_seeds: pyramids not configured");
+  if (nf <= 0 || !in->frame_T || !in->frame_slot) return fail(c, PLSVO_E_INVALID, "update_seeds: no frames");
+  if (in->n_pyr_levels > c->pyr.n_levels) return fail(c, PLSVO_E_INVALID, "update_seeds: n_pyr_levels exceeds the configured pyramid");
+  if (in->cam.width != c->pyr.w[0] || in->cam.height != c->pyr.h[0]) return fail(c, PLSVO_E_INVALID, "update_seeds: camera size does not match the configured pyramid");
+  if (np > 0 && (!in->pt_ref_frame || !in->pt_cur_frame || !in->pt_px || !in->pt_f || !in->pt_level || !in->pt_type || !in->pt_a || !in->pt_b || !in->pt_mu || !in->pt_z_range || !in->pt_sigma2))
+    return fail(c, PLSVO_E_INVALID, "update_seeds: null point-seed array");
+  if (ns > 0 && (!in->seg_ref_frame || !in->seg_cur_frame || !in->seg_px || !in->seg_f || !in->seg_sf || !in->seg_ef || !in->seg_level || !in->seg_a || !in->seg_b ||
+                 !in->seg_mu_s || !in->seg_mu_e || !in->seg_z_range_s || !in->seg_z_range_e || !in->seg_sigma2_s || !in->seg_sigma2_e))
+    return fail(c, PLSVO_E_INVALID, "update_seeds: null line-seed array");
+  for (int k = 0; k < nf; ++k) if (in->frame_slot[k] < 0 || in->frame_slot[k] >= c->pyr.n_slots) return fail(c, PLSVO_E_CAPACITY, "update_seeds: pyramid slot out of range");
+  bool any_edgelet = false;
+  for (int i = 0; i < np; ++i) {
+    if (in->pt_ref_frame[i] < 0 || in->pt_ref_frame[i] >= nf || in->pt_cur_frame[i] < 0 || in->pt_cur_frame[i] >= nf) return fail(c, PLSVO_E_INVALID, "update_seeds: frame index out of range");
+    if (in->pt_level[i] < 0 || in->pt_level[i] >= c->pyr.n_levels) return fail(c, PLSVO_E_INVALID, "update_seeds: feature level outside the configured pyramid");
+    if (in->pt_type[i] == PLSVO_FTR_EDGELET) any_edgelet = true;
+  }
+  if (any_edgelet && in->edgelet_filtering && !in->pt_grad) return fail(c, PLSVO_E_INVALID, "update_seeds: edgelets without pt_grad");
+  for (int i = 0; i < ns; ++i) {
+    if (in->seg_ref_frame[i] < 0 || in->seg_ref_frame[i] >= nf || in->seg_cur_frame[i] < 0 || in->seg_cur_frame[i] >= nf) return fail(c, PLSVO_E_INVALID, "update_seeds: frame index out of range");
+    if (in->seg_level[i] < 0 || in->seg_level[i] >= c->pyr.n_levels) return fail(c, PLSVO_E_INVALID, "update_seeds: feature level outside the configured pyramid");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  // one packed upload per element type
+  std::vector<double> d; std::vector<int> iv; std::vector<float> fv;
+  auto putd = [&](const double* p, size_t k) { const size_t o = d.size(); if (p) d.insert(d.end(), p, p + k); else d.resize(d.size() + k, 0.0); return o; };
+  auto puti = [&](const int32_t* p, size_t k) { const size_t o = iv.size(); iv.insert(iv.end(), p, p + k); return o; };
+  auto putf = [&](const float* p, size_t k) { const size_t o = fv.size(); fv.insert(fv.end(), p, p + k); return o; };
+  const size_t NP = (size_t)np, NS = (size_t)ns;
+  const size_t o_T = putd(in->frame_T, (size_t)nf * 7), o_ppx = putd(in->pt_px, NP * 2), o_pf = putd(in->pt_f, NP * 3), o_pg = putd(in->pt_grad, NP * 2);
+  const size_t o_spx = putd(in->seg_px, NS * 2), o_sf0 = putd(in->seg_f, NS * 3), o_ssf = putd(in->seg_sf, NS * 3), o_sef = putd(in->seg_ef, NS * 3);
+  const size_t o_slot = puti(in->frame_slot, (size_t)nf), o_prf = puti(in->pt_ref_frame, NP), o_pcf = puti(in->pt_cur_frame, NP), o_plv = puti(in->pt_level, NP);
+  const size_t o_srf = puti(in->seg_ref_frame, NS), o_scf = puti(in->seg_cur_frame, NS), o_slv = puti(in->seg_level, NS);
+  const size_t o_pa = putf(in->pt_a, NP), o_pb = putf(in->pt_b, NP), o_pmu = putf(in->pt_mu, NP), o_pzr = putf(in->pt_z_range, NP), o_ps2 = putf(in->pt_sigma2, NP);
+  const size_t o_sa = putf(in->seg_a, NS), o_sb = putf(in->seg_b, NS), o_smus = putf(in->seg_mu_s, NS), o_smue = putf(in->seg_mu_e, NS);
+  const size_t o_szrs = putf(in->seg_z_range_s, NS), o_szre = putf(in->seg_z_range_e, NS), o_ss2s = putf(in->seg_sigma2_s, NS), o_ss2e = putf(in->seg_sigma2_e, NS);
+  auto pad16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  const size_t dbytes = pad16(d.size() * sizeof(double)), ibytes = pad16(iv.size() * sizeof(int)), fbytes = pad16(fv.size() * sizeof(float)), bbytes = pad16(NP);
+  HIP_TRY(c, c->s_d_in.ensure(dbytes + ibytes + fbytes + bbytes + 16));
+  char* din = reinterpret_cast<char*>(c->s_d_in.p);
+  HIP_TRY(c, hipMemcpyAsync(din, d.data(), d.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(din + dbytes, iv.data(), iv.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  if (!fv.empty()) HIP_TRY(c, hipMemcpyAsync(din + dbytes + ibytes, fv.data(), fv.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  if (np > 0) HIP_TRY(c, hipMemcpyAsync(din + dbytes + ibytes + fbytes, in->pt_type, NP, hipMemcpyHostToDevice, c->stream));
+  // outputs: doubles, then floats, then ints
+  const size_t od_n = NP * 6 + NS * 8, of_n = NP * 4 + NS * 6, oi_n = NP + NS;
+  const size_t od_b = pad16(od_n * sizeof(double)), of_b = pad16(of_n * sizeof(float)), oi_b = pad16(oi_n * sizeof(int));
+  HIP_TRY(c, c->s_d_out.ensure(od_b + of_b + oi_b + 16));
+  char* dout = reinterpret_cast<char*>(c->s_d_out.p);
+  const double* dd = reinterpret_cast<const double*>(din);
+  const int* di = reinterpret_cast<const int*>(din + dbytes);
+  const float* df = reinterpret_cast<const float*>(din + dbytes + ibytes);
+  double* od = reinterpret_cast<double*>(dout);
+  float* of = reinterpret_cast<float*>(dout + od_b);
+  int* oi = reinterpret_cast<int*>(dout + od_b + of_b);
+  SeedsBatchDev b{};
+  b.pyr_base = c->pyr.base; b.slot_bytes = c->pyr.slot_bytes; b.width = c->pyr.w[0]; b.height = c->pyr.h[0];
+  b.fx = in->cam.fx; b.fy = in->cam.fy; b.cx = in->cam.cx; b.cy = in->cam.cy; b.cam_width = in->cam.width; b.cam_height = in->cam.height;
+  b.n_pyr_levels = in->n_pyr_levels; b.align_max_iter = in->align_max_iter; b.max_epi_search_steps = in->max_epi_search_steps;
+  b.edgelet_filtering = in->edgelet_filtering; b.edgelet_max_angle = in->edgelet_max_angle;
+  b.px_error_angle = std::atan(in->px_noise / (2.0 * std::fabs(in->cam.fx))) * 2.0;   // depth_filter.cpp:279-280 (host libm, like the reference)
+  b.convergence_sigma2_thresh = in->convergence_sigma2_thresh;
+  b.n_pt = np; b.n_seg = ns;
+  b.frame_T = dd + o_T; b.frame_slot = di + o_slot;
+  b.pt_ref_frame = di + o_prf; b.pt_cur_frame = di + o_pcf; b.pt_level = di + o_plv; b.pt_px = dd + o_ppx; b.pt_f = dd + o_pf;
+  b.pt_grad = in->pt_grad ? dd + o_pg : nullptr; b.pt_type = reinterpret_cast<const uint8_t*>(din + dbytes + ibytes + fbytes);
+  b.pt_a = df + o_pa; b.pt_b = df + o_pb; b.pt_mu = df + o_pmu; b.pt_z_range = df + o_pzr; b.pt_sigma2 = df + o_ps2;
+  b.seg_ref_frame = di + o_srf; b.seg_cur_frame = di + o_scf; b.seg_level = di + o_slv;
+  b.seg_px = dd + o_spx; b.seg_f = dd + o_sf0; b.seg_sf = dd + o_ssf; b.seg_ef = dd + o_sef;
+  b.seg_a = df + o_sa; b.seg_b = df + o_sb; b.seg_mu_s = df + o_smus; b.seg_mu_e = df + o_smue; b.seg_z_range_s = df + o_szrs;
+  b.seg_z_range_e = df + o_szre; b.seg_sigma2_s = df + o_ss2s; b.seg_sigma2_e = df + o_ss2e;
+  b.o_pt_xyz = od; b.o_pt_px = od + NP * 3; b.o_pt_depth = od + NP * 5;
+  double* ods = od + NP * 6;
+  b.o_seg_xyz_s = ods; b.o_seg_xyz_e = ods + NS * 3; b.o_seg_depth_s = ods + NS * 6; b.o_seg_depth_e = ods + NS * 7;
+  b.o_pt_a = of; b.o_pt_b = of + NP; b.o_pt_mu = of + NP * 2; b.o_pt_sigma2 = of + NP * 3;
+  float* ofs = of + NP * 4;
+  b.o_seg_a = ofs; b.o_seg_b = ofs + NS; b.o_seg_mu_s = ofs + NS * 2; b.o_seg_mu_e = ofs + NS * 3; b.o_seg_sigma2_s = ofs + NS * 4; b.o_seg_sigma2_e = ofs + NS * 5;
+  b.o_pt_status = oi; b.o_seg_status = oi + NP;
+  {
+    EventPair ep{}; prof_begin(c, PLSVO_K_SEEDS, &ep);
+    HIP_TRY(c, launch_update_seeds(b, c->stream));
+    prof_end(c, PLSVO_K_SEEDS, &ep);
+  }
+  std::vector<char> h(od_b + of_b + oi_b);
+  HIP_TRY(c, hipMemcpyAsync(h.data(), dout, h.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const double* hd = reinterpret_cast<const double*>(h.data());
+  const float* hf = reinterpret_cast<const float*>(h.data() + od_b);
+  const int* hi = reinterpret_cast<const int*>(h.data() + od_b + of_b);
+  auto cpd = [&](double* dst, const double* src, size_t k) { if (dst && k) memcpy(dst, src, k * sizeof(double)); };
+  auto cpf = [&](float* dst, const float* src, size_t k) { if (dst && k) memcpy(dst, src, k * sizeof(float)); };
+  cpd(out->pt_xyz_world, hd, NP * 3); cpd(out->pt_px_cur, hd + NP * 3, NP * 2); cpd(out->pt_depth, hd + NP * 5, NP);
+  const double* hds = hd + NP * 6;
+  cpd(out->seg_xyz_world_s, hds, NS * 3); cpd(out->seg_xyz_world_e, hds + NS * 3, NS * 3); cpd(out->seg_depth_s, hds + NS * 6, NS); cpd(out->seg_depth_e, hds + NS * 7, NS);
+  cpf(out->pt_a, hf, NP); cpf(out->pt_b, hf + NP, NP); cpf(out->pt_mu, hf + NP * 2, NP); cpf(out->pt_sigma2, hf + NP * 3, NP);
+  const float* hfs = hf + NP * 4;
+  cpf(out->seg_a, hfs, NS); cpf(out->seg_b, hfs + NS, NS); cpf(out->seg_mu_s, hfs + NS * 2, NS); cpf(out->seg_mu_e, hfs + NS * 3, NS);
+  cpf(out->seg_sigma2_s, hfs + NS * 4, NS); cpf(out->seg_sigma2_e, hfs + NS * 5, NS);
+  if (out->pt_status && np) memcpy(out->pt_status, hi, NP * sizeof(int));
+  if (out->seg_status && ns) memcpy(out->seg_status, hi + NP, NS * sizeof(int));
+  return PLSVO_OK;
 }
 
 // ---- multi-GPU gather ------------------------------------------------------------------------------

@@ -141,6 +141,26 @@ struct MatchBatchDev {
   double* px_out; uint8_t* found; int* search_level; int* n_iter;
 };
 
+// depth-filter seeds (include/plsvo_hip.h plsvo_seeds_in / plsvo_seeds_out), one lane per seed
+struct SeedsBatchDev {
+  const uint8_t* pyr_base; unsigned long long slot_bytes;
+  int width, height;
+  double fx, fy, cx, cy; int cam_width, cam_height;
+  int n_pyr_levels, align_max_iter, max_epi_search_steps, edgelet_filtering;
+  double edgelet_max_angle, px_error_angle, convergence_sigma2_thresh;
+  int n_pt, n_seg;
+  const double* frame_T; const int* frame_slot;
+  const int* pt_ref_frame; const int* pt_cur_frame; const double* pt_px; const double* pt_f; const int* pt_level; const uint8_t* pt_type;
+  const double* pt_grad; const float* pt_a; const float* pt_b; const float* pt_mu; const float* pt_z_range; const float* pt_sigma2;
+  const int* seg_ref_frame; const int* seg_cur_frame; const double* seg_px; const double* seg_f; const double* seg_sf; const double* seg_ef;
+  const int* seg_level; const float* seg_a; const float* seg_b; const float* seg_mu_s; const float* seg_mu_e; const float* seg_z_range_s;
+  const float* seg_z_range_e; const float* seg_sigma2_s; const float* seg_sigma2_e;
+  // outputs
+  int* o_pt_status; float* o_pt_a; float* o_pt_b; float* o_pt_mu; float* o_pt_sigma2; double* o_pt_xyz; double* o_pt_px; double* o_pt_depth;
+  int* o_seg_status; float* o_seg_a; float* o_seg_b; float* o_seg_mu_s; float* o_seg_mu_e; float* o_seg_sigma2_s; float* o_seg_sigma2_e;
+  double* o_seg_xyz_s; double* o_seg_xyz_e; double* o_seg_depth_s; double* o_seg_depth_e;
+};
+
 struct ReprojBatchDev {
   double fx, fy, cx, cy; int cam_width, cam_height;
   int n, cell_size, grid_n_cols, boundary;

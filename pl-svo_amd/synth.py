@@ -394,3 +394,44 @@ def make_match_batch(seed, W=640, H=480, n_pts=120, n_seg=40, zoom=0.0, motion_s
              cur_frame=np.ones(n, np.int32), ref_frame=np.zeros(n, np.int32), ref_px=ref_px, ref_f=ref_f, ref_level=ref_level,
              ref_type=ref_type, ref_grad=ref_grad, pos=pos, px_cur=px_cur, px_true=px_true, n_pts=n_pts, n_seg=n_seg)
     return st, d
+
+
+# ------------------------------------------------------------------------------------------------
+# depth-filter seeds: uninformed depth priors on the keyframe-0 features of a sequence
+# ------------------------------------------------------------------------------------------------
+
+def make_seeds(seq, cur_frame=1, edgelet_frac=0.2, depth_spread=0.8, seed=0):
+    """Point and line seeds as DepthFilter::initializeSeeds creates them (src/depth_filter.cpp:49-71): mu = 1/depth_mean,
+    z_range = 1/depth_min, sigma2 = z_range^2/36, a = b = 10 -- for every keyframe-0 feature of a sequence made by
+    sequence.make_sequence (a dict).  Returns (pt, seg, truth): the field dicts of abi.SeedsJob and the true depths."""
+    rng = np.random.default_rng(seed + 4100)
+    cam, T = seq["cam"], seq["poses_true"]
+    ref_pos = se3_inv(T[0])[4:]
+    depth = np.linalg.norm(seq["pt_pos"] - ref_pos, axis=1)
+    sdepth = np.linalg.norm(seq["seg_spos"] - ref_pos, axis=1)
+    edepth = np.linalg.norm(seq["seg_epos"] - ref_pos, axis=1)
+    all_d = np.concatenate([depth, sdepth, edepth])
+    dmean, dmin = float(np.mean(all_d)), float(np.min(all_d)) * depth_spread
+    n, ns = len(depth), len(sdepth)
+    ga = rng.uniform(0, 2 * math.pi, n)
+    pt = dict(ref_frame=np.zeros(n, np.int32), cur_frame=np.full(n, cur_frame, np.int32), px=seq["pt_px0"], f=seq["pt_f0"], level=np.zeros(n, np.int32),
+              type=(rng.uniform(size=n) < edgelet_frac).astype(np.uint8), grad=np.stack([np.cos(ga), np.sin(ga)], axis=1),
+              a=np.full(n, 10.0), b=np.full(n, 10.0), mu=np.full(n, 1.0 / dmean), z_range=np.full(n, 1.0 / dmin), sigma2=np.full(n, (1.0 / dmin) ** 2 / 36.0))
+    mid = 0.5 * (seq["seg_spx0"] + seq["seg_epx0"])            # LineFeat's Feature::px is the segment centre
+    fx, fy, cx, cy = cam[:4]
+    fm = np.stack([(mid[:, 0] - cx) / fx, (mid[:, 1] - cy) / fy, np.ones(ns)], axis=1)
+    fm /= np.linalg.norm(fm, axis=1, keepdims=True)
+    z0 = np.full(ns, 1.0 / dmean)
+    zr = np.full(ns, 1.0 / dmin)
+    seg = dict(ref_frame=np.zeros(ns, np.int32), cur_frame=np.full(ns, cur_frame, np.int32), px=mid, f=fm, sf=seq["seg_sf0"], ef=seq["seg_ef0"],
+               level=np.zeros(ns, np.int32), a=np.full(ns, 10.0), b=np.full(ns, 10.0), mu_s=z0.copy(), mu_e=z0.copy(), z_range_s=zr.copy(),
+               z_range_e=zr.copy(), sigma2_s=zr ** 2 / 36.0, sigma2_e=zr ** 2 / 36.0)
+    return pt, seg, dict(pt_depth=depth, seg_sdepth=sdepth, seg_edepth=edepth)
+
+
+def apply_seed_update(pt, seg, res):
+    """copy the posterior of a plsvo_update_seeds result back into the field dicts (what the host does per frame)"""
+    for k in ("a", "b", "mu", "sigma2"):
+        pt[k] = res["pt_" + k].copy()
+    for k in ("a", "b", "mu_s", "mu_e", "sigma2_s", "sigma2_e"):
+        seg[k] = res["seg_" + k].copy()
