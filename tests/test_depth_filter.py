@@ -81,8 +81,10 @@ def _assert_close(rd, ro):
         a, b = rd[k].astype(np.float64), ro[k].astype(np.float64)
         fin = np.isfinite(a) & np.isfinite(b)
         assert np.array_equal(np.isfinite(a), np.isfinite(b)), k
-        # a, b come from (e-f)/(f-e/f): a difference of nearly equal floats that amplifies the 1-ulp exp() difference
-        tol = 2e-3 if k.endswith(("_a", "_b")) else 2e-6
+        # the only inexact step is exp() inside the normal pdf (device: correctly rounded float; glibc expf: within 0.502 ulp).
+        # a, b = (e-f)/(f-e/f) and sigma2 = C1(s2+m^2) + C2(sigma2+mu^2) - mu_new^2 are differences of nearly equal floats
+        # that amplify that last-bit difference; mu is well conditioned
+        tol = 2e-3 if k.endswith(("_a", "_b")) else (2e-4 if "sigma2" in k else 2e-6)
         assert np.allclose(a[fin], b[fin], rtol=tol, atol=0), (k, np.max(np.abs(a[fin] - b[fin]) / np.abs(b[fin])))
     assert np.allclose(rd["pt_xyz_world"], ro["pt_xyz_world"], rtol=1e-6, atol=1e-9)
 
