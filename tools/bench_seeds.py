@@ -1,0 +1,58 @@
+"""Micro-benchmark of the depth-filter seed update (next row #4, last item): seeds/s on the GPU (kernel time from hipEvents, and
+end-to-end through the synchronous C ABI including the PCIe copies) next to the CPU oracle on one core.
+SEED_SEQS sequences (keyframe + 3 later frames, 640x480), 200 point seeds + 80 line seeds each, all updated with frame 2."""
+import importlib, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+P = importlib.import_module("pl-svo_amd")
+seqm = importlib.import_module("pl-svo_amd.sequence")
+from oracle import binding as ob
+
+n_seq = int(os.environ.get("SEED_SEQS", "64"))
+W, H, NF = 640, 480, 4
+ctx = P.capi.Context(0)
+ctx.config_pyramids(NF * n_seq, W, H, 4)
+pts, segs, Ts, first = [], [], [], None
+for s in range(n_seq):
+    seq = seqm.make_sequence(8000 + s, n_frames=NF, W=W, H=H, n_pts=200, n_seg=80, step_scale=1.0)
+    for k, im in enumerate(seq["images"]):
+        ctx.build_pyramid(NF * s + k, im, 0)
+    pt, seg, _ = P.synth.make_seeds(seq, cur_frame=2)
+    if first is None:
+        first = (seq, pt, seg)
+    for dct in (pt, seg):
+        dct["ref_frame"] = dct["ref_frame"] + NF * s
+        dct["cur_frame"] = dct["cur_frame"] + NF * s
+    pts.append(pt); segs.append(seg); Ts.append(seq["poses_true"])
+cat = lambda lst, k: np.concatenate([d[k] for d in lst])
+pt = {k: cat(pts, k) for k in pts[0]}
+seg = {k: cat(segs, k) for k in segs[0]}
+job = P.abi.SeedsJob(first[0]["cam"], np.concatenate(Ts), np.arange(NF * n_seq), pt, seg)
+ctx.update_seeds(job)
+ctx.set_profiling(True); ctx.reset_profiling()
+reps = 5
+t0 = time.perf_counter()
+for _ in range(reps):
+    rd = ctx.update_seeds(job)
+wall = (time.perf_counter() - t0) / reps
+ms, n = ctx.kernel_time(P.abi.K_SEEDS)
+kern = ms / n * 1e-3
+# CPU oracle on the first sequence
+seq0, pt0, seg0 = first
+pt0 = dict(pt0); seg0 = dict(seg0)
+pt0["ref_frame"] = pt0["ref_frame"] * 0; pt0["cur_frame"] = pt0["cur_frame"] * 0 + 2
+seg0["ref_frame"] = seg0["ref_frame"] * 0; seg0["cur_frame"] = seg0["cur_frame"] * 0 + 2
+fr0 = [ob.build_pyramid(im, 4) for im in seq0["images"]]
+j0 = P.abi.SeedsJob(seq0["cam"], seq0["poses_true"], np.arange(NF), pt0, seg0)
+t0 = time.perf_counter()
+for _ in range(5):
+    ro = ob.update_seeds(j0, fr0)
+cpu = (time.perf_counter() - t0) / 5
+same = bool(np.array_equal(ro["pt_status"], rd["pt_status"][:200]) and np.array_equal(ro["pt_depth"], rd["pt_depth"][:200]) and
+            np.array_equal(ro["seg_status"], rd["seg_status"][:80]))
+nseeds = job.n_pt + job.n_seg
+print(json.dumps({"seeds": nseeds, "point_seeds": job.n_pt, "line_seeds": job.n_seg, "updated_frac_points": round(float((rd["pt_status"] >= 2).mean()), 3),
+                  "kernel_ms": round(kern * 1e3, 4), "seeds_per_s_kernel": round(nseeds / kern), "abi_call_ms_incl_pcie": round(wall * 1e3, 3),
+                  "seeds_per_s_abi": round(nseeds / wall), "cpu_oracle_seeds_per_s_1core": round(280 / cpu),
+                  "status_and_depth_equal_oracle_first_sequence": same}))

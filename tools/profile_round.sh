@@ -13,6 +13,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; cat $O/bench_default.json
 timeout 300 python tools/bench_match.py > $O/match_microbench.json 2> $O/match_microbench.err; cat $O/match_microbench.json
 timeout 300 python tools/bench_structopt.py > $O/structopt_microbench.json 2> /dev/null
+timeout 300 python tools/bench_seeds.py > $O/seeds_microbench.json 2> $O/seeds_microbench.err; cat $O/seeds_microbench.json
 CMD="python $R/bench.py --batch 32768 --steps 3 --warmup 1 --no-cpu-baseline"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -- $CMD > $O/kt.log 2>&1
