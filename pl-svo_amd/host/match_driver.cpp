@@ -2,9 +2,12 @@
 // Matcher::findMatchDirect (src/reprojector.cpp:288, :348): a keyframe and a current frame built from a binary dump
 // written by tests/test_gpu_adapter.py, candidates queued from PointFeat / LineFeat objects, one batched run, results
 // printed for the test to compare with the oracle.  The batch is run twice: the second pass must hit the adapter's
-// keyframe-pyramid cache and give the same answer.  Usage: match_driver <input.bin> <output.txt>
+// keyframe-pyramid cache and give the same answer.  With a third file the depth-filter adapter
+// (plsvo::depth_filter::updateSeeds) is run on seed lists built from the same features.
+// Usage: match_driver <input.bin> <output.txt> [seeds.bin]
 #include <cstdio>
 #include <cstdlib>
+#include <list>
 #include <vector>
 
 #include "plsvo/hip_adapter.hpp"
@@ -77,6 +80,42 @@ int main(int argc, char** argv) {
       m.segment_px(hs[(size_t)i], s, e);
       fprintf(o, "seg%d %d %d %.17g %.17g %.17g %.17g\n", pass, m.found(hs[(size_t)i]) ? 1 : 0, m.search_level(hs[(size_t)i]), s[0], s[1], e[0], e[1]);
     }
+  }
+  // ---- DepthFilter::updateSeeds(frame) through the adapter (optional third input file) ----
+  if (argc > 3) {
+    FILE* g = fopen(argv[3], "rb");
+    if (!g) { perror("open"); return 2; }
+    std::vector<double> h = read_doubles(g, 3);
+    const int nps = (int)h[0], nss = (int)h[1], batch_counter = (int)h[2];
+    std::list<mini::PointSeed> pt_seeds; std::list<mini::LineSeed> seg_seeds;
+    for (int i = 0; i < nps; ++i) {
+      std::vector<double> d = read_doubles(g, 7);
+      mini::PointSeed sd; sd.ftr = &pfs[(size_t)d[0]]; sd.batch_id = (int)d[1]; sd.id = i;
+      sd.a = (float)d[2]; sd.b = (float)d[3]; sd.mu = (float)d[4]; sd.z_range = (float)d[5]; sd.sigma2 = (float)d[6];
+      pt_seeds.push_back(sd);
+    }
+    for (int i = 0; i < nss; ++i) {
+      std::vector<double> d = read_doubles(g, 15);
+      mini::LineSeed sd; mini::LineFeat& L = lfs[(size_t)d[0]];
+      L.px = mini::Vec2(d[10], d[11]); L.f = mini::Vec3(d[12], d[13], d[14]);       // Feature::px / f of the segment feature
+      sd.ftr = &L; sd.batch_id = (int)d[1]; sd.id = i;
+      sd.a = (float)d[2]; sd.b = (float)d[3]; sd.mu_s = (float)d[4]; sd.mu_e = (float)d[5]; sd.z_range_s = (float)d[6]; sd.z_range_e = (float)d[7];
+      sd.sigma2_s = (float)d[8]; sd.sigma2_e = (float)d[9];
+      seg_seeds.push_back(sd);
+    }
+    fclose(g);
+    plsvo::depth_filter::SeedUpdateOptions opt;
+    opt.n_pyr_levels = n_pyr_levels;
+    FILE* oo = o;
+    const bool ok = plsvo::depth_filter::updateSeeds(
+        cur, pt_seeds, seg_seeds, batch_counter, opt,
+        [oo](mini::PointSeed& sd, const double* xyz) { fprintf(oo, "pconv %d %.17g %.17g %.17g %.9g\n", sd.id, xyz[0], xyz[1], xyz[2], (double)sd.sigma2); },
+        [oo](mini::LineSeed& sd, const double* xs, const double* xe) {
+          fprintf(oo, "sconv %d %.17g %.17g %.17g %.17g %.17g %.17g\n", sd.id, xs[0], xs[1], xs[2], xe[0], xe[1], xe[2]); });
+    if (!ok) { fprintf(stderr, "depth_filter::updateSeeds failed\n"); return 3; }
+    for (auto& sd : pt_seeds) fprintf(o, "pseed %d %.9g %.9g %.9g %.9g\n", sd.id, (double)sd.a, (double)sd.b, (double)sd.mu, (double)sd.sigma2);
+    for (auto& sd : seg_seeds) fprintf(o, "sseed %d %.9g %.9g %.9g %.9g %.9g %.9g\n", sd.id, (double)sd.a, (double)sd.b, (double)sd.mu_s, (double)sd.mu_e,
+                                       (double)sd.sigma2_s, (double)sd.sigma2_e);
   }
   fclose(o);
   return 0;

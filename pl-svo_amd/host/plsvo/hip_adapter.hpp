@@ -413,6 +413,54 @@ bool optimize(PointIt pts_begin, PointIt pts_end, size_t n_iter, SegIt segs_begi
 }  // namespace structure_optimizer
 }  // namespace plsvo
 
+namespace plsvo_hip_adapter {
+// Frames referenced by one batch of the direct matcher / the seed update: index -> (pose, pyramid slot).  The pyramids are
+// uploaded on first sight and cached on the device by (address, id_) in the context's slots 2.. (Context::lookup).
+struct FrameRegistry {
+  std::vector<const void*> frames;
+  std::vector<double> frame_T;
+  std::vector<int32_t> frame_slot;
+  plsvo_pinhole cam;
+  bool ok;
+  unsigned long batch_start;
+  FrameRegistry() : ok(true), batch_start(0) {}
+  void clear() { frames.clear(); frame_T.clear(); frame_slot.clear(); ok = true; batch_start = 0; }
+  template <class FrameT>
+  int index(const FrameT* fr) {
+    for (size_t k = 0; k < frames.size(); ++k) if (frames[k] == (const void*)fr) return (int)k;
+    Context& c = default_context();
+    typedef typename std::remove_reference<decltype(*fr->cam_)>::type Cam;
+    const plsvo_pinhole cm = camera_traits<Cam>::get(*fr->cam_);
+    const int n_levels = (int)fr->img_pyr_.size();
+    if (frames.empty()) cam = cm;
+    if (!c.ensure(cm.width, cm.height, n_levels)) ok = false;
+    int slot = 0;
+    if (ok) {
+      if (batch_start == 0) batch_start = c.clock + 1;
+      int victim = -1;
+      slot = c.lookup((const void*)fr, (long)fr->id_, batch_start, &victim);
+      if (slot < 0) {
+        if (victim < 0) {
+          std::fprintf(stderr, "[plsvo_hip] more than %d distinct frames in one batch (raise PLSVO_KF_SLOTS)\n", (int)c.cache.size());
+          ok = false; slot = 0;
+        } else {
+          slot = 2 + victim;
+          if (!upload_frame_pyramid(c, slot, *fr, n_levels)) { ok = false; c.cache[(size_t)victim] = Context::CachedFrame{nullptr, 0, 0ul}; }
+          else c.cache[(size_t)victim] = Context::CachedFrame{(const void*)fr, (long)fr->id_, ++c.clock};
+        }
+      }
+    }
+    frames.push_back((const void*)fr);
+    double T[7];
+    typedef typename std::remove_cv<typename std::remove_reference<decltype(fr->T_f_w_)>::type>::type SE3T;
+    se3_traits<SE3T>::get(fr->T_f_w_, T);
+    frame_T.insert(frame_T.end(), T, T + 7);
+    frame_slot.push_back(slot);
+    return (int)frames.size() - 1;
+  }
+};
+}  // namespace plsvo_hip_adapter
+
 namespace plsvo {
 
 /// Batched replacement of Matcher::findMatchDirect (include/plsvo/matcher.h:120-131, src/matcher.cpp:157-280), the
@@ -430,12 +478,12 @@ namespace plsvo {
 /// level, PointFeat::type / grad, LineFeat::spx / epx / sf / ef, Frame::T_f_w_ / cam_ / img_pyr_ / id_.
 class DirectMatcher {
  public:
-  explicit DirectMatcher(int n_pyr_levels, int align_max_iter = 10) : n_pyr_levels_(n_pyr_levels), align_max_iter_(align_max_iter), ok_(true), batch_start_(0) {}
+  explicit DirectMatcher(int n_pyr_levels, int align_max_iter = 10) : n_pyr_levels_(n_pyr_levels), align_max_iter_(align_max_iter) {}
 
   void clear() {
-    frames_.clear(); frame_T_.clear(); frame_slot_.clear(); cur_frame_.clear(); ref_frame_.clear(); ref_px_.clear(); ref_f_.clear();
+    reg_.clear(); cur_frame_.clear(); ref_frame_.clear(); ref_px_.clear(); ref_f_.clear();
     ref_level_.clear(); ref_type_.clear(); ref_grad_.clear(); pos_.clear(); px_cur_.clear(); items_.clear(); out_px_.clear(); out_found_.clear();
-    out_level_.clear(); ok_ = true; batch_start_ = 0;
+    out_level_.clear();
   }
 
   /// queue findMatchDirect(pt, cur_frame, px_cur); ref_ftr is what pt.getCloseViewObs(cur_frame.pos(), ref_ftr) returned
@@ -463,11 +511,11 @@ class DirectMatcher {
     const size_t n = ref_level_.size();
     out_px_.assign(px_cur_.begin(), px_cur_.end()); out_found_.assign(n ? n : 1, 0); out_level_.assign(n ? n : 1, -1);
     if (n == 0) return true;
-    if (!ok_) return false;
+    if (!reg_.ok) return false;
     plsvo_match_in in;
-    in.cam = cam_; in.n_pyr_levels = n_pyr_levels_; in.align_max_iter = align_max_iter_;
-    in.n_frames = (int32_t)frames_.size(); in.n = (int32_t)n;
-    in.frame_T = frame_T_.data(); in.frame_slot = frame_slot_.data(); in.cur_frame = cur_frame_.data(); in.ref_frame = ref_frame_.data();
+    in.cam = reg_.cam; in.n_pyr_levels = n_pyr_levels_; in.align_max_iter = align_max_iter_;
+    in.n_frames = (int32_t)reg_.frames.size(); in.n = (int32_t)n;
+    in.frame_T = reg_.frame_T.data(); in.frame_slot = reg_.frame_slot.data(); in.cur_frame = cur_frame_.data(); in.ref_frame = ref_frame_.data();
     in.ref_px = ref_px_.data(); in.ref_f = ref_f_.data(); in.ref_level = ref_level_.data(); in.ref_type = ref_type_.data();
     in.ref_grad = ref_grad_.data(); in.pos = pos_.data(); in.px_cur = px_cur_.data();
     plsvo_match_out out;
@@ -503,39 +551,7 @@ class DirectMatcher {
   struct Item { int first, n; };
 
   template <class FrameT>
-  int frame_index(const FrameT* fr) {
-    using namespace plsvo_hip_adapter;
-    for (size_t k = 0; k < frames_.size(); ++k) if (frames_[k] == (const void*)fr) return (int)k;
-    Context& c = default_context();
-    typedef typename std::remove_reference<decltype(*fr->cam_)>::type Cam;
-    const plsvo_pinhole cam = camera_traits<Cam>::get(*fr->cam_);
-    const int n_levels = (int)fr->img_pyr_.size();
-    if (frames_.empty()) cam_ = cam;
-    if (!c.ensure(cam.width, cam.height, n_levels)) ok_ = false;
-    int slot = 0;
-    if (ok_) {
-      if (batch_start_ == 0) batch_start_ = c.clock + 1;
-      int victim = -1;
-      slot = c.lookup((const void*)fr, (long)fr->id_, batch_start_, &victim);
-      if (slot < 0) {
-        if (victim < 0) {
-          std::fprintf(stderr, "[plsvo_hip] DirectMatcher: more than %d distinct frames in one batch (raise PLSVO_KF_SLOTS)\n", (int)c.cache.size());
-          ok_ = false; slot = 0;
-        } else {
-          slot = 2 + victim;
-          if (!upload_frame_pyramid(c, slot, *fr, n_levels)) { ok_ = false; c.cache[(size_t)victim] = Context::CachedFrame{nullptr, 0, 0ul}; }
-          else c.cache[(size_t)victim] = Context::CachedFrame{(const void*)fr, (long)fr->id_, ++c.clock};
-        }
-      }
-    }
-    frames_.push_back((const void*)fr);
-    double T[7];
-    typedef typename std::remove_cv<typename std::remove_reference<decltype(fr->T_f_w_)>::type>::type SE3T;
-    se3_traits<SE3T>::get(fr->T_f_w_, T);
-    frame_T_.insert(frame_T_.end(), T, T + 7);
-    frame_slot_.push_back(slot);
-    return (int)frames_.size() - 1;
-  }
+  int frame_index(const FrameT* fr) { return reg_.index(fr); }
   template <class V2, class V3, class Pos, class Px>
   void push(int cf, int rf, const V2& px, const V3& f, int level, uint8_t type, double g0, double g1, const Pos& pos, const Px& px_cur) {
     cur_frame_.push_back(cf); ref_frame_.push_back(rf); ref_level_.push_back(level); ref_type_.push_back(type);
@@ -546,16 +562,114 @@ class DirectMatcher {
   }
 
   int n_pyr_levels_, align_max_iter_;
-  bool ok_;
-  unsigned long batch_start_;
-  plsvo_pinhole cam_;
-  std::vector<const void*> frames_;
-  std::vector<double> frame_T_, ref_px_, ref_f_, ref_grad_, pos_, px_cur_, out_px_;
-  std::vector<int32_t> frame_slot_, cur_frame_, ref_frame_, ref_level_, out_level_;
+  plsvo_hip_adapter::FrameRegistry reg_;
+  std::vector<double> ref_px_, ref_f_, ref_grad_, pos_, px_cur_, out_px_;
+  std::vector<int32_t> cur_frame_, ref_frame_, ref_level_, out_level_;
   std::vector<uint8_t> ref_type_, out_found_;
   std::vector<Item> items_;
 };
 
+}  // namespace plsvo
+
+namespace plsvo {
+namespace depth_filter {
+
+/// The reference's defaults (DepthFilter::Options include/plsvo/depth_filter.h:112-131, Matcher::Options matcher.h:88-106)
+struct SeedUpdateOptions {
+  int n_pyr_levels;                  // Config::nPyrLevels()
+  int max_n_kfs;                     // DepthFilter::Options::max_n_kfs
+  double seed_convergence_sigma2_thresh;
+  int align_max_iter, max_epi_search_steps;
+  bool epi_search_edgelet_filtering;
+  double epi_search_edgelet_max_angle;
+  SeedUpdateOptions() : n_pyr_levels(3), max_n_kfs(3), seed_convergence_sigma2_thresh(200.0), align_max_iter(10), max_epi_search_steps(1000),
+                        epi_search_edgelet_filtering(true), epi_search_edgelet_max_angle(0.7) {}
+};
+
+/// Batched replacement of DepthFilter::updateSeeds(frame) (src/depth_filter.cpp:262-471): every seed of both lists is
+/// updated against `frame` in ONE launch, then the lists are walked once in the reference's order to apply exactly its
+/// mutations: seeds older than max_n_kfs batches are erased (:290-293, :386-389), `b++` on a failed search, the new
+/// a/b/mu/sigma2, converged seeds are handed to the callbacks with their world position(s) and erased (:335-358,
+/// :438-462), NaN seeds are erased.  The callbacks create the landmark (`new Point(xyz_world, it->ftr)`,
+/// `it->ftr->feat3D = point`, seed_converged_cb_) -- map objects stay host business:
+///     on_point(seed, xyz_world[3]);   on_segment(seed, xyz_world_s[3], xyz_world_e[3]);
+/// Seed types are duck-typed on the reference's members (batch_id, ftr, a, b, mu, z_range, sigma2 / the _s _e pairs).
+/// Not reproduced: seeds_updating_halt_ (a launch is not interruptible) and the detector's setGridOccpuancy
+/// (:330-333; feature detection is outside this path).
+template <class FrameT, class PointSeedList, class LineSeedList, class OnPoint, class OnSegment>
+bool updateSeeds(const FrameT& frame, PointSeedList& pt_seeds, LineSeedList& seg_seeds, int batch_counter, const SeedUpdateOptions& opt,
+                 OnPoint on_point, OnSegment on_segment) {
+  using namespace plsvo_hip_adapter;
+  for (auto it = pt_seeds.begin(); it != pt_seeds.end();) { if ((batch_counter - it->batch_id) > opt.max_n_kfs) it = pt_seeds.erase(it); else ++it; }
+  for (auto it = seg_seeds.begin(); it != seg_seeds.end();) { if ((batch_counter - it->batch_id) > opt.max_n_kfs) it = seg_seeds.erase(it); else ++it; }
+  FrameRegistry reg;
+  std::vector<int32_t> prf, pcf, plv, srf, scf, slv;
+  std::vector<double> ppx, pf, pg, spx, sfc, ssf, sef;
+  std::vector<uint8_t> ptype;
+  std::vector<float> pa, pb, pmu, pzr, ps2, sa, sb, smus, smue, szrs, szre, ss2s, ss2e;
+  const int cf = pt_seeds.empty() && seg_seeds.empty() ? 0 : reg.index(&frame);
+  for (auto it = pt_seeds.begin(); it != pt_seeds.end(); ++it) {
+    typedef typename std::remove_reference<decltype(*it->ftr)>::type Ftr;
+    prf.push_back(reg.index(it->ftr->frame)); pcf.push_back(cf); plv.push_back(it->ftr->level);
+    ppx.push_back(it->ftr->px[0]); ppx.push_back(it->ftr->px[1]);
+    for (int k = 0; k < 3; ++k) pf.push_back(it->ftr->f[k]);
+    pg.push_back(it->ftr->grad[0]); pg.push_back(it->ftr->grad[1]);
+    ptype.push_back((int)it->ftr->type == (int)Ftr::EDGELET ? PLSVO_FTR_EDGELET : PLSVO_FTR_CORNER);
+    pa.push_back(it->a); pb.push_back(it->b); pmu.push_back(it->mu); pzr.push_back(it->z_range); ps2.push_back(it->sigma2);
+  }
+  for (auto it = seg_seeds.begin(); it != seg_seeds.end(); ++it) {
+    srf.push_back(reg.index(it->ftr->frame)); scf.push_back(cf); slv.push_back(it->ftr->level);
+    spx.push_back(it->ftr->px[0]); spx.push_back(it->ftr->px[1]);
+    for (int k = 0; k < 3; ++k) { sfc.push_back(it->ftr->f[k]); ssf.push_back(it->ftr->sf[k]); sef.push_back(it->ftr->ef[k]); }
+    sa.push_back(it->a); sb.push_back(it->b); smus.push_back(it->mu_s); smue.push_back(it->mu_e); szrs.push_back(it->z_range_s); szre.push_back(it->z_range_e);
+    ss2s.push_back(it->sigma2_s); ss2e.push_back(it->sigma2_e);
+  }
+  const size_t np = pa.size(), ns = sa.size();
+  if (np + ns == 0) return true;
+  if (!reg.ok) return false;
+  plsvo_seeds_in in;
+  in.cam = reg.cam; in.n_pyr_levels = opt.n_pyr_levels; in.align_max_iter = opt.align_max_iter; in.max_epi_search_steps = opt.max_epi_search_steps;
+  in.edgelet_filtering = opt.epi_search_edgelet_filtering ? 1 : 0; in.edgelet_max_angle = opt.epi_search_edgelet_max_angle; in.px_noise = 1.0;
+  in.convergence_sigma2_thresh = opt.seed_convergence_sigma2_thresh;
+  in.n_frames = (int32_t)reg.frames.size(); in.n_pt = (int32_t)np; in.n_seg = (int32_t)ns; in.reserved0 = 0;
+  in.frame_T = reg.frame_T.data(); in.frame_slot = reg.frame_slot.data();
+  in.pt_ref_frame = prf.data(); in.pt_cur_frame = pcf.data(); in.pt_px = ppx.data(); in.pt_f = pf.data(); in.pt_level = plv.data(); in.pt_type = ptype.data();
+  in.pt_grad = pg.data(); in.pt_a = pa.data(); in.pt_b = pb.data(); in.pt_mu = pmu.data(); in.pt_z_range = pzr.data(); in.pt_sigma2 = ps2.data();
+  in.seg_ref_frame = srf.data(); in.seg_cur_frame = scf.data(); in.seg_px = spx.data(); in.seg_f = sfc.data(); in.seg_sf = ssf.data(); in.seg_ef = sef.data();
+  in.seg_level = slv.data(); in.seg_a = sa.data(); in.seg_b = sb.data(); in.seg_mu_s = smus.data(); in.seg_mu_e = smue.data();
+  in.seg_z_range_s = szrs.data(); in.seg_z_range_e = szre.data(); in.seg_sigma2_s = ss2s.data(); in.seg_sigma2_e = ss2e.data();
+  std::vector<int32_t> pst(np + 1), sst(ns + 1);
+  std::vector<float> oa(np + 1), ob(np + 1), omu(np + 1), os2(np + 1), osa(ns + 1), osb(ns + 1), osmus(ns + 1), osmue(ns + 1), oss2s(ns + 1), oss2e(ns + 1);
+  std::vector<double> oxyz(3 * np + 3), oxs(3 * ns + 3), oxe(3 * ns + 3);
+  plsvo_seeds_out out;
+  out.pt_status = pst.data(); out.pt_a = oa.data(); out.pt_b = ob.data(); out.pt_mu = omu.data(); out.pt_sigma2 = os2.data(); out.pt_xyz_world = oxyz.data();
+  out.pt_px_cur = nullptr; out.pt_depth = nullptr;
+  out.seg_status = sst.data(); out.seg_a = osa.data(); out.seg_b = osb.data(); out.seg_mu_s = osmus.data(); out.seg_mu_e = osmue.data();
+  out.seg_sigma2_s = oss2s.data(); out.seg_sigma2_e = oss2e.data(); out.seg_xyz_world_s = oxs.data(); out.seg_xyz_world_e = oxe.data();
+  out.seg_depth_s = nullptr; out.seg_depth_e = nullptr;
+  Context& c = default_context();
+  if (plsvo_update_seeds(c.ctx, &in, &out) != PLSVO_OK) {
+    std::fprintf(stderr, "[plsvo_hip] update_seeds failed: %s\n", plsvo_hip_last_error(c.ctx));
+    return false;
+  }
+  size_t i = 0;
+  for (auto it = pt_seeds.begin(); it != pt_seeds.end(); ++i) {
+    it->a = oa[i]; it->b = ob[i]; it->mu = omu[i]; it->sigma2 = os2[i];
+    if (pst[i] == PLSVO_SEED_CONVERGED) { on_point(*it, &oxyz[3 * i]); it = pt_seeds.erase(it); }
+    else if (pst[i] == PLSVO_SEED_NAN) it = pt_seeds.erase(it);
+    else ++it;
+  }
+  i = 0;
+  for (auto it = seg_seeds.begin(); it != seg_seeds.end(); ++i) {
+    it->a = osa[i]; it->b = osb[i]; it->mu_s = osmus[i]; it->mu_e = osmue[i]; it->sigma2_s = oss2s[i]; it->sigma2_e = oss2e[i];
+    if (sst[i] == PLSVO_SEED_CONVERGED) { on_segment(*it, &oxs[3 * i], &oxe[3 * i]); it = seg_seeds.erase(it); }
+    else if (sst[i] == PLSVO_SEED_NAN) it = seg_seeds.erase(it);
+    else ++it;
+  }
+  return true;
+}
+
+}  // namespace depth_filter
 }  // namespace plsvo
 
 namespace svo = plsvo;  // BASELINE.json spells the upstream name svo::SparseImgAlign

@@ -46,7 +46,7 @@ struct Point { Vec3 pos_; std::list<PointFeat*> obs_; };              // Feature
 struct LineSeg { Vec3 spos_, epos_; std::list<LineFeat*> obs_; };     // Feature3D<LineFeat>::obs_
 struct Feature { Frame* frame = nullptr; Vec2 px; Vec3 f; int level = 0; };
 struct PointFeat : Feature { enum FeatureType { CORNER, EDGELET }; FeatureType type = CORNER; Vec2 grad; Point* feat3D = nullptr; };
-struct LineFeat : Feature { Vec2 spx, epx; Vec3 sf, ef, line; LineSeg* feat3D = nullptr; double length = 0; };
+struct LineFeat : Feature { Vec2 spx, epx, grad; Vec3 sf, ef, line; LineSeg* feat3D = nullptr; double length = 0; };
 struct Frame {
   int id_ = 0;
   Camera* cam_ = nullptr;
@@ -56,6 +56,9 @@ struct Frame {
   std::list<PointFeat*> pt_fts_;
   std::list<LineFeat*> seg_fts_;
 };
+// depth-filter seeds (include/plsvo/depth_filter.h:47-101)
+struct PointSeed { int batch_id = 0, id = 0; PointFeat* ftr = nullptr; float a = 10, b = 10, mu = 0, z_range = 0, sigma2 = 0; };
+struct LineSeed { int batch_id = 0, id = 0; LineFeat* ftr = nullptr; float a = 10, b = 10, mu_s = 0, mu_e = 0, z_range_s = 0, z_range_e = 0, sigma2_s = 0, sigma2_e = 0; };
 typedef std::shared_ptr<Frame> FramePtr;
 
 }  // namespace mini

@@ -122,3 +122,82 @@ def test_direct_matcher_adapter_reproduces_find_match_direct(P, ob, tmp_path):
         assert np.array_equal(np.nan_to_num(sg[:, 2:4], nan=-1), np.nan_to_num(ro["px_cur"][s0:e0], nan=-1))
         assert np.array_equal(np.nan_to_num(sg[:, 4:6], nan=-1), np.nan_to_num(ro["px_cur"][e0:], nan=-1))
     assert ro["found"].mean() > 0.3
+
+
+def test_depth_filter_adapter_reproduces_update_seeds(P, ob, tmp_path):
+    """plsvo::depth_filter::updateSeeds: std::lists of PointSeed / LineSeed in, the reference's mutations out -- stale seeds
+    erased, a/b/mu/sigma2 updated, converged seeds reported with their world position and erased -- against the oracle."""
+    driver = os.path.join(ROOT, "pl-svo_amd", "host", "match_driver")
+    W, H, nlev, npts, nseg = 320, 240, 4, 40, 10
+    st, d = P.synth.make_match_batch(882, W, H, npts, nseg, zoom=0.0, motion_scale=2.0, edgelet_frac=0.2, levels=(0,), level_p=(1.0,))
+    imgs = P.synth.render_streams([st]).numpy()[0]
+    frames = [ob.build_pyramid(imgs[0], nlev), ob.build_pyramid(imgs[1], nlev)]
+    s0, e0 = npts, npts + nseg
+    path = tmp_path / "match.bin"
+    with open(path, "wb") as f:
+        np.array([W, H, nlev, npts, nseg, 3], float).tofile(f)
+        np.array(st.cam[:4], float).tofile(f)
+        d["frame_T"].astype(np.float64).tofile(f)
+        for pyr in frames:
+            for l in pyr:
+                np.ascontiguousarray(l, np.uint8).tofile(f)
+        np.hstack([d["ref_px"][:npts], d["ref_f"][:npts], d["ref_level"][:npts, None].astype(float), d["ref_type"][:npts, None].astype(float),
+                   d["ref_grad"][:npts], d["pos"][:npts], d["px_cur"][:npts]]).astype(np.float64).tofile(f)
+        np.hstack([d["ref_px"][s0:e0], d["ref_px"][e0:], d["ref_f"][s0:e0], d["ref_f"][e0:], d["ref_level"][s0:e0, None].astype(float),
+                   d["pos"][s0:e0], d["pos"][e0:], d["px_cur"][s0:e0], d["px_cur"][e0:]]).astype(np.float64).tofile(f)
+    # seeds: uninformed priors around the scene depth; seed 1 is nearly converged, seed 2 is too old (erased unseen)
+    ref_pos = P.synth.se3_inv(d["frame_T"][0])[4:]
+    depth = np.linalg.norm(d["pos"] - ref_pos, axis=1)
+    dmean, dmin = float(depth.mean()), 0.8 * float(depth.min())
+    f32 = lambda v: float(np.float32(v))
+    pt_rows = [[i, 5, 10.0, 10.0, f32(1 / dmean), f32(1 / dmin), f32((1 / dmin) ** 2 / 36)] for i in range(npts)]
+    pt_rows[1][4], pt_rows[1][6] = f32(1 / depth[1]), f32(1e-8)
+    pt_rows[2][1] = 1                                           # batch_counter - batch_id = 4 > max_n_kfs = 3
+    mid = 0.5 * (d["ref_px"][s0:e0] + d["ref_px"][e0:])
+    fx, fy, cx, cy = st.cam[:4]
+    fm = np.stack([(mid[:, 0] - cx) / fx, (mid[:, 1] - cy) / fy, np.ones(nseg)], axis=1)
+    fm /= np.linalg.norm(fm, axis=1, keepdims=True)
+    seg_rows = [[i, 5, 10.0, 10.0, f32(1 / dmean), f32(1 / dmean), f32(1 / dmin), f32(1 / dmin), f32((1 / dmin) ** 2 / 36), f32((1 / dmin) ** 2 / 36),
+                 mid[i, 0], mid[i, 1], fm[i, 0], fm[i, 1], fm[i, 2]] for i in range(nseg)]
+    spath = tmp_path / "seeds.bin"
+    with open(spath, "wb") as f:
+        np.array([npts, nseg, 5], float).tofile(f)
+        np.array(pt_rows, float).tofile(f)
+        np.array(seg_rows, float).tofile(f)
+    out = tmp_path / "out.txt"
+    subprocess.run([driver, str(path), str(out), str(spath)], check=True, timeout=120)
+    rows = [l.split() for l in open(out).read().strip().splitlines()]
+    # oracle on the same seeds (without the stale one)
+    keep = np.array([i for i in range(npts) if i != 2])
+    pr = np.array(pt_rows)[keep]
+    pt = dict(ref_frame=np.zeros(len(keep), np.int32), cur_frame=np.ones(len(keep), np.int32), px=d["ref_px"][keep], f=d["ref_f"][keep],
+              level=d["ref_level"][keep], type=d["ref_type"][keep], grad=d["ref_grad"][keep], a=pr[:, 2], b=pr[:, 3], mu=pr[:, 4], z_range=pr[:, 5],
+              sigma2=pr[:, 6])
+    sr = np.array(seg_rows)
+    seg = dict(ref_frame=np.zeros(nseg, np.int32), cur_frame=np.ones(nseg, np.int32), px=mid, f=fm, sf=d["ref_f"][s0:e0], ef=d["ref_f"][e0:],
+               level=d["ref_level"][s0:e0], a=sr[:, 2], b=sr[:, 3], mu_s=sr[:, 4], mu_e=sr[:, 5], z_range_s=sr[:, 6], z_range_e=sr[:, 7],
+               sigma2_s=sr[:, 8], sigma2_e=sr[:, 9])
+    ro = ob.update_seeds(P.abi.SeedsJob(st.cam, d["frame_T"], np.array([0, 1]), pt, seg), frames)
+    got_p = {int(r[1]): [float(x) for x in r[2:]] for r in rows if r[0] == "pseed"}
+    got_pc = {int(r[1]): [float(x) for x in r[2:]] for r in rows if r[0] == "pconv"}
+    got_s = {int(r[1]): [float(x) for x in r[2:]] for r in rows if r[0] == "sseed"}
+    got_sc = {int(r[1]) for r in rows if r[0] == "sconv"}
+    assert 2 not in got_p and 2 not in got_pc, "the stale seed must be erased before the update"
+    assert 1 in got_pc and ro["pt_status"][list(keep).index(1)] == P.abi.SEED_CONVERGED
+    for j, i in enumerate(keep):
+        stt = ro["pt_status"][j]
+        if stt == P.abi.SEED_CONVERGED:
+            assert i in got_pc and np.allclose(got_pc[i][:3], ro["pt_xyz_world"][j], rtol=1e-6)
+        elif stt == P.abi.SEED_NAN:
+            assert i not in got_p and i not in got_pc
+        else:
+            exp = [ro["pt_a"][j], ro["pt_b"][j], ro["pt_mu"][j], ro["pt_sigma2"][j]]
+            assert i in got_p and np.allclose(got_p[i], exp, rtol=2e-3), (i, got_p.get(i), exp)
+            assert np.allclose(got_p[i][2], exp[2], rtol=2e-6)
+    for i in range(nseg):
+        if ro["seg_status"][i] == P.abi.SEED_CONVERGED:
+            assert i in got_sc
+        elif ro["seg_status"][i] != P.abi.SEED_NAN:
+            exp = [ro[k][i] for k in ("seg_a", "seg_b", "seg_mu_s", "seg_mu_e", "seg_sigma2_s", "seg_sigma2_e")]
+            assert i in got_s and np.allclose(got_s[i], exp, rtol=2e-3), (i, got_s.get(i), exp)
+    assert (ro["pt_status"] >= 2).sum() > 10
