@@ -145,13 +145,14 @@ def test_depth_filter_adapter_reproduces_update_seeds(P, ob, tmp_path):
                    d["ref_grad"][:npts], d["pos"][:npts], d["px_cur"][:npts]]).astype(np.float64).tofile(f)
         np.hstack([d["ref_px"][s0:e0], d["ref_px"][e0:], d["ref_f"][s0:e0], d["ref_f"][e0:], d["ref_level"][s0:e0, None].astype(float),
                    d["pos"][s0:e0], d["pos"][e0:], d["px_cur"][s0:e0], d["px_cur"][e0:]]).astype(np.float64).tofile(f)
-    # seeds: uninformed priors around the scene depth; seed 1 is nearly converged, seed 2 is too old (erased unseen)
+    # seeds: uninformed priors around the scene depth; seeds 1, 5, 9, .. are nearly converged, seed 2 is too old (erased unseen)
     ref_pos = P.synth.se3_inv(d["frame_T"][0])[4:]
     depth = np.linalg.norm(d["pos"] - ref_pos, axis=1)
     dmean, dmin = float(depth.mean()), 0.8 * float(depth.min())
     f32 = lambda v: float(np.float32(v))
     pt_rows = [[i, 5, 10.0, 10.0, f32(1 / dmean), f32(1 / dmin), f32((1 / dmin) ** 2 / 36)] for i in range(npts)]
-    pt_rows[1][4], pt_rows[1][6] = f32(1 / depth[1]), f32(1e-8)
+    for i in range(1, npts, 4):                                 # every fourth seed is nearly converged around the true depth
+        pt_rows[i][4], pt_rows[i][6] = f32(1 / depth[i]), f32(1e-6)
     pt_rows[2][1] = 1                                           # batch_counter - batch_id = 4 > max_n_kfs = 3
     mid = 0.5 * (d["ref_px"][s0:e0] + d["ref_px"][e0:])
     fx, fy, cx, cy = st.cam[:4]
@@ -183,7 +184,8 @@ def test_depth_filter_adapter_reproduces_update_seeds(P, ob, tmp_path):
     got_s = {int(r[1]): [float(x) for x in r[2:]] for r in rows if r[0] == "sseed"}
     got_sc = {int(r[1]) for r in rows if r[0] == "sconv"}
     assert 2 not in got_p and 2 not in got_pc, "the stale seed must be erased before the update"
-    assert 1 in got_pc and ro["pt_status"][list(keep).index(1)] == P.abi.SEED_CONVERGED
+    conv = {int(i) for j, i in enumerate(keep) if ro["pt_status"][j] == P.abi.SEED_CONVERGED}
+    assert conv and set(got_pc) == conv, (conv, set(got_pc))
     for j, i in enumerate(keep):
         stt = ro["pt_status"][j]
         if stt == P.abi.SEED_CONVERGED:
