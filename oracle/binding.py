@@ -75,6 +75,10 @@ def lib():
             ("plsvo_oracle_tukey", [C.c_float], C.c_float),
             ("plsvo_oracle_mad_scale", [C.POINTER(C.c_float), C.c_uint64], C.c_float),
             ("plsvo_oracle_median_f64", [d, C.c_uint64], C.c_double),
+            ("plsvo_oracle_zmssd", [abi.c_u8_p, abi.c_u8_p, C.c_int], C.c_int),
+            ("plsvo_oracle_depth_from_triangulation", [d, d, d, d], C.c_int),
+            ("plsvo_oracle_compute_tau", [d, d, C.c_double, C.c_double], C.c_double),
+            ("plsvo_oracle_update_point_seed", [C.c_float, C.c_float, C.POINTER(C.c_float)], None),
         ]:
             f = getattr(L, name)
             f.argtypes = args
@@ -293,3 +297,32 @@ def mad_scale(errors):
 def median_f64(v):
     v = np.ascontiguousarray(v, dtype=np.float64).copy()
     return float(lib().plsvo_oracle_median_f64(_dp(v), v.size))
+
+
+def zmssd(ref_patch, cur_img, x0, y0):
+    """ZMSSD<4> score of the 8x8 reference patch against the 8x8 window of cur_img whose top-left pixel is (x0, y0)"""
+    ref = np.ascontiguousarray(ref_patch, dtype=np.uint8).reshape(64)
+    img = np.ascontiguousarray(cur_img, dtype=np.uint8)
+    ptr = C.cast(img.ctypes.data + y0 * img.strides[0] + x0, abi.c_u8_p)
+    return int(lib().plsvo_oracle_zmssd(ref.ctypes.data_as(abi.c_u8_p), ptr, img.strides[0]))
+
+
+def depth_from_triangulation(T_search_ref, f_ref, f_cur):
+    T = np.ascontiguousarray(T_search_ref, dtype=np.float64)
+    a = np.ascontiguousarray(f_ref, dtype=np.float64)
+    b = np.ascontiguousarray(f_cur, dtype=np.float64)
+    out = np.zeros(1)
+    ok = lib().plsvo_oracle_depth_from_triangulation(_dp(T), _dp(a), _dp(b), _dp(out))
+    return bool(ok), float(out[0])
+
+
+def compute_tau(T_ref_cur, f, z, px_error_angle):
+    T = np.ascontiguousarray(T_ref_cur, dtype=np.float64)
+    a = np.ascontiguousarray(f, dtype=np.float64)
+    return float(lib().plsvo_oracle_compute_tau(_dp(T), _dp(a), float(z), float(px_error_angle)))
+
+
+def update_point_seed(x, tau2, a, b, mu, z_range, sigma2):
+    st = (C.c_float * 5)(a, b, mu, z_range, sigma2)
+    lib().plsvo_oracle_update_point_seed(C.c_float(x), C.c_float(tau2), st)
+    return tuple(float(v) for v in st)

@@ -1638,3 +1638,25 @@ int plsvo_oracle_update_seeds(const plsvo_seeds_in* in, const plsvo_oracle_pyr* 
   }
   return PLSVO_OK;
 }
+
+/* --- depth-filter pieces exposed for unit tests ------------------------------------------------ */
+int plsvo_oracle_zmssd(const uint8_t* ref_patch64, const uint8_t* cur_patch, int stride) {
+  zmssd_t z; zmssd_init(&z, ref_patch64); return zmssd_score(&z, cur_patch, stride);
+}
+int plsvo_oracle_depth_from_triangulation(const double T_search_ref[7], const double f_ref[3], const double f_cur[3], double* depth) {
+  const se3_t T = se3_load(T_search_ref); return depth_from_triangulation(&T, f_ref, f_cur, depth);
+}
+double plsvo_oracle_compute_tau(const double T_ref_cur[7], const double f[3], double z, double px_error_angle) {
+  const se3_t T = se3_load(T_ref_cur); return compute_tau(&T, f, z, px_error_angle);
+}
+/* updatePointSeed (src/depth_filter.cpp:489-515): state = {a, b, mu, z_range, sigma2} in/out */
+void plsvo_oracle_update_point_seed(float x, float tau2, float state[5]) {
+  float a = state[0], b = state[1], mu = state[2], sigma2 = state[4];
+  const float norm_scale = sqrtf(sigma2 + tau2);
+  if (isnan(norm_scale)) return;
+  float fq, eq;
+  seed_update_end(x, tau2, a, b, state[3], &mu, &sigma2, norm_scale, &fq, &eq);
+  a = (eq - fq) / (fq - eq / fq);
+  b = a * (1.0f - fq) / fq;
+  state[0] = a; state[1] = b; state[2] = mu; state[4] = sigma2;
+}

@@ -130,3 +130,66 @@ def test_hip_update_seeds_edge_cases(P, ob, gpu_ctx, seqm):
     pt["ref_frame"][0] = 9
     with pytest.raises(P.capi.PlsvoError):
         gpu_ctx.update_seeds(P.abi.SeedsJob(seq["cam"], seq["poses_true"], np.arange(3), pt, seg))
+
+
+# ---- the pieces of the seed update against independent NumPy / closed-form answers (CPU) -----------------------------
+
+def test_zmssd_matches_numpy(ob):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (40, 50), dtype=np.uint8)
+    ref = rng.integers(0, 256, (8, 8), dtype=np.uint8)
+    for (x0, y0) in ((0, 0), (7, 3), (42, 32)):
+        A, B = ref.astype(np.int64).ravel(), img[y0:y0 + 8, x0:x0 + 8].astype(np.int64).ravel()
+        expect = (A * A).sum() - 2 * (A * B).sum() + (B * B).sum() - (A.sum() ** 2 - 2 * A.sum() * B.sum() + B.sum() ** 2) // 64
+        assert ob.zmssd(ref, img, x0, y0) == expect
+    # zero-mean: a constant brightness offset costs nothing; identical patches score 0
+    assert ob.zmssd(img[5:13, 5:13], img, 5, 5) == 0
+    dim = (img[5:13, 5:13] // 2).astype(np.uint8)
+    assert ob.zmssd(dim, np.ascontiguousarray(np.pad(dim + 20, 4)), 4, 4) == 0
+
+
+def test_triangulation_and_tau_known_answers(P, ob):
+    # a point at depth 5 on the ray f_ref of the reference camera, seen by a camera 0.5 m to the right
+    f_ref = np.array([0.1, -0.05, 1.0]); f_ref /= np.linalg.norm(f_ref)
+    X = 5.0 * f_ref
+    T_cur_ref = P.synth.se3_exp(np.array([-0.5, 0.02, 0.01, 0.01, -0.02, 0.005]))
+    Xc = P.synth.se3_act(T_cur_ref, X)
+    ok, depth = ob.depth_from_triangulation(T_cur_ref, f_ref, Xc / np.linalg.norm(Xc))
+    assert ok and abs(depth - 5.0) < 1e-9
+    # parallel rays (no translation, same bearing): AtA is singular -> false
+    assert not ob.depth_from_triangulation(P.synth.se3_exp(np.zeros(6)), f_ref, f_ref)[0]
+    # tau: the depth change caused by a one-pixel angular error; small, positive and growing with depth^2 / baseline
+    T_ref_cur = P.synth.se3_inv(T_cur_ref)
+    ang = 2.0 * np.arctan(1.0 / (2.0 * 416.0))
+    t5, t10 = ob.compute_tau(T_ref_cur, f_ref, 5.0, ang), ob.compute_tau(T_ref_cur, f_ref, 10.0, ang)
+    assert 0 < t5 < t10 and 3.0 < t10 / t5 < 5.0
+    # closed form of :604-620 in NumPy
+    t = T_ref_cur[4:]; a = f_ref * 5.0 - t
+    alpha = np.arccos(f_ref @ t / np.linalg.norm(t)); beta = np.arccos(a @ (-t) / (np.linalg.norm(t) * np.linalg.norm(a)))
+    zp = np.linalg.norm(t) * np.sin(beta + ang) / np.sin(3.14159265 - alpha - beta - ang)
+    assert abs(t5 - (zp - 5.0)) < 1e-12
+
+
+def test_point_seed_posterior_matches_numpy(ob):
+    """updatePointSeed (:489-515) in float64 NumPy: the float32 oracle must agree to float accuracy, an inlier measurement
+    must pull mu towards x, shrink sigma2 and raise a/(a+b); an outlier far outside must do the opposite to the inlier ratio"""
+    def ref(x, tau2, a, b, mu, zr, s2):
+        ns = np.sqrt(s2 + tau2)
+        pdf = np.exp(-(x - mu) ** 2 / (2 * ns * ns)) / (ns * np.sqrt(2 * np.pi))
+        s2n = 1.0 / (1.0 / s2 + 1.0 / tau2); m = s2n * (mu / s2 + x / tau2)
+        C1, C2 = a / (a + b) * pdf, b / (a + b) / zr
+        C1, C2 = C1 / (C1 + C2), C2 / (C1 + C2)
+        f = C1 * (a + 1) / (a + b + 1) + C2 * a / (a + b + 1)
+        e = C1 * (a + 1) * (a + 2) / ((a + b + 1) * (a + b + 2)) + C2 * a * (a + 1) / ((a + b + 1) * (a + b + 2))
+        mun = C1 * m + C2 * mu
+        s2o = C1 * (s2n + m * m) + C2 * (s2 + mu * mu) - mun * mun
+        an = (e - f) / (f - e / f)
+        return an, an * (1 - f) / f, mun, s2o
+    st = (10.0, 10.0, 0.25, 0.5, 0.5 ** 2 / 36)
+    a, b, mu, zr, s2 = ob.update_point_seed(0.27, 1e-4, *st)
+    ea, eb, emu, es2 = ref(0.27, 1e-4, *st)
+    assert abs(mu - emu) < 1e-6 and abs(s2 - es2) < 1e-4 * es2 and abs(a - ea) < 2e-2 * ea and abs(b - eb) < 2e-2 * eb and zr == 0.5   # a, b: ill-conditioned
+    assert 0.25 < mu < 0.27 and s2 < st[4] and a / (a + b) > 0.5
+    a2, b2, mu2, _, s22 = ob.update_point_seed(0.45, 1e-4, *st)          # 2.4 sigma away: mostly explained as an outlier
+    assert a2 / (a2 + b2) < a / (a + b) and abs(mu2 - 0.25) < abs(0.45 - 0.25)
+    assert ob.update_point_seed(0.27, float("nan"), *st) == tuple(np.float32(v).item() for v in st)   # NaN norm_scale: untouched (:492-493)
