@@ -173,9 +173,10 @@ struct P1Fetch2 {
 #ifndef PLSVO_MIN_WAVES
 #define PLSVO_MIN_WAVES 2   // measured: capping VGPRs at 128 (4 waves/SIMD) spills and loses to 2 unspilled waves/SIMD
 #endif
-// LDS_PX: keep the per-iteration patch sums (6 doubles per patch) and the patches' 3-D points in LDS instead of
-// round-tripping them through L2/HBM every iteration (measured with FETCH_SIZE/WRITE_SIZE: ~36 % of the traffic)
-template <int T, int LDS_PX>   // LDS_PX bit 0: patch sums in LDS, bit 1: patch 3-D points in LDS
+// The per-iteration patch sums (6 doubles per patch) round-trip through L2 between phase 1 and phase 2.  Keeping them in
+// LDS was measured three ways on MI355X: all of them (one workgroup per CU fewer: -8 %), as many as fit beside the tables
+// at four workgroups per CU (no difference), none (this code).
+template <int T>
 __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBatchDev b, int cap, int level_hi, int level_lo) {
   const int job_id = blockIdx.x;
   const AlignJobDev job = b.jobs[job_id];
@@ -191,9 +192,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   double* s_red = reinterpret_cast<double*>(smem);                       // RED_N * (T/64)
   double* s_pose = s_red + RED_N * (T / 64);                             // 0..8 R, 9..11 t, 12..18 model, 19..25 old model, 26 chi2_, 27 #evals
   double* s_tot = s_pose + 32;                                           // block totals of the last iteration: 21 H, 6 Jres, chi2, n_meas, evals
-  double* s_part = s_tot + 32;                                           // 6 * cap  (LDS_PX & 1)
-  double* s_xyz = s_part + ((LDS_PX & 1) ? 6 * cap : 0);                 // 3 * cap  (LDS_PX & 2)
-  int* s_ctl = reinterpret_cast<int*>(s_xyz + ((LDS_PX & 2) ? 3 * cap : 0));   // 0 break, 1 stop, 2 iterations done, 3 error, 4.. scan tmp
+  int* s_ctl = reinterpret_cast<int*>(s_tot + 32);                       // 0 break, 1 stop, 2 iterations done, 3 error, 4.. scan tmp
   float2* s_uv = reinterpret_cast<float2*>(s_ctl + 32);                  // cap
   int2* s_meta = reinterpret_cast<int2*>(s_uv + cap);                    // cap
   float* s_abs = reinterpret_cast<float*>(s_meta + cap);                 // cap
@@ -213,8 +212,8 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   }
   const size_t pbase = (size_t)job.patch_off;
   const int nfeat = job.n_pts + job.n_seg;
-  double* const part = (LDS_PX & 1) ? s_part : (b.partial + 6 * pbase);  // per-iteration patch sums
-  double* const pxyz = (LDS_PX & 2) ? s_xyz : (b.patch_xyz + 3 * pbase); // 3-D point of every patch (ref frame)
+  double* const part = b.partial + 6 * pbase;        // per-iteration patch sums
+  double* const pxyz = b.patch_xyz + 3 * pbase;      // 3-D point of every patch (ref frame)
 
   for (int level = lv_first; level >= lv_last; --level) {
     // (level geometry is recomputed instead of indexing the kernel-argument arrays with a run-time level,
@@ -639,40 +638,28 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   }
 }
 
-// LDS bytes the kernel needs for a given patch capacity and staged-image capacity (host side helper)
-size_t align_level_lds_bytes(int threads, int cap, int lds_px) {
+// LDS bytes the kernel needs for a given patch capacity `cap` (host side helper)
+size_t align_level_lds_bytes(int threads, int cap) {
   size_t o = sizeof(double) * RED_N * (threads / 64) + sizeof(double) * 64 + sizeof(int) * 32;
-  if (lds_px & 1) o += (size_t)cap * 6 * sizeof(double);
-  if (lds_px & 2) o += (size_t)cap * 3 * sizeof(double);
   o += (size_t)cap * (sizeof(float2) + sizeof(int2) + sizeof(float) + sizeof(int) + sizeof(int)) + 16;
   return o;
 }
 
-template <int T, int PX>
+template <int T>
 static hipError_t launch_fused_T(const AlignBatchDev& b, int cap, int level_hi, int level_lo, size_t lds, hipStream_t stream) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_fused_kernel<T, PX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_fused_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((align_fused_kernel<T, PX>), dim3(b.n_jobs), dim3(T), lds, stream, b, cap, level_hi, level_lo);
+  hipLaunchKernelGGL((align_fused_kernel<T>), dim3(b.n_jobs), dim3(T), lds, stream, b, cap, level_hi, level_lo);
   return hipGetLastError();
 }
 
-template <int T>
-static hipError_t launch_fused_px(const AlignBatchDev& b, int cap, int lds_px, int level_hi, int level_lo, size_t lds, hipStream_t stream) {
-  switch (lds_px) {
-    case 0: return launch_fused_T<T, 0>(b, cap, level_hi, level_lo, lds, stream);
-    case 1: return launch_fused_T<T, 1>(b, cap, level_hi, level_lo, lds, stream);
-    case 3: return launch_fused_T<T, 3>(b, cap, level_hi, level_lo, lds, stream);
-    default: return hipErrorInvalidValue;
-  }
-}
-
-hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int lds_px, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream) {
+hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream) {
   switch (threads) {
-    case 64: return launch_fused_px<64>(b, cap, lds_px, level_hi, level_lo, lds, stream);
-    case 128: return launch_fused_px<128>(b, cap, lds_px, level_hi, level_lo, lds, stream);
-    case 256: return launch_fused_px<256>(b, cap, lds_px, level_hi, level_lo, lds, stream);
-    case 512: return launch_fused_px<512>(b, cap, lds_px, level_hi, level_lo, lds, stream);
-    case 1024: return launch_fused_px<1024>(b, cap, lds_px, level_hi, level_lo, lds, stream);
+    case 64: return launch_fused_T<64>(b, cap, level_hi, level_lo, lds, stream);
+    case 128: return launch_fused_T<128>(b, cap, level_hi, level_lo, lds, stream);
+    case 256: return launch_fused_T<256>(b, cap, level_hi, level_lo, lds, stream);
+    case 512: return launch_fused_T<512>(b, cap, level_hi, level_lo, lds, stream);
+    case 1024: return launch_fused_T<1024>(b, cap, level_hi, level_lo, lds, stream);
     default: return hipErrorInvalidValue;
   }
 }

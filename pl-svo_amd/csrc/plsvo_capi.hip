@@ -19,8 +19,8 @@
 
 namespace plsvo_hip {
 // kernels (align_kernels.hip, poseopt_kernels.hip, pyramid_kernels.hip)
-size_t align_level_lds_bytes(int threads, int cap, int lds_px);
-hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int lds_px, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream);
+size_t align_level_lds_bytes(int threads, int cap);
+hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream);
 hipError_t launch_align_init(const AlignBatchDev& b, hipStream_t stream);
 hipError_t launch_align_finish(const AlignBatchDev& b, double* d_poses, hipStream_t stream);
 hipError_t launch_pose_opt(const PoseBatchDev& b, hipStream_t stream);
@@ -411,21 +411,13 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   return PLSVO_OK;
 }
 
-// Launch configuration of the fused alignment kernel (measured on MI355X):
-//   threads  128 per workgroup (two waves per frame pair; four workgroups share a CU at ~230 VGPRs)
-//   lds_px   per-iteration patch sums (bit 0) and the patches' 3-D points (bit 1) live in LDS as long as the CU still
-//            holds as many workgroups as the VGPR budget allows: 160 KiB / (8 / waves-per-workgroup)
-// Environment overrides (experiments only): PLSVO_ALIGN_THREADS, PLSVO_ALIGN_LDS_PX, PLSVO_ALIGN_PER_LEVEL.
-static void pick_align_config(plsvo_ctx* c, int cap, int* threads, int* lds_px, size_t* lds) {
+// Launch configuration of the fused alignment kernel (measured on MI355X): 128 threads per workgroup (two
+// waves per frame pair; four workgroups share a CU at ~225 VGPRs), LDS holds only the per-patch tables.
+// Environment overrides (experiments only): PLSVO_ALIGN_THREADS, PLSVO_ALIGN_PER_LEVEL.
+static void pick_align_config(int cap, int* threads, size_t* lds) {
   int t = 128;
   if (const char* s = getenv("PLSVO_ALIGN_THREADS")) { const int v = atoi(s); if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) t = v; }
-  const int wg_per_cu = std::max(1, 8 / std::max(1, t / 64));
-  const size_t budget = (size_t)160 * 1024 / (size_t)wg_per_cu;
-  int px = 0;
-  if (align_level_lds_bytes(t, cap, 3) <= budget) px = 3;
-  else if (align_level_lds_bytes(t, cap, 1) <= budget) px = 1;
-  if (const char* s = getenv("PLSVO_ALIGN_LDS_PX")) { const int v = atoi(s); if ((v == 0 || v == 1 || v == 3) && align_level_lds_bytes(t, cap, v) <= c->lds_per_block) px = v; }
-  *threads = t; *lds_px = px; *lds = align_level_lds_bytes(t, cap, px);
+  *threads = t; *lds = align_level_lds_bytes(t, cap);
 }
 
 extern "C" int plsvo_align_run(plsvo_ctx* c) {
@@ -440,19 +432,19 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
   if (c->a_gmax >= c->a_gmin && c->a_gmax >= 0) {
     int cap = 4;
     for (int l = c->a_gmin; l <= c->a_gmax; ++l) cap = std::max(cap, c->a_cap[l]);
-    int threads, lds_px; size_t lds;
-    pick_align_config(c, cap, &threads, &lds_px, &lds);
+    int threads; size_t lds;
+    pick_align_config(cap, &threads, &lds);
     if (lds > c->lds_per_block) return fail(c, PLSVO_E_CAPACITY, "align_run: patch tables do not fit in LDS (too many features in one job)");
     bool per_level = false;
     if (const char* s = getenv("PLSVO_ALIGN_PER_LEVEL")) per_level = atoi(s) != 0;
     if (!per_level) {
       EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
-      HIP_TRY(c, launch_align_levels(c->a_b, cap, lds_px, c->a_gmax, c->a_gmin, threads, lds, c->stream));
+      HIP_TRY(c, launch_align_levels(c->a_b, cap, c->a_gmax, c->a_gmin, threads, lds, c->stream));
       prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
     } else {
       for (int level = c->a_gmax; level >= c->a_gmin; --level) {
         EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
-        HIP_TRY(c, launch_align_levels(c->a_b, cap, lds_px, level, level, threads, lds, c->stream));
+        HIP_TRY(c, launch_align_levels(c->a_b, cap, level, level, threads, lds, c->stream));
         prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
       }
     }
