@@ -56,5 +56,42 @@ def main():
         print(tag, "iters", res.iters, res.iters_ref)
 
 
+def widened_rows():
+    """fixtures of the widened rows: structure optimisation, reprojection + direct matching, depth-filter seeds"""
+    seqm = importlib.import_module("pl-svo_amd.sequence")
+    # structure optimisation
+    sb = P.synth.make_structure_batch(9201, 16, 12, 5)
+    so = ob.structure_optimize(P.structopt_job_from_batch(sb))
+    np.savez_compressed(os.path.join(HERE, "structopt_small.npz"), **{k: sb[k] for k in ("frame_T", "pt_pos", "pt_obs_off", "pt_obs_frame", "pt_obs_f",
+                        "seg_spos", "seg_epos", "seg_obs_off", "seg_obs_frame", "seg_obs_sf", "seg_obs_ef")}, **{"out_" + k: v for k, v in so.items()})
+    # reprojection + direct matching on a 160x120 keyframe / current-frame pair
+    st, d = P.synth.make_match_batch(9301, 160, 120, 24, 6, zoom=0.2, edgelet_frac=0.3, levels=(0, 1), level_p=(0.7, 0.3))
+    imgs = P.synth.render_streams([st]).numpy()[0]
+    frames = [ob.build_pyramid(imgs[0], 4), ob.build_pyramid(imgs[1], 4)]
+    rp = ob.reproject(P.abi.ReprojectJob(d["cam"], d["frame_T"], d["cur_frame"], d["pos"], cell_size=30))
+    mr = ob.match_direct(P.match_job_from_batch(d), frames)
+    keys = ("frame_T", "frame_slot", "cur_frame", "ref_frame", "ref_px", "ref_f", "ref_level", "ref_type", "ref_grad", "pos", "px_cur")
+    np.savez_compressed(os.path.join(HERE, "match_small.npz"), img0=imgs[0], img1=imgs[1], cam=np.array(d["cam"], float), **{k: d[k] for k in keys},
+                        out_reproj_px=rp["px"], out_reproj_cell=rp["cell"], **{"out_" + k: v for k, v in mr.items()})
+    print("match_small found", int(mr["found"].sum()), "of", len(mr["found"]))
+    # depth-filter seeds: keyframe 0, updated with frames 1 and 2
+    seq = seqm.make_sequence(9401, n_frames=3, W=160, H=120, n_pts=24, n_seg=6, step_scale=1.0)
+    fr = [ob.build_pyramid(im, 4) for im in seq["images"]]
+    pt, seg, _ = P.synth.make_seeds(seq, cur_frame=1)
+    outs = {}
+    for k in (1, 2):
+        pt["cur_frame"], seg["cur_frame"] = np.full(len(pt["px"]), k, np.int32), np.full(len(seg["px"]), k, np.int32)
+        if k == 1:
+            inputs = {"pt_" + n: np.array(v) for n, v in pt.items()}
+            inputs.update({"seg_" + n: np.array(v) for n, v in seg.items()})
+        r = ob.update_seeds(P.abi.SeedsJob(seq["cam"], seq["poses_true"], np.arange(3), pt, seg), fr)
+        outs.update({f"out{k}_" + n: v for n, v in r.items()})
+        P.synth.apply_seed_update(pt, seg, r)
+    np.savez_compressed(os.path.join(HERE, "seeds_small.npz"), img0=seq["images"][0], img1=seq["images"][1], img2=seq["images"][2],
+                        cam=np.array(seq["cam"], float), frame_T=seq["poses_true"], **inputs, **outs)
+    print("seeds_small statuses", np.bincount(outs["out1_pt_status"], minlength=5), np.bincount(outs["out2_pt_status"], minlength=5))
+
+
 if __name__ == "__main__":
     main()
+    widened_rows()
