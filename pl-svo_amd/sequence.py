@@ -12,8 +12,16 @@ keyframe 0).  It exists to exercise the entry points chained the way the referen
 files in the reference harness's format; it is not a VO system: no feature detection, depth filter,
 keyframe selection or map maintenance.
 
+With mapping=True two more steps run per frame, again as processFrame / the depth-filter thread order them:
+
+    structure optimisation of the 20 least recently refined landmarks   plsvo_structure_optimize   (:340)
+    depth-filter update of the seeds with the new frame                  plsvo_update_seeds         (depth_filter.cpp:262)
+
+starting from a map that knows only part of the landmarks (with noisy positions) and holds the rest as seeds that turn
+into landmarks when they converge.
+
 `backend` is duck-typed: load_frames(list of level-0 images), sparse_align(job), reproject(job), match_direct(job),
-pose_optimize(job).  The product backend is HipBackend (C ABI on the GPU, no fallback); tests pass an oracle-backed one
+pose_optimize(job), and for mapping structure_optimize(job), update_seeds(job).  The product backend is HipBackend (C ABI on the GPU, no fallback); tests pass an oracle-backed one
 to check the whole chain end to end."""
 import copy
 import math
@@ -45,6 +53,12 @@ class HipBackend:
     def pose_optimize(self, job):
         return self.ctx.pose_optimize(job)
 
+    def structure_optimize(self, job):
+        return self.ctx.structure_optimize(job)
+
+    def update_seeds(self, job):
+        return self.ctx.update_seeds(job)
+
 
 def make_sequence(seed, n_frames=6, W=320, H=240, n_pts=120, n_seg=30, step_scale=0.5):
     """Camera moving smoothly over the textured plane of synth.make_align_stream.  Returns a dict with the level-0
@@ -74,17 +88,39 @@ def _bearing(cam, px):
     return r / np.linalg.norm(r, axis=1, keepdims=True)
 
 
-def run_sequence(backend, seq, max_level=3, min_level=1, n_pyr_levels=3, reproj_thresh=2.0):
-    """-> list of per-frame dicts (pose T_f_w, cov, counts).  Frame 0 is the keyframe with the true pose."""
+def run_sequence(backend, seq, max_level=3, min_level=1, n_pyr_levels=3, reproj_thresh=2.0, mapping=False, known_frac=0.6,
+                 pos_noise=0.005, map_seed=0, kf_every=5):
+    """-> list of per-frame dicts (pose T_f_w, cov, counts).  Frame 0 is the keyframe with the true pose.
+    mapping=True: only `known_frac` of the point landmarks start in the map (positions off by `pos_noise` x depth along
+    their viewing ray), the others are depth-filter seeds; the seed update runs every frame; every `kf_every`-th frame
+    plays the keyframe: its matches become observations of their landmarks (Feature3D::obs_ grows at keyframes only, as
+    in the reference) and the 20 least recently refined landmarks with >= 2 observations are structure-optimised."""
     cam = seq["cam"]
     backend.load_frames(seq["images"])
     n_pts, n_seg = len(seq["pt_pos"]), len(seq["seg_spos"])
     T_prev = seq["poses_true"][0].copy()
-    # features of the previous frame that still carry a landmark: index into the map + pixel position
-    prev = dict(pt_idx=np.arange(n_pts), pt_px=seq["pt_px0"].copy(), seg_idx=np.arange(n_seg), seg_spx=seq["seg_spx0"].copy(),
-                seg_epx=seq["seg_epx0"].copy())
-    out = [dict(T=T_prev.copy(), cov=np.full((6, 6), 1e-9), n_align=0, n_matched_pt=n_pts, n_matched_seg=n_seg)]
     kf_T = seq["poses_true"][0]
+    P3 = seq["pt_pos"].copy()                      # the map's point positions (seq["pt_pos"] stays the truth)
+    known = np.ones(n_pts, bool)
+    if mapping:
+        rng = np.random.default_rng(map_seed + 77)
+        known = rng.uniform(size=n_pts) < known_frac
+        kf_pos = synth.se3_inv(kf_T)[4:]
+        ray = P3 - kf_pos
+        P3[known] = (kf_pos + ray * (1.0 + rng.uniform(-pos_noise, pos_noise, n_pts))[:, None])[known]
+        depth0 = np.linalg.norm(ray, axis=1)
+        dmean, dmin = float(depth0[known].mean()), 0.7 * float(depth0[known].min())
+        nsd = int((~known).sum())
+        seeds = dict(idx=np.nonzero(~known)[0], a=np.full(nsd, 10.0, np.float32), b=np.full(nsd, 10.0, np.float32), mu=np.full(nsd, 1.0 / dmean, np.float32),
+                     z_range=np.full(nsd, 1.0 / dmin, np.float32), sigma2=np.full(nsd, (1.0 / dmin) ** 2 / 36.0, np.float32))
+        obs = {int(i): [(0, seq["pt_f0"][i])] for i in range(n_pts)}     # Feature3D::obs_: (frame, unit bearing)
+        last_optim = np.zeros(n_pts, np.int64)
+        poses_est = [kf_T.copy()]
+    # features of the previous frame that still carry a landmark: index into the map + pixel position
+    k0 = np.nonzero(known)[0]
+    prev = dict(pt_idx=k0, pt_px=seq["pt_px0"][k0].copy(), seg_idx=np.arange(n_seg), seg_spx=seq["seg_spx0"].copy(),
+                seg_epx=seq["seg_epx0"].copy())
+    out = [dict(T=T_prev.copy(), cov=np.full((6, 6), 1e-9), n_align=0, n_matched_pt=int(known.sum()), n_matched_seg=n_seg)]
     for k in range(1, len(seq["images"])):
         # ---- 1. sparse image alignment, previous frame -> frame k (processFrame :266-274) ----
         ref_pos = synth.se3_inv(T_prev)[4:]
@@ -93,15 +129,16 @@ def run_sequence(backend, seq, max_level=3, min_level=1, n_pyr_levels=3, reproj_
             return _bearing(cam, px) * np.linalg.norm(pos - ref_pos, axis=1)[:, None]        # f * |pos - ref_pos| (:229-230)
         pi, si = prev["pt_idx"], prev["seg_idx"]
         job = abi.AlignJob(cam, max_level, min_level, 30, 1e-6, synth.se3_mul(T_prev, synth.se3_inv(T_prev)), prev["pt_px"],
-                           scaled(prev["pt_px"], seq["pt_pos"][pi]), prev["seg_spx"], prev["seg_epx"],
+                           scaled(prev["pt_px"], P3[pi]), prev["seg_spx"], prev["seg_epx"],
                            np.linalg.norm(prev["seg_epx"] - prev["seg_spx"], axis=1), scaled(prev["seg_spx"], seq["seg_spos"][si]),
                            scaled(prev["seg_epx"], seq["seg_epos"][si]), ref_slot=k - 1, cur_slot=k)
         ar = backend.sparse_align(job)
         T_k = synth.se3_mul(ar.T, T_prev)                                                    # :92
         # ---- 2. reprojection of the whole map (Reprojector::reprojectMap) ----
-        pos_all = np.concatenate([seq["pt_pos"], seq["seg_spos"], seq["seg_epos"]])
+        pos_all = np.concatenate([P3, seq["seg_spos"], seq["seg_epos"]])
         rp = backend.reproject(abi.ReprojectJob(cam, np.stack([kf_T, T_k]), np.ones(len(pos_all), np.int32), pos_all, cell_size=30))
         vis = rp["cell"] >= 0
+        vis[:n_pts] &= known                     # seeds are not in the map yet
         seg_vis = vis[n_pts:n_pts + n_seg] & vis[n_pts + n_seg:]
         vis[n_pts:n_pts + n_seg] = seg_vis
         vis[n_pts + n_seg:] = seg_vis
@@ -126,7 +163,7 @@ def run_sequence(backend, seq, max_level=3, min_level=1, n_pyr_levels=3, reproj_
         sf, ef = _bearing(cam, px_new[n_pts + seg_i]), _bearing(cam, px_new[n_pts + n_seg + seg_i])
         line = np.cross(sf, ef)
         line = line / np.sqrt(line[:, 0:1] ** 2 + line[:, 1:2] ** 2) if len(seg_i) else np.zeros((0, 3))    # feature.cpp:103-104
-        pj = abi.PoseOptJob(T_k, abs(cam[0]), reproj_thresh, 10, _bearing(cam, px_new[pt_i]), seq["pt_pos"][pt_i], level[pt_i], line,
+        pj = abi.PoseOptJob(T_k, abs(cam[0]), reproj_thresh, 10, _bearing(cam, px_new[pt_i]), P3[pt_i], level[pt_i], line,
                             seq["seg_spos"][seg_i], seq["seg_epos"][seg_i], level[n_pts + seg_i])
         pr = backend.pose_optimize(pj)
         T_k = pr.T.copy()
@@ -134,8 +171,47 @@ def run_sequence(backend, seq, max_level=3, min_level=1, n_pyr_levels=3, reproj_
         prev = dict(pt_idx=pt_i[pt_keep], pt_px=px_new[pt_i[pt_keep]], seg_idx=seg_i[seg_keep],
                     seg_spx=px_new[n_pts + seg_i[seg_keep]], seg_epx=px_new[n_pts + n_seg + seg_i[seg_keep]])
         T_prev = T_k
-        out.append(dict(T=T_k.copy(), cov=pr.cov.copy(), n_align=ar.n_tracked, n_matched_pt=int(pt_ok.sum()), n_matched_seg=int(seg_ok.sum()),
-                        n_kept_pt=int(pt_keep.sum()), n_kept_seg=int(seg_keep.sum())))
+        rec = dict(T=T_k.copy(), cov=pr.cov.copy(), n_align=ar.n_tracked, n_matched_pt=int(pt_ok.sum()), n_matched_seg=int(seg_ok.sum()),
+                   n_kept_pt=int(pt_keep.sum()), n_kept_seg=int(seg_keep.sum()))
+        if mapping:
+            poses_est.append(T_k.copy())
+            kept = pt_i[pt_keep]
+            is_kf = (k % kf_every) == 0
+            if is_kf:
+                for i, brg in zip(kept, _bearing(cam, px_new[kept])):
+                    obs[int(i)].append((k, brg))
+            # ---- 5. structure optimisation (FrameHandlerBase::optimizeStructure: the 20 least recently refined, :202-237) ----
+            cand = np.array([i for i in kept if len(obs[int(i)]) >= 2], np.int64)
+            if len(cand) and is_kf:
+                sel = cand[np.argsort(last_optim[cand], kind="stable")[:20]]
+                off, ofr, of_ = [0], [], []
+                for i in sel:
+                    for fr_, brg in obs[int(i)]:
+                        ofr.append(fr_)
+                        of_.append(brg)
+                    off.append(len(ofr))
+                z3, zi = np.zeros((0, 3)), np.zeros(0, np.int32)
+                so = backend.structure_optimize(abi.StructOptJob(np.stack(poses_est), P3[sel], off, ofr, np.array(of_), z3, z3, np.zeros(1, np.int32), zi, z3, z3, 5, 5))
+                P3[sel] = so["pt_pos"]
+                last_optim[sel] = k
+            # ---- 6. depth-filter update of the seeds with this frame (DepthFilter::updateSeeds) ----
+            ns = len(seeds["idx"])
+            if ns:
+                si_ = seeds["idx"]
+                ptd = dict(ref_frame=np.zeros(ns, np.int32), cur_frame=np.ones(ns, np.int32), px=seq["pt_px0"][si_], f=seq["pt_f0"][si_], level=np.zeros(ns, np.int32),
+                           a=seeds["a"], b=seeds["b"], mu=seeds["mu"], z_range=seeds["z_range"], sigma2=seeds["sigma2"])
+                sr = backend.update_seeds(abi.SeedsJob(cam, np.stack([kf_T, T_k]), np.array([0, k], np.int32), ptd, None, n_pyr_levels=n_pyr_levels))
+                stt = sr["pt_status"]
+                conv = stt == abi.SEED_CONVERGED
+                P3[si_[conv]] = sr["pt_xyz_world"][conv]
+                known[si_[conv]] = True
+                keep_s = ~(conv | (stt == abi.SEED_NAN))
+                seeds = dict(idx=si_[keep_s], a=sr["pt_a"][keep_s], b=sr["pt_b"][keep_s], mu=sr["pt_mu"][keep_s], z_range=seeds["z_range"][keep_s],
+                             sigma2=sr["pt_sigma2"][keep_s])
+                rec["n_seed_converged"] = int(conv.sum())
+            rec.update(n_known=int(known.sum()), n_seeds=len(seeds["idx"]),
+                       landmark_err=float(np.median(np.linalg.norm(P3[known] - seq["pt_pos"][known], axis=1))))
+        out.append(rec)
     return out
 
 

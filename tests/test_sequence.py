@@ -31,6 +31,12 @@ class OracleBackend:
     def pose_optimize(self, job):
         return self.ob.pose_optimize(job)[0]
 
+    def structure_optimize(self, job):
+        return self.ob.structure_optimize(job)
+
+    def update_seeds(self, job):
+        return self.ob.update_seeds(job, [self.pyr[s] for s in job.frame_slot])
+
 
 @pytest.fixture(scope="module")
 def seqm():
@@ -44,6 +50,37 @@ def test_oracle_chain_tracks_the_true_trajectory(P, ob, seqm):
     assert max(e[0] for e in err) < 6e-3 and max(e[1] for e in err) < 3e-2, err      # ~1 px at 320x240 (fx = 208)
     assert all(r["n_matched_pt"] > 40 for r in res[1:])
     assert all(r["n_matched_seg"] >= 3 for r in res[1:])
+
+
+def test_oracle_mapping_chain_grows_the_map(P, ob, seqm):
+    """mapping mode: 40 % of the points start as depth-filter seeds; the seed update turns them into landmarks, structure
+    optimisation runs at every pseudo-keyframe, and tracking keeps following the truth with the growing map"""
+    seq = seqm.make_sequence(3, n_frames=30, W=320, H=240, n_pts=120, n_seg=24, step_scale=1.0)
+    res = seqm.run_sequence(OracleBackend(ob), seq, mapping=True)
+    err = seqm.pose_errors(res, seq)
+    assert max(e[0] for e in err) < 1e-2 and max(e[1] for e in err) < 3e-2, err
+    assert res[1]["n_seeds"] >= 40 and res[-1]["n_seeds"] <= 0.2 * res[1]["n_seeds"]
+    assert res[-1]["n_known"] > res[1]["n_known"] + 30 and res[-1]["n_matched_pt"] > res[1]["n_matched_pt"] + 25
+    assert res[-1]["landmark_err"] < 0.03            # converged seeds land within centimetres of the true points (depth ~4 m)
+
+
+@pytest.mark.gpu
+def test_hip_mapping_chain_follows_the_oracle_chain(P, ob, gpu_ctx, seqm):
+    """all seven entry points chained (align, reproject, match, pose-opt, structure-opt, seeds, trajectory record)"""
+    seq = seqm.make_sequence(6, n_frames=24, W=320, H=240, n_pts=100, n_seg=20, step_scale=1.0)
+    ro = seqm.run_sequence(OracleBackend(ob), seq, mapping=True)
+    rd = seqm.run_sequence(seqm.HipBackend(gpu_ctx), seq, mapping=True)
+    first_conv = next((k for k, r in enumerate(ro) if r.get("n_seed_converged", 0) > 0), len(ro))
+    for k, (a, b) in enumerate(zip(rd, ro)):
+        ang, tr, ok = Hh.pose_close(a["T"], b["T"])
+        if k < first_conv:      # identical maps on both sides: the parity bar applies frame by frame
+            assert ok, (k, ang, tr)
+        # afterwards a seed may cross the convergence threshold one frame apart on the two sides (last-bit exp differences)
+        assert ang < 5e-3 and abs(a.get("n_known", 0) - b.get("n_known", 0)) <= 3, (k, ang, a.get("n_known"), b.get("n_known"))
+    ed = seqm.pose_errors(rd, seq)
+    assert max(e[0] for e in ed) < 1e-2 and max(e[1] for e in ed) < 3e-2
+    ok, rec = P.capi.trajectory_record(rd[-1]["T"], rd[-1]["cov"])
+    assert ok and abs(np.linalg.norm(rec[3:]) - 1.0) < 1e-9
 
 
 @pytest.mark.gpu
