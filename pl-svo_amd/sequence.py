@@ -60,14 +60,19 @@ class HipBackend:
         return self.ctx.update_seeds(job)
 
 
-def make_sequence(seed, n_frames=6, W=320, H=240, n_pts=120, n_seg=30, step_scale=0.5):
+def make_sequence(seed, n_frames=6, W=320, H=240, n_pts=120, n_seg=30, step_scale=0.5, total=None):
     """Camera moving smoothly over the textured plane of synth.make_align_stream.  Returns a dict with the level-0
     images, the camera, the true poses T_f_w of every frame and the map: landmark positions with their keyframe-0
-    observations."""
+    observations.  Per-frame motion is step_scale x (3 % of the scene depth, 0.01 rad) in a random direction, or -- with
+    `total` -- whatever divides a whole-sequence motion of total x (scene depth, 0.25 rad) into n_frames - 1 equal steps
+    (long sequences must keep the keyframe's landmarks in view)."""
     st = synth.make_align_stream(seed, W, H, n_pts, n_seg, 3, motion_scale=step_scale)
     rng = np.random.default_rng(seed + 300000)
     d0 = st.plane_d / st.plane_n[2]
     xi = np.concatenate([rng.uniform(-0.03, 0.03, 3) * d0, rng.uniform(-0.01, 0.01, 3)]) * step_scale
+    if total is not None:
+        dirs = rng.uniform(-1.0, 1.0, 6)
+        xi = np.concatenate([dirs[:3] / np.linalg.norm(dirs[:3]) * total * d0, dirs[3:] / np.linalg.norm(dirs[3:]) * total * 0.25]) / max(n_frames - 1, 1)
     subs, T_rel = [], []
     for k in range(1, n_frames):
         s = copy.copy(st)

@@ -14,7 +14,7 @@ n_frames = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 mapping = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
 os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
-seq = seqm.make_sequence(seed, n_frames, 640, 480, 200, 80, step_scale=1.0 if mapping else 0.5)
+seq = seqm.make_sequence(seed, n_frames, 640, 480, 200, 80, total=0.35)      # 35 % of the scene depth + 0.09 rad over the whole run
 ctx = P.capi.Context(0)
 res = seqm.run_sequence(seqm.HipBackend(ctx), seq, mapping=mapping)
 n = P.trajectory.write_trajectory(out, ["%.6f" % (0.05 * k) for k in range(n_frames)], [r["T"] for r in res], [r["cov"] for r in res])
