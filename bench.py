@@ -194,28 +194,14 @@ def main():
                 po, _ = ob.pose_optimize(pose_jobs[i])
                 ang2, dist2 = synth.se3_log_angle_dist(po.T, pres[i].T)
                 assert ang < 1e-4 and ang2 < 1e-4, "bench batch disagrees with the oracle"
-            def cpu_worker(first, stride, seconds):
-                # the C oracle is re-entrant and ctypes drops the GIL during the call, so plain threads scale over cores
-                done, i, t_end = 0, first, time.perf_counter() + seconds
-                while time.perf_counter() < t_end:
-                    ob.sparse_align(align_jobs[i % n_s], pyrs[i % n_s][0], pyrs[i % n_s][1])
-                    ob.pose_optimize(pose_jobs[i % n_s])
-                    done += 1
-                    i += stride
-                return done
+            # the timed loops run inside the oracle library (POSIX threads, no Python between frames)
             half = 0.5 * args.cpu_seconds
-            tc0 = time.perf_counter()
-            done1 = cpu_worker(0, 1, half)
-            tc1 = time.perf_counter() - tc0
+            done1, tc1 = ob.bench(align_jobs[:n_s], [p[0] for p in pyrs], [p[1] for p in pyrs], pose_jobs[:n_s], 1, half)
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            from concurrent.futures import ThreadPoolExecutor
-            tc0 = time.perf_counter()
-            with ThreadPoolExecutor(max_workers=cores) as ex:
-                doneN = sum(ex.map(lambda w: cpu_worker(w, cores, half), range(cores)))
-            tcN = time.perf_counter() - tc0
+            doneN, tcN = ob.bench(align_jobs[:n_s], [p[0] for p in pyrs], [p[1] for p in pyrs], pose_jobs[:n_s], cores, half)
             result["cpu_baseline"] = {"value": round(doneN / tcN, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-                                      "sample": f"{doneN} frames on {cores} threads in {tcN:.1f} s (independent streams, cycling over the first "
-                                                f"{n_s} streams of the timed batch), oracle/libplsvo_oracle.so, python ctypes call overhead included",
+                                      "sample": f"{doneN} frames on {cores} threads in {tcN:.1f} s (independent streams, round-robin over the first "
+                                                f"{n_s} streams of the timed batch), oracle/libplsvo_oracle.so, timed inside the library",
                                       "single_thread_value": round(done1 / tc1, 2),
                                       "single_thread_sample": f"{done1} frames in {tc1:.1f} s on one thread"}
             result["speedup_vs_cpu_all_cores"] = round(value / (doneN / tcN), 1)

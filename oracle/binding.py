@@ -60,6 +60,9 @@ def lib():
         L.plsvo_oracle_trajectory_record.argtypes = [abi.c_double_p, abi.c_double_p, abi.c_double_p]
         L.plsvo_oracle_update_seeds.restype = C.c_int
         L.plsvo_oracle_update_seeds.argtypes = [C.POINTER(abi.SeedsIn), C.POINTER(OraclePyr), C.POINTER(abi.SeedsOut)]
+        L.plsvo_oracle_bench.restype = C.c_longlong
+        L.plsvo_oracle_bench.argtypes = [C.c_int, C.POINTER(abi.AlignIn), C.POINTER(OraclePyr), C.POINTER(OraclePyr), C.POINTER(abi.PoseOptIn),
+                                         C.c_int, C.c_double, C.POINTER(C.c_double)]
         L.plsvo_oracle_halfsample.restype = None
         L.plsvo_oracle_halfsample.argtypes = [abi.c_u8_p, C.c_int, C.c_int, C.c_int, abi.c_u8_p, C.c_int, C.c_int]
         d = abi.c_double_p
@@ -205,6 +208,23 @@ def update_seeds(job, frame_levels):
     if rc != 0:
         raise RuntimeError(f"oracle update_seeds failed rc={rc}")
     return job.trim(bufs)
+
+
+def bench(align_jobs, ref_pyrs, cur_pyrs, pose_jobs, n_threads, seconds):
+    """SparseImgAlign::run + optimizeGaussNewton over the given streams on n_threads POSIX threads (no Python in the loop).
+    Returns (frames completed, wall seconds)."""
+    n = len(align_jobs)
+    aj = (abi.AlignIn * n)(*[j.c for j in align_jobs])
+    pj = (abi.PoseOptIn * n)(*[j.c for j in pose_jobs])
+    rp, cp, keep = (OraclePyr * n)(), (OraclePyr * n)(), []
+    for i in range(n):
+        a, k1 = make_pyr(ref_pyrs[i])
+        b, k2 = make_pyr(cur_pyrs[i])
+        rp[i], cp[i] = a, b
+        keep += [k1, k2]
+    el = C.c_double(0.0)
+    done = lib().plsvo_oracle_bench(n, aj, rp, cp, pj, int(n_threads), float(seconds), C.byref(el))
+    return int(done), float(el.value)
 
 
 # --- small helpers for unit tests -------------------------------------------------------------

@@ -1660,3 +1660,65 @@ void plsvo_oracle_update_point_seed(float x, float tau2, float state[5]) {
   b = a * (1.0f - fq) / fq;
   state[0] = a; state[1] = b; state[2] = mu; state[4] = sigma2;
 }
+
+/* ============================================================================================ */
+/* CPU-baseline harness: the two hot functions over independent streams on n_threads POSIX threads */
+/* (bench.py's cpu_baseline leg; the reference itself is single-threaded on this path)           */
+/* ============================================================================================ */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+  int tid, n_threads, n_streams, max_seg, max_pts;
+  const plsvo_align_in* aj; const plsvo_oracle_pyr* ref; const plsvo_oracle_pyr* cur; const plsvo_poseopt_in* pj;
+  double seconds; long long done;
+} bench_arg_t;
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+
+static void* bench_worker(void* p) {
+  bench_arg_t* a = (bench_arg_t*)p;
+  uint8_t* alive = (uint8_t*)malloc((size_t)a->max_seg + 1);
+  uint8_t* pk = (uint8_t*)malloc((size_t)a->max_pts + 1);
+  uint8_t* sk = (uint8_t*)malloc((size_t)a->max_seg + 1);
+  const double t_end = now_s() + a->seconds;
+  long long done = 0;
+  int n_log = 0;
+  for (int i = a->tid; now_s() < t_end; i += a->n_threads) {
+    const int s = i % a->n_streams;
+    plsvo_align_out ao; memset(&ao, 0, sizeof(ao)); ao.seg_alive_out = alive;
+    plsvo_oracle_sparse_align(&a->aj[s], &a->ref[s], &a->cur[s], &ao, NULL, 0, &n_log);
+    plsvo_poseopt_out po; memset(&po, 0, sizeof(po)); po.pt_keep = pk; po.seg_keep = sk;
+    plsvo_oracle_pose_optimize(&a->pj[s], &po, NULL, 0, &n_log);
+    ++done;
+  }
+  free(alive); free(pk); free(sk);
+  a->done = done;
+  return NULL;
+}
+
+/* runs SparseImgAlign::run + optimizeGaussNewton on streams 0..n_streams-1 (round-robin over the threads) for `seconds`;
+ * returns the number of frames completed by all threads, *elapsed gets the wall time */
+long long plsvo_oracle_bench(int n_streams, const plsvo_align_in* aj, const plsvo_oracle_pyr* ref, const plsvo_oracle_pyr* cur,
+                             const plsvo_poseopt_in* pj, int n_threads, double seconds, double* elapsed) {
+  if (n_streams <= 0 || n_threads <= 0) return -1;
+  int max_seg = 1, max_pts = 1;
+  for (int s = 0; s < n_streams; ++s) {
+    if (aj[s].n_seg > max_seg) max_seg = aj[s].n_seg;
+    if (pj[s].n_seg > max_seg) max_seg = pj[s].n_seg;
+    if (pj[s].n_pts > max_pts) max_pts = pj[s].n_pts;
+  }
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+  bench_arg_t* args = (bench_arg_t*)malloc(sizeof(bench_arg_t) * (size_t)n_threads);
+  const double t0 = now_s();
+  for (int t = 0; t < n_threads; ++t) {
+    bench_arg_t a = { t, n_threads, n_streams, max_seg, max_pts, aj, ref, cur, pj, seconds, 0 };
+    args[t] = a;
+    pthread_create(&th[t], NULL, bench_worker, &args[t]);
+  }
+  long long total = 0;
+  for (int t = 0; t < n_threads; ++t) { pthread_join(th[t], NULL); total += args[t].done; }
+  if (elapsed) *elapsed = now_s() - t0;
+  free(th); free(args);
+  return total;
+}

@@ -138,3 +138,13 @@ def test_camera_roundtrip(ob, P):
     xyz = f * 3.7
     ob.lib().plsvo_oracle_world2cam(C.byref(cam), xyz.ctypes.data_as(P.abi.c_double_p), back.ctypes.data_as(P.abi.c_double_p))
     assert np.allclose(back, px, atol=1e-12)
+
+
+def test_cpu_baseline_harness_runs_the_two_hot_functions_on_threads(P, ob):
+    """bench.py's cpu_baseline leg: frames are counted inside the oracle library, on POSIX threads"""
+    import helpers as Hh
+    cases = [Hh.make_case(ob, 300 + i, 160, 120, 20, 6, 4, 3, 1) for i in range(3)]
+    pj = [P.poseopt_job_from_frame(P.synth.make_poseopt_frame(300 + i, 40, 10)) for i in range(3)]
+    d1, t1 = ob.bench([c[3] for c in cases], [c[1] for c in cases], [c[2] for c in cases], pj, 1, 0.3)
+    d2, t2 = ob.bench([c[3] for c in cases], [c[1] for c in cases], [c[2] for c in cases], pj, 2, 0.3)
+    assert d1 > 0 and d2 > 0 and 0.25 < t1 < 2.0 and 0.25 < t2 < 2.0
