@@ -14,6 +14,7 @@ result poses (7 doubles each), once per step.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
 import argparse
+import math
 import importlib
 import json
 import os
@@ -32,6 +33,24 @@ BYTES_PER_PATCH_ITER = 485      # residual/Jacobian, per patch-i
 W, H = 640, 480
 N_PTS, N_SEG = 200, 80
 N_PYR, MAX_LEVEL, MIN_LEVEL = 4, 3, 1
+
+
+def host_cores():
+    """threads worth starting for the CPU baseline: the affinity mask, capped by the container's CPU quota (cgroup v2/v1)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(math.ceil(int(q) / int(p)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(math.ceil(q / p))))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def main():
@@ -197,11 +216,12 @@ def main():
             # the timed loops run inside the oracle library (POSIX threads, no Python between frames)
             half = 0.5 * args.cpu_seconds
             done1, tc1 = ob.bench(align_jobs[:n_s], [p[0] for p in pyrs], [p[1] for p in pyrs], pose_jobs[:n_s], 1, half)
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = host_cores()
             doneN, tcN = ob.bench(align_jobs[:n_s], [p[0] for p in pyrs], [p[1] for p in pyrs], pose_jobs[:n_s], cores, half)
             result["cpu_baseline"] = {"value": round(doneN / tcN, 2), "unit": "frames/s", "cores": cores, "kind": "port",
                                       "sample": f"{doneN} frames on {cores} threads in {tcN:.1f} s (independent streams, round-robin over the first "
                                                 f"{n_s} streams of the timed batch), oracle/libplsvo_oracle.so, timed inside the library",
+                                      "scaling_over_one_thread": round((doneN / tcN) / (done1 / tc1), 2),
                                       "single_thread_value": round(done1 / tc1, 2),
                                       "single_thread_sample": f"{done1} frames in {tc1:.1f} s on one thread"}
             result["speedup_vs_cpu_all_cores"] = round(value / (doneN / tcN), 1)
