@@ -1,6 +1,8 @@
 /*
  * plsvo_hip.h -- C ABI of the MI355X (gfx950) hot path of PL-SVO:
- *   sparse image alignment (points + sampled line segments) and motion-only pose optimisation.
+ *   sparse image alignment (points + sampled line segments) and motion-only pose optimisation,
+ *   plus the steps either side of it: device pyramids, map reprojection, direct feature
+ *   matching, structure optimisation, depth-filter seed updates, trajectory records.
  *
  * This header IS the drop-in boundary.  The reference has no FFI layer; its boundary is two C++
  * call signatures (reference file:line given per entry point below).  The C++ adapter in

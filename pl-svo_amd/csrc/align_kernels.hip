@@ -330,7 +330,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       }
     }
     if (tid == 0) { SE3d m = se3_load(s_pose + 12); quat_to_matrix(m.q, s_pose); s_pose[9] = m.t[0]; s_pose[10] = m.t[1]; s_pose[11] = m.t[2]; }
-    __syncthreads();  // LDS image, pose state and cache complete
+    __syncthreads();  // patch tables, pose state and cache complete
     TICK(0);
 
     // ---- Gauss-Newton iterations ([ext] NLLSSolver::optimizeGaussNewton) ----
