@@ -413,11 +413,12 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
 
 // Launch configuration of the fused alignment kernel (measured on MI355X): 128 threads per workgroup (two
 // waves per frame pair; four workgroups share a CU at ~225 VGPRs), LDS holds only the per-patch tables.
-// Environment overrides (experiments only): PLSVO_ALIGN_THREADS, PLSVO_ALIGN_PER_LEVEL.
+// Environment overrides (experiments only): PLSVO_ALIGN_THREADS, PLSVO_ALIGN_PER_LEVEL, PLSVO_ALIGN_LDS_PAD.
 static void pick_align_config(int cap, int* threads, size_t* lds) {
   int t = 128;
   if (const char* s = getenv("PLSVO_ALIGN_THREADS")) { const int v = atoi(s); if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) t = v; }
   *threads = t; *lds = align_level_lds_bytes(t, cap);
+  if (const char* s = getenv("PLSVO_ALIGN_LDS_PAD")) *lds += (size_t)std::max(0, atoi(s));   // occupancy experiments: unused LDS bytes per workgroup
 }
 
 extern "C" int plsvo_align_run(plsvo_ctx* c) {
