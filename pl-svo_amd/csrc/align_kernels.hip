@@ -178,7 +178,9 @@ struct P1Fetch2 {
 // at four workgroups per CU (no difference), none (this code).
 template <int T>
 __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBatchDev b, int cap, int level_hi, int level_lo) {
-  const int job_id = blockIdx.x;
+  // longest-processing-time-first: the hardware hands out workgroups in blockIdx order, so the jobs with the most patches
+  // start first and the launch tail is made of the cheapest frames
+  const int job_id = b.order ? b.order[blockIdx.x] : (int)blockIdx.x;
   const AlignJobDev job = b.jobs[job_id];
   if (job.skip) return;
   const int lv_first = min(job.max_level, level_hi), lv_last = max(job.min_level, level_lo);

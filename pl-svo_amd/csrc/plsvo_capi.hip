@@ -83,7 +83,7 @@ struct plsvo_ctx {
   int a_cap[PLSVO_MAX_LEVELS]{};
   int a_trace_cap = 0;
   DevBuf a_d_jobs, a_d_state, a_d_T0, a_d_ptpx, a_d_ptxyz, a_d_spx, a_d_epx, a_d_len, a_d_p, a_d_q, a_d_alive_in, a_d_alive;
-  DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_cdx, a_d_cdy, a_d_partial, a_d_log, a_d_poses;
+  DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_cdx, a_d_cdy, a_d_partial, a_d_log, a_d_poses, a_d_order;
   AlignBatchDev a_b{};
 
   // pose-opt batch
@@ -189,7 +189,7 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
   for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_upload, &c->a_d_jobs, &c->a_d_state, &c->a_d_T0, &c->a_d_ptpx, &c->a_d_ptxyz, &c->a_d_spx,
                      &c->a_d_epx, &c->a_d_len, &c->a_d_p, &c->a_d_q, &c->a_d_alive_in, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv,
-                     &c->a_d_cref, &c->a_d_cdx, &c->a_d_cdy, &c->a_d_partial, &c->a_d_log, &c->a_d_poses, &c->p_d_jobs, &c->p_d_state,
+                     &c->a_d_cref, &c->a_d_cdx, &c->a_d_cdy, &c->a_d_partial, &c->a_d_log, &c->a_d_poses, &c->a_d_order, &c->p_d_jobs, &c->p_d_state,
                      &c->p_d_f, &c->p_d_pos, &c->p_d_plevel, &c->p_d_line, &c->p_d_spos, &c->p_d_epos, &c->p_d_slevel,
                      &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64, &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out };
   for (DevBuf* b : bufs) b->release();
@@ -324,6 +324,7 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   std::vector<uint8_t> alive;
   int gmax = -1, gmin = 99;
   int caps[PLSVO_MAX_LEVELS] = { 0 };
+  std::vector<long long> work((size_t)n, 0);   // patches summed over the levels, per job: the launch-order key
   size_t patch_total = 0;
   for (int j = 0; j < n; ++j) {
     const plsvo_align_in& a = in[j];
@@ -353,21 +354,29 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
     // patch capacity per level: every point + every sample of every segment (upper bound; the kernel
     // recomputes the same count on the device and checks it against this bound)
     int ub_min = 0;
+    long long ub_sum = 0;
     for (int l = a.max_level; l >= a.min_level; --l) {
       long long ub = a.n_pts;
       for (int s = 0; s < a.n_seg; ++s)
         ub += seg_num_samples(a.seg_spx[2 * s], a.seg_spx[2 * s + 1], a.seg_epx[2 * s], a.seg_epx[2 * s + 1], a.seg_len[s], l);
       if (ub > (1 << 20) - 8) return fail(c, PLSVO_E_CAPACITY, "align_stage: more than 2^20 patches in one job");
       const int ub4 = (int)((ub + 3) & ~3LL);
+      ub_sum += ub;
       if (!J.skip) caps[l] = std::max(caps[l], ub4);
       ub_min = std::max(ub_min, ub4);
     }
     J.patch_off = (int)patch_total; J.patch_cap = ub_min;
+    work[(size_t)j] = J.skip ? 0 : ub_sum;
     patch_total += (size_t)ub_min;
     if (patch_total > (size_t)0x7fffffff / 16) return fail(c, PLSVO_E_CAPACITY, "align_stage: batch too large (patch index overflow)");
     if (!J.skip) { gmax = std::max(gmax, a.max_level); gmin = std::min(gmin, a.min_level); }
   }
+  // launch order: most patches (summed over the levels) first; stable, so equal jobs keep their batch order
+  std::vector<int> order((size_t)n);
+  for (int j = 0; j < n; ++j) order[(size_t)j] = j;
+  if (!getenv("PLSVO_ALIGN_NO_LPT")) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return work[(size_t)x] > work[(size_t)y]; });
   int rc;
+  if ((rc = upload(c, c->a_d_order, order))) return rc;
   if ((rc = upload(c, c->a_d_jobs, jobs))) return rc;
   if ((rc = upload(c, c->a_d_T0, T0))) return rc;
   if ((rc = upload(c, c->a_d_ptpx, ptpx))) return rc;
@@ -404,6 +413,7 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   b.log = c->a_trace_cap > 0 ? c->a_d_log.as<plsvo_align_iterlog>() : nullptr;
   b.log_cap = c->a_trace_cap;
   b.n_jobs = n;
+  b.order = c->a_d_order.as<int>();
   c->a_jobs.swap(jobs);
   c->a_n = n; c->a_total_seg = (int)alive.size(); c->a_gmax = gmax; c->a_gmin = gmin;
   for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) c->a_cap[l] = caps[l];

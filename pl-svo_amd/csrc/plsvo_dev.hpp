@@ -83,6 +83,7 @@ struct AlignBatchDev {
   plsvo_align_iterlog* log;    // log_cap per job, or null
   int log_cap;
   int n_jobs;
+  const int* order;            // launch order: workgroup w works on job order[w] (jobs with the most patches first), or null
 };
 
 struct PoseJobDev {
