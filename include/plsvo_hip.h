@@ -344,12 +344,12 @@ typedef struct plsvo_match_out {    /* caller buffers; any of them may be NULL *
 
 int plsvo_match_direct(plsvo_ctx* ctx, const plsvo_match_in* in, plsvo_match_out* out);
 
-/* Reprojector::reproject(frame, Point*) / (frame, LineSeg*) (src/reprojector.cpp:387-423): the projection of map
+/* Reprojector::reproject(frame, Point*) / (frame, LineSeg*) (src/reprojector.cpp:389-423): the projection of map
  * landmarks into a frame that produces the candidates (and their initial px_cur) for plsvo_match_direct.
  *   px[i]   = frame->w2c(pos[i]) = world2cam(T_f_w * pos[i])                      (include/plsvo/frame.h:113)
  *   cell[i] = (int)(px.y / cell_size) * grid_n_cols + (int)(px.x / cell_size)    when isInFrame(px.cast<int>(), 8),
  *             -1 otherwise (the reference then rejects the landmark; a segment needs both end points in frame and
- *             is filed under both cells, :403-419 -- the caller ANDs, like for plsvo_match_direct)
+ *             is filed under both cells, :405-421 -- the caller ANDs, like for plsvo_match_direct)
  * The grid itself (cells, random visit order, one match per cell) is host control flow and stays with the caller. */
 typedef struct plsvo_reproject_in {
   plsvo_pinhole cam;
@@ -357,7 +357,7 @@ typedef struct plsvo_reproject_in {
   int32_t n;                        /* landmark positions (points, segment start points, segment end points) */
   int32_t cell_size;                /* Config::gridSize() (points) or gridSizeSegs() (segments) */
   int32_t grid_n_cols;              /* ceil(width / cell_size)  (reprojector.cpp:59, :71) */
-  int32_t boundary;                 /* 8: "the patch size in the matcher" (:391) */
+  int32_t boundary;                 /* 8: "the patch size in the matcher" (:393) */
   int32_t reserved0;
   const double* frame_T;            /* 7*n_frames  Frame::T_f_w_ */
   const int32_t* frame;             /* n: index of the frame each position is projected into */

@@ -1263,7 +1263,7 @@ int plsvo_oracle_match_direct(const plsvo_match_in* in, const plsvo_oracle_pyr* 
   return PLSVO_OK;
 }
 
-/* Reprojector::reproject for points and segment end points (src/reprojector.cpp:387-423) */
+/* Reprojector::reproject for points and segment end points (src/reprojector.cpp:389-423) */
 int plsvo_oracle_reproject(const plsvo_reproject_in* in, plsvo_reproject_out* out) {
   if (!in || !out || in->n < 0 || in->cell_size <= 0) return PLSVO_E_INVALID;
   for (int i = 0; i < in->n; ++i) {
@@ -1277,7 +1277,7 @@ int plsvo_oracle_reproject(const plsvo_reproject_in* in, plsvo_reproject_out* ou
     if (px[0] == px[0] && px[1] == px[1] && fabs(px[0]) < 1e9 && fabs(px[1]) < 1e9) {
       const int ox = (int)px[0], oy = (int)px[1];
       if (ox >= in->boundary && ox < in->cam.width - in->boundary && oy >= in->boundary && oy < in->cam.height - in->boundary)
-        cell = (int)(px[1] / in->cell_size) * in->grid_n_cols + (int)(px[0] / in->cell_size);   /* :393-394 */
+        cell = (int)(px[1] / in->cell_size) * in->grid_n_cols + (int)(px[0] / in->cell_size);   /* :397-398 */
     }
     if (out->px) { out->px[2 * i] = px[0]; out->px[2 * i + 1] = px[1]; }
     if (out->cell) out->cell[i] = cell;

@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(MT) match_direct_kernel(const MatchBatchDev b)
   b.n_iter[i] = iters;
 }
 
-// Reprojector::reproject (src/reprojector.cpp:387-423): one lane per landmark position
+// Reprojector::reproject (src/reprojector.cpp:389-423): one lane per landmark position
 __global__ void __launch_bounds__(256) reproject_kernel(const ReprojBatchDev b) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= b.n) return;

@@ -1,4 +1,4 @@
-"""Reprojection of landmarks into a frame (Reprojector::reproject, src/reprojector.cpp:387-423) -- the producer of the
+"""Reprojection of landmarks into a frame (Reprojector::reproject, src/reprojector.cpp:389-423) -- the producer of the
 direct matcher's candidates -- and the trajectory wire format of the reference's harness (app/run_pipeline.cpp:425-451).
 CPU: oracle against NumPy and known answers.  GPU: bit-exact against the oracle."""
 import numpy as np
