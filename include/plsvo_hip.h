@@ -245,8 +245,8 @@ int plsvo_poseopt_work(plsvo_ctx* ctx, uint64_t* pt_iters, uint64_t* seg_iters);
 
 /* ------------------------------------------------------------------------------------------ */
 /* structure optimisation (hot-path contract row (f) "next" #3)                                */
-/* replaces plsvo::Point::optimize / plsvo::LineSeg::optimize (src/feature3D_impl.cpp:36-96,   */
-/* :98-175), called from FrameHandlerBase::optimizeStructure (src/frame_handler_base.cpp:      */
+/* replaces plsvo::Point::optimize / plsvo::LineSeg::optimize (src/feature3D_impl.cpp:36-95,   */
+/* :97-174), called from FrameHandlerBase::optimizeStructure (src/frame_handler_base.cpp:      */
 /* 202-237; call site src/frame_handler_mono.cpp:340)                                          */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -290,11 +290,11 @@ int plsvo_structure_optimize(plsvo_ctx* ctx, const plsvo_structopt_in* in, plsvo
 
 /* ------------------------------------------------------------------------------------------ */
 /* direct feature matching (hot-path contract row (f) "next" #2)                               */
-/* replaces plsvo::Matcher::findMatchDirect for points (src/matcher.cpp:157-208) and for line  */
-/* segments (:233-280), with everything they call: warp::getWarpMatrixAffine (:40-68),         */
-/* warp::getBestSearchLevel (:70-84), warp::warpAffine (:86-128),                              */
-/* Matcher::createPatchFromPatchWithBorder (:146-155), Matcher::precomputeRefPatch (:210-231), */
-/* feature_alignment::align1D (src/feature_alignment.cpp:41-157) and align2D (:159-283).       */
+/* replaces plsvo::Matcher::findMatchDirect for points (src/matcher.cpp:159-207) and for line  */
+/* segments (:232-275), with everything they call: warp::getWarpMatrixAffine (:44-71),         */
+/* warp::getBestSearchLevel (:73-86), warp::warpAffine (:88-129),                              */
+/* Matcher::createPatchFromPatchWithBorder (:148-157), Matcher::precomputeRefPatch (:209-230), */
+/* feature_alignment::align1D (src/feature_alignment.cpp:41-158) and align2D (:160-290).       */
 /* Call sites: Reprojector::refineBestCandidate (src/reprojector.cpp:288, :348).               */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -305,7 +305,7 @@ int plsvo_structure_optimize(plsvo_ctx* ctx, const plsvo_structopt_in* in, plsvo
  * frame cur_frame[i], starting from px_cur[i] (the landmark's projection, written by Reprojector), against the
  * 8x8 patch around the landmark's closest-view observation (Point::getCloseViewObs, chosen by the host).
  * A line segment contributes two candidates (start and end point, each with its own pos / px / f); the
- * caller ANDs the two `found` flags like matcher.cpp:258-279.  Images are the ctx's pyramid slots.
+ * caller ANDs the two `found` flags like matcher.cpp:253-274.  Images are the ctx's pyramid slots.
  *   frame_T      7*n_frames  Frame::T_f_w_ of every frame referenced
  *   frame_slot   n_frames    pyramid slot holding that frame's Frame::img_pyr_
  *   cur_frame    n           index of the frame matched into
@@ -317,7 +317,7 @@ int plsvo_structure_optimize(plsvo_ctx* ctx, const plsvo_structopt_in* in, plsvo
  *   px_cur       2*n         initial estimate in level-0 pixels of the current image */
 typedef struct plsvo_match_in {
   plsvo_pinhole cam;                /* ref_ftr_->frame->cam_ == cur_frame.cam_ (one camera) */
-  int32_t n_pyr_levels;             /* Config::nPyrLevels(): search level <= n_pyr_levels-1 (matcher.cpp:172) */
+  int32_t n_pyr_levels;             /* Config::nPyrLevels(): search level <= n_pyr_levels-1 (matcher.cpp:177) */
   int32_t align_max_iter;           /* Matcher::Options::align_max_iter (10, include/plsvo/matcher.h:98) */
   int32_t n_frames;
   int32_t n;
@@ -336,7 +336,7 @@ typedef struct plsvo_match_in {
 
 typedef struct plsvo_match_out {    /* caller buffers; any of them may be NULL */
   double* px_cur;                   /* 2*n  refined position (level-0 pixels); the input value when the
-                                       reference observation is too close to the border (matcher.cpp:166-168) */
+                                       reference observation is too close to the border (matcher.cpp:168-170) */
   uint8_t* found;                   /* n    findMatchDirect's return value */
   int32_t* search_level;            /* n    Matcher::search_level_ (-1 when rejected before the warp) */
   int32_t* n_iter;                  /* n    residual passes executed by align1D/align2D */
@@ -380,24 +380,24 @@ int plsvo_trajectory_record(const double T_f_w[7], const double cov[36], double 
 /* ------------------------------------------------------------------------------------------ */
 /* depth-filter seed update (hot-path contract row (f) "next" #4, last item)                   */
 /* replaces the per-seed bodies of DepthFilter::updatePointSeeds / updateLineSeeds             */
-/* (src/depth_filter.cpp:270-368, :370-471) with everything they call:                         */
-/* Matcher::findEpipolarMatchDirect (src/matcher.cpp:276-416) and                              */
-/* findEpipolarMatchDirectSegmentEndpoint (:418-611), depthFromTriangulation (:132-145),       */
-/* [ext] vk::patch_score::ZMSSD<4>, DepthFilter::computeTau (src/depth_filter.cpp:604-620),    */
-/* updatePointSeed (:489-515), updateLineSeed (:517-576).                                      */
-/* The seed lists, the batch-age test (:290-293), the converged-seed callbacks and the         */
+/* (src/depth_filter.cpp:270-365, :367-471) with everything they call:                         */
+/* Matcher::findEpipolarMatchDirect (src/matcher.cpp:277-420) and                              */
+/* findEpipolarMatchDirectSegmentEndpoint (:422-586), depthFromTriangulation (:133-146),       */
+/* [ext] vk::patch_score::ZMSSD<4>, DepthFilter::computeTau (src/depth_filter.cpp:568-584),    */
+/* updatePointSeed (:489-512), updateLineSeed (:514-566).                                      */
+/* The seed lists, the batch-age test (:289-292), the converged-seed callbacks and the         */
 /* detector's grid occupancy stay on the host; this call maps seed state -> seed state.        */
 /* ------------------------------------------------------------------------------------------ */
 
-#define PLSVO_SEED_NOT_VISIBLE 0    /* behind the camera or outside the image: unchanged (:298-305) */
-#define PLSVO_SEED_NO_MATCH    1    /* epipolar search failed: b += 1 (:313-319) */
+#define PLSVO_SEED_NOT_VISIBLE 0    /* behind the camera or outside the image: unchanged (:296-304) */
+#define PLSVO_SEED_NO_MATCH    1    /* epipolar search failed: b += 1 (:311-318) */
 #define PLSVO_SEED_UPDATED     2    /* Bayesian update applied, seed stays */
-#define PLSVO_SEED_CONVERGED   3    /* updated and sqrt(sigma2) < z_range/thresh: the host creates the landmark from xyz_world and removes the seed (:335-358) */
-#define PLSVO_SEED_NAN         4    /* updated but z_inv_min was NaN: the host removes the seed (:359-363) */
+#define PLSVO_SEED_CONVERGED   3    /* updated and sqrt(sigma2) < z_range/thresh: the host creates the landmark from xyz_world and removes the seed (:334-355) */
+#define PLSVO_SEED_NAN         4    /* updated but z_inv_min was NaN: the host removes the seed (:356-360) */
 
-/* float fields are the reference's float members of PointSeed / LineSeed (include/plsvo/depth_filter.h:61-100).
+/* float fields are the reference's float members of PointSeed / LineSeed (include/plsvo/depth_filter.h:60-96).
  * Point seed i: ref feature (frame pt_ref_frame[i], px, f, level, type, grad) + Beta/normal parameters.
- * Line seed i: Feature::px / f (what the reference hands to the end-point search for BOTH end points, :404-407),
+ * Line seed i: Feature::px / f (what the reference hands to the end-point search for BOTH end points, :411-414),
  * LineFeat::sf / ef (used for visibility, tau and the landmark), level, and the two-ended parameters. */
 typedef struct plsvo_seeds_in {
   plsvo_pinhole cam;
@@ -406,7 +406,7 @@ typedef struct plsvo_seeds_in {
   int32_t max_epi_search_steps;     /* Matcher::Options::max_epi_search_steps (1000) */
   int32_t edgelet_filtering;        /* Matcher::Options::epi_search_edgelet_filtering (1) */
   double edgelet_max_angle;         /* Matcher::Options::epi_search_edgelet_max_angle (0.7) */
-  double px_noise;                  /* 1.0 (:279) */
+  double px_noise;                  /* 1.0 (:279-280) */
   double convergence_sigma2_thresh; /* DepthFilter::Options::seed_convergence_sigma2_thresh (200.0) */
   int32_t n_frames;
   int32_t n_pt;
@@ -439,7 +439,7 @@ typedef struct plsvo_seeds_out {     /* caller buffers; any of them may be NULL 
   int32_t* pt_status;               /* n_pt PLSVO_SEED_* */
   float* pt_a; float* pt_b; float* pt_mu; float* pt_sigma2;
   double* pt_xyz_world;             /* 3*n_pt, valid for PLSVO_SEED_CONVERGED */
-  double* pt_px_cur;                /* 2*n_pt Matcher::px_cur_ after a successful match (for setGridOccpuancy, :330-333) */
+  double* pt_px_cur;                /* 2*n_pt Matcher::px_cur_ after a successful match (for setGridOccpuancy, :327-331) */
   double* pt_depth;                 /* n_pt   the triangulated depth z of a successful match */
   int32_t* seg_status;
   float* seg_a; float* seg_b; float* seg_mu_s; float* seg_mu_e; float* seg_sigma2_s; float* seg_sigma2_e;

@@ -865,7 +865,7 @@ done:
 }
 
 /* ============================================================================================ */
-/* Point::optimize / LineSeg::optimize  src/feature3D_impl.cpp:36-175                            */
+/* Point::optimize / LineSeg::optimize  src/feature3D_impl.cpp:36-174                            */
 /* ============================================================================================ */
 
 /* [ext] Eigen::LDLT<Matrix3d>::compute + solve, the 3x3 instance of the algorithm restated above */
@@ -939,7 +939,7 @@ int plsvo_oracle_structure_optimize(const plsvo_structopt_in* in, plsvo_structop
   se3_t* T = (se3_t*)malloc(sizeof(se3_t) * (size_t)(in->n_frames > 0 ? in->n_frames : 1));
   double* Rm = (double*)malloc(sizeof(double) * 9 * (size_t)(in->n_frames > 0 ? in->n_frames : 1));
   for (int k = 0; k < in->n_frames; ++k) { T[k] = se3_load(in->frame_T + 7 * k); quat_to_matrix(T[k].q, Rm + 9 * k); }
-  /* Point::optimize :36-96 */
+  /* Point::optimize :36-95 */
   for (int i = 0; i < in->n_pts; ++i) {
     double pos[3] = { in->pt_pos[3 * i], in->pt_pos[3 * i + 1], in->pt_pos[3 * i + 2] };
     double old_point[3] = { pos[0], pos[1], pos[2] };
@@ -961,7 +961,7 @@ int plsvo_oracle_structure_optimize(const plsvo_structopt_in* in, plsvo_structop
     if (out->pt_pos) { out->pt_pos[3 * i] = pos[0]; out->pt_pos[3 * i + 1] = pos[1]; out->pt_pos[3 * i + 2] = pos[2]; }
     if (out->pt_iters) out->pt_iters[i] = iters;
   }
-  /* LineSeg::optimize :98-175: both end points advance together and roll back together */
+  /* LineSeg::optimize :97-174: both end points advance together and roll back together */
   for (int i = 0; i < in->n_seg; ++i) {
     double sp[3], ep[3], old_s[3], old_e[3];
     for (int k = 0; k < 3; ++k) { sp[k] = old_s[k] = in->seg_spos[3 * i + k]; ep[k] = old_e[k] = in->seg_epos[3 * i + k]; }
@@ -994,7 +994,7 @@ int plsvo_oracle_structure_optimize(const plsvo_structopt_in* in, plsvo_structop
 }
 
 /* ============================================================================================ */
-/* direct feature matching: Matcher::findMatchDirect (src/matcher.cpp:157-280) and callees      */
+/* direct feature matching: Matcher::findMatchDirect (src/matcher.cpp:159-275) and callees      */
 /* ============================================================================================ */
 /* Summation orders of the Eigen fixed-size float expressions below are restated from Eigen 3.2 (the
  * release contemporary with the reference; no version is pinned, CMakeLists.txt:39): coefficient-based
@@ -1005,7 +1005,7 @@ int plsvo_oracle_structure_optimize(const plsvo_structopt_in* in, plsvo_structop
 static int f2i_trunc(float x) { return isnan(x) ? INT32_MIN : (int)x; }
 
 /* [ext] vk::interpolateMat_8u (vikit/vision.h): bilinear lookup in float; the caller guarantees
- * 0 <= u < cols-1, 0 <= v < rows-1 (matcher.cpp:121) */
+ * 0 <= u < cols-1, 0 <= v < rows-1 (matcher.cpp:124) */
 static float interpolate_mat_8u(const uint8_t* img, int stride, float u, float v) {
   const int x = (int)floorf(u), y = (int)floorf(v);
   const float subpix_x = u - x, subpix_y = v - y;
@@ -1017,7 +1017,7 @@ static float interpolate_mat_8u(const uint8_t* img, int stride, float u, float v
   return w00 * ptr[0] + w01 * ptr[stride] + w10 * ptr[1] + w11 * ptr[stride + 1];
 }
 
-/* warp::getWarpMatrixAffine (matcher.cpp:40-68).  A is row-major {a00, a01, a10, a11}. */
+/* warp::getWarpMatrixAffine (matcher.cpp:44-71).  A is row-major {a00, a01, a10, a11}. */
 static void warp_matrix_affine(const plsvo_pinhole* cam, const double px_ref[2], const double f_ref[3],
                                double depth_ref, const se3_t* T_cur_ref, int level_ref, double A[4]) {
   const int halfpatch_size = 5;
@@ -1037,7 +1037,7 @@ static void warp_matrix_affine(const plsvo_pinhole* cam, const double px_ref[2],
   A[1] = (px_dv[0] - px_cur[0]) / halfpatch_size; A[3] = (px_dv[1] - px_cur[1]) / halfpatch_size;  /* col(1) */
 }
 
-/* warp::getBestSearchLevel (matcher.cpp:70-84) */
+/* warp::getBestSearchLevel (matcher.cpp:73-86) */
 static int best_search_level(const double A[4], int max_level) {
   int search_level = 0;
   double D = A[0] * A[3] - A[2] * A[1];   /* [ext] Eigen 2x2 determinant */
@@ -1045,7 +1045,7 @@ static int best_search_level(const double A[4], int max_level) {
   return search_level;
 }
 
-/* warp::warpAffine (matcher.cpp:86-128); returns 0 when the inverse warp is NaN (the reference then leaves
+/* warp::warpAffine (matcher.cpp:88-129); returns 0 when the inverse warp is NaN (the reference then leaves
  * the Matcher's previous patch in place, :96-100 -- state this restatement does not carry: such a candidate is
  * reported as not found) */
 static int warp_affine(const double A_cur_ref[4], const uint8_t* img_ref, int cols, int rows, int stride,
@@ -1073,7 +1073,7 @@ static int warp_affine(const double A_cur_ref[4], const uint8_t* img_ref, int co
 
 enum { M_PATCH = 8, M_HALF = 4, M_AREA = 64, M_STEP = 10 };
 
-/* feature_alignment::align2D (feature_alignment.cpp:159-283), scalar path */
+/* feature_alignment::align2D (feature_alignment.cpp:160-290), scalar path */
 static int align_2d(const uint8_t* cur_img, int cols, int rows, int cur_step, const uint8_t* ref_patch_with_border,
                     const uint8_t* ref_patch, int n_iter, double cur_px_estimate[2], int* iters) {
   int converged = 0;
@@ -1143,7 +1143,7 @@ static int align_2d(const uint8_t* cur_img, int cols, int rows, int cur_step, co
   return converged;
 }
 
-/* feature_alignment::align1D (feature_alignment.cpp:41-157) */
+/* feature_alignment::align1D (feature_alignment.cpp:41-158) */
 static int align_1d(const uint8_t* cur_img, int cols, int rows, int cur_step, const float dir[2],
                     const uint8_t* ref_patch_with_border, const uint8_t* ref_patch, int n_iter,
                     double cur_px_estimate[2], int* iters) {
@@ -1178,7 +1178,7 @@ static int align_1d(const uint8_t* cur_img, int cols, int rows, int cur_step, co
   for (; iter < n_iter; ++iter) {
     const int u_r = f2i_trunc(floorf(u)), v_r = f2i_trunc(floorf(v));
     if (u_r < M_HALF || v_r < M_HALF || u_r >= cols - M_HALF || v_r >= rows - M_HALF) break;
-    if (isnan(u) || isnan(v)) { *iters = iter; return 0; }   /* :92-93 returns without writing cur_px_estimate */
+    if (isnan(u) || isnan(v)) { *iters = iter; return 0; }   /* :94-95 returns without writing cur_px_estimate */
     const float subpix_x = u - u_r, subpix_y = v - v_r;
     const float wTL = (float)((1.0 - subpix_x) * (1.0 - subpix_y));
     const float wTR = (float)(subpix_x * (1.0 - subpix_y));
@@ -1198,7 +1198,7 @@ static int align_1d(const uint8_t* cur_img, int cols, int rows, int cur_step, co
         new_chi2 += res * res;
       }
     }
-    if (iter > 0 && new_chi2 > chi2) { u -= update[0]; v -= update[1]; ++iter; break; }   /* :126-134, as written */
+    if (iter > 0 && new_chi2 > chi2) { u -= update[0]; v -= update[1]; ++iter; break; }   /* :123-131, as written */
     chi2 = new_chi2;
     update[0] = Hinv[0][0] * Jres[0] + Hinv[0][1] * Jres[1];
     update[1] = Hinv[1][0] * Jres[0] + Hinv[1][1] * Jres[1];
@@ -1212,8 +1212,8 @@ static int align_1d(const uint8_t* cur_img, int cols, int rows, int cur_step, co
   return converged;
 }
 
-/* Matcher::findMatchDirect for one candidate: a point (matcher.cpp:157-208) or one end point of a line
- * segment (:210-231 + :258-277).  The closest-view observation has been chosen by the caller (:163, :240). */
+/* Matcher::findMatchDirect for one candidate: a point (matcher.cpp:159-207) or one end point of a line
+ * segment (:209-230 + :253-274).  The closest-view observation has been chosen by the caller (:165, :239). */
 int plsvo_oracle_match_direct(const plsvo_match_in* in, const plsvo_oracle_pyr* frames, plsvo_match_out* out) {
   if (!in || !out || in->n < 0 || in->n_frames <= 0 || !frames) return PLSVO_E_INVALID;
   const int halfpatch_size_ = 4;
@@ -1222,7 +1222,7 @@ int plsvo_oracle_match_direct(const plsvo_match_in* in, const plsvo_oracle_pyr* 
     double px_cur[2] = { in->px_cur[2 * i], in->px_cur[2 * i + 1] };
     int found = 0, search_level = -1, iters = 0;
     const double* rpx = in->ref_px + 2 * i;
-    /* :166-168  px.cast<int>() / (1<<level): truncation, then integer division */
+    /* :168-170  px.cast<int>() / (1<<level): truncation, then integer division */
     if (cam_is_in_frame(&in->cam, (int)rpx[0] / (1 << level), (int)rpx[1] / (1 << level), halfpatch_size_ + 2, level)) {
       const se3_t T_ref = se3_load(in->frame_T + 7 * rf), T_cur = se3_load(in->frame_T + 7 * cf);
       const se3_t T_ref_inv = se3_inv(&T_ref);
@@ -1238,7 +1238,7 @@ int plsvo_oracle_match_direct(const plsvo_match_in* in, const plsvo_oracle_pyr* 
       const plsvo_oracle_pyr* cp = &frames[cf];
       if (warp_affine(A, rp->img[level], rp->width[level], rp->height[level], rp->stride[level], rpx, level, search_level,
                       halfpatch_size_ + 1, patch_with_border)) {
-        for (int y = 1; y < M_PATCH + 1; ++y)          /* createPatchFromPatchWithBorder :146-155 */
+        for (int y = 1; y < M_PATCH + 1; ++y)          /* createPatchFromPatchWithBorder :148-157 */
           for (int x = 0; x < M_PATCH; ++x) patch[(y - 1) * M_PATCH + x] = patch_with_border[y * M_STEP + 1 + x];
         double px_scaled[2] = { px_cur[0] / (1 << search_level), px_cur[1] / (1 << search_level) };
         if (in->ref_type[i] == PLSVO_FTR_EDGELET) {
@@ -1321,7 +1321,7 @@ static int zmssd_score(const zmssd_t* z, const uint8_t* cur_patch, int stride) {
   return z->sumAA - 2 * sumAB + sumBB - (z->sumA * z->sumA - 2 * z->sumA * sumB + sumB * sumB) / M_AREA;
 }
 
-/* depthFromTriangulation (src/matcher.cpp:132-145) */
+/* depthFromTriangulation (src/matcher.cpp:133-146) */
 static int depth_from_triangulation(const se3_t* T_search_ref, const double f_ref[3], const double f_cur[3], double* depth) {
   double R[9], c0[3];
   quat_to_matrix(T_search_ref->q, R);                       /* rotation_matrix() * f_ref */
@@ -1342,8 +1342,8 @@ static int depth_from_triangulation(const se3_t* T_search_ref, const double f_re
   return 1;
 }
 
-/* Matcher::findEpipolarMatchDirect (src/matcher.cpp:276-416; segment_endpoint == 0) and
- * findEpipolarMatchDirectSegmentEndpoint (:418-611; segment_endpoint == 1).  Returns 1 on success. */
+/* Matcher::findEpipolarMatchDirect (src/matcher.cpp:277-420; segment_endpoint == 0) and
+ * findEpipolarMatchDirectSegmentEndpoint (:422-586; segment_endpoint == 1).  Returns 1 on success. */
 typedef struct { double px_cur[2]; int search_level; int reject; int n_evals; } epi_out_t;
 static int find_epipolar_match_direct(const plsvo_seeds_in* in, const plsvo_oracle_pyr* frames, int rf, int cf, const double px_ref[2],
                                       const double f_ref[3], int level, int type, const double grad[2], double d_estimate,
@@ -1355,7 +1355,7 @@ static int find_epipolar_match_direct(const plsvo_seeds_in* in, const plsvo_orac
   const se3_t T_cur_ref = se3_mul(&T_cur, &T_ref_inv);
   int zmssd_best = zmssd_threshold();
   double uv_best[2] = { 0.0, 0.0 };
-  if (segment_endpoint && (isnan(d_min) || isnan(d_max))) { eo->reject = 1; return 0; }         /* :433-437 */
+  if (segment_endpoint && (isnan(d_min) || isnan(d_max))) { eo->reject = 1; return 0; }         /* :436-440 */
   /* epipolar segment on the unit plane: A = project2d(T * (f*d_min)), B = project2d(T * (f*d_max)) */
   double pa[3] = { f_ref[0] * d_min, f_ref[1] * d_min, f_ref[2] * d_min }, pb[3] = { f_ref[0] * d_max, f_ref[1] * d_max, f_ref[2] * d_max };
   double ca[3], cb[3], A[2], B[2];
@@ -1364,7 +1364,7 @@ static int find_epipolar_match_direct(const plsvo_seeds_in* in, const plsvo_orac
   const double epi_dir[2] = { A[0] - B[0], A[1] - B[1] };
   double Aw[4];
   warp_matrix_affine(&in->cam, px_ref, f_ref, d_estimate, &T_cur_ref, level, Aw);
-  if (!segment_endpoint && type == PLSVO_FTR_EDGELET && in->edgelet_filtering) {                 /* :300-310 */
+  if (!segment_endpoint && type == PLSVO_FTR_EDGELET && in->edgelet_filtering) {                 /* :303-311 */
     double g[2] = { Aw[0] * grad[0] + Aw[1] * grad[1], Aw[2] * grad[0] + Aw[3] * grad[1] };
     const double gn = sqrt(g[0] * g[0] + g[1] * g[1]);
     g[0] /= gn; g[1] /= gn;
@@ -1379,8 +1379,8 @@ static int find_epipolar_match_direct(const plsvo_seeds_in* in, const plsvo_orac
   plsvo_oracle_world2cam(&in->cam, uvB, px_B);
   const double dA[2] = { px_A[0] - px_B[0], px_A[1] - px_B[1] };
   const double epi_length = sqrt(dA[0] * dA[0] + dA[1] * dA[1]) / (1 << search_level);
-  /* :460-464 (segments) reject NaN/inf before the warp; for points the reference runs into the step loop with an
-   * undefined n_steps (:352) -- both are reported as "no match" here */
+  /* :480-484 (segments) reject NaN/inf before the warp; for points the reference runs into the step loop with an
+   * undefined n_steps (:347) -- both are reported as "no match" here */
   if (isnan(epi_length) || isinf(epi_length)) { if (segment_endpoint) eo->reject = 1; return 0; }
   uint8_t patch_with_border[M_STEP * M_STEP], patch[M_AREA];
   const plsvo_oracle_pyr* rp = &frames[rf];
@@ -1392,7 +1392,7 @@ static int find_epipolar_match_direct(const plsvo_seeds_in* in, const plsvo_orac
   const int ccols = cp->width[search_level], crows = cp->height[search_level], cstride = cp->stride[search_level];
   const double sc = (double)(1 << search_level);
   int iters = 0;
-  if (epi_length < 2.0) {                                                                        /* :331-350 */
+  if (epi_length < 2.0) {                                                                        /* :325-344 */
     double px_scaled[2] = { ((px_A[0] + px_B[0]) / 2.0) / sc, ((px_A[1] + px_B[1]) / 2.0) / sc };
     eo->px_cur[0] = (px_A[0] + px_B[0]) / 2.0; eo->px_cur[1] = (px_A[1] + px_B[1]) / 2.0;
     if (align_2d(cimg, ccols, crows, cstride, patch_with_border, patch, in->align_max_iter, px_scaled, &iters)) {
@@ -1403,9 +1403,9 @@ static int find_epipolar_match_direct(const plsvo_seeds_in* in, const plsvo_orac
     }
     return 0;
   }
-  size_t n_steps = (size_t)(epi_length / 0.7);                                                    /* :352 */
+  size_t n_steps = (size_t)(epi_length / 0.7);                                                    /* :347 */
   const double step[2] = { epi_dir[0] / (double)n_steps, epi_dir[1] / (double)n_steps };
-  if (n_steps > (size_t)in->max_epi_search_steps) return 0;                                       /* :355-360 */
+  if (n_steps > (size_t)in->max_epi_search_steps) return 0;                                       /* :350-355 */
   zmssd_t score;
   zmssd_init(&score, patch);
   double uv[2] = { B[0] - step[0], B[1] - step[1] };
@@ -1419,13 +1419,13 @@ static int find_epipolar_match_direct(const plsvo_seeds_in* in, const plsvo_orac
     if (pxi0 == last_x && pxi1 == last_y) continue;
     last_x = pxi0; last_y = pxi1;
     if (!cam_is_in_frame(&in->cam, pxi0, pxi1, patch_size_, search_level)) continue;
-    /* the reference indexes with img.cols (:383-385); the pyramids here are tight (cols == step) */
+    /* the reference indexes with img.cols (:381-383); the pyramids here are tight (cols == step) */
     const uint8_t* cur_patch_ptr = cimg + (ptrdiff_t)(pxi1 - halfpatch_size_) * cstride + (pxi0 - halfpatch_size_);
     const int z = zmssd_score(&score, cur_patch_ptr, cstride);
     eo->n_evals += 1;
     if (z < zmssd_best) { zmssd_best = z; uv_best[0] = uv[0]; uv_best[1] = uv[1]; }
   }
-  if (zmssd_best < zmssd_threshold()) {                                                           /* :394-414 subpix_refinement = true */
+  if (zmssd_best < zmssd_threshold()) {                                                           /* :392-412 subpix_refinement = true */
     eo->px_cur[0] = in->cam.fx * uv_best[0] + in->cam.cx; eo->px_cur[1] = in->cam.fy * uv_best[1] + in->cam.cy;
     double px_scaled[2] = { eo->px_cur[0] / sc, eo->px_cur[1] / sc };
     if (align_2d(cimg, ccols, crows, cstride, patch_with_border, patch, in->align_max_iter, px_scaled, &iters)) {
@@ -1439,7 +1439,7 @@ static int find_epipolar_match_direct(const plsvo_seeds_in* in, const plsvo_orac
   return 0;
 }
 
-/* DepthFilter::computeTau (src/depth_filter.cpp:604-620) */
+/* DepthFilter::computeTau (src/depth_filter.cpp:568-584) */
 static double compute_tau(const se3_t* T_ref_cur, const double f[3], double z, double px_error_angle) {
   const double* t = T_ref_cur->t;
   const double a[3] = { f[0] * z - t[0], f[1] * z - t[1], f[2] * z - t[2] };
@@ -1464,8 +1464,8 @@ static float normal_pdf_f(float mean, float sd, float x) {
   return result;
 }
 
-/* one end of the Vogiatzis-Hernandez update: the common text of updatePointSeed (:489-515) and of the two halves of
- * updateLineSeed (:517-560).  Returns f and e through pointers; mu/sigma2 are updated in place. */
+/* one end of the Vogiatzis-Hernandez update: the common text of updatePointSeed (:489-512) and of the two halves of
+ * updateLineSeed (:514-552).  Returns f and e through pointers; mu/sigma2 are updated in place. */
 static void seed_update_end(float x, float tau2, float a, float b, float z_range, float* mu, float* sigma2, float norm_scale, float* f_out, float* e_out) {
   const float pdf = normal_pdf_f(*mu, norm_scale, x);
   float s2 = 1. / (1. / *sigma2 + 1. / tau2);
@@ -1497,12 +1497,12 @@ int plsvo_oracle_update_seeds(const plsvo_seeds_in* in, const plsvo_oracle_pyr* 
     const double* f = in->pt_f + 3 * i;
     const se3_t T_ref = se3_load(in->frame_T + 7 * rf), T_cur = se3_load(in->frame_T + 7 * cf);
     const se3_t T_cur_inv = se3_inv(&T_cur);
-    const se3_t T_ref_cur = se3_mul(&T_ref, &T_cur_inv);                         /* :296 */
+    const se3_t T_ref_cur = se3_mul(&T_ref, &T_cur_inv);                         /* :295 */
     const se3_t T_cur_ref = se3_inv(&T_ref_cur);
     const double s = 1.0 / mu;
     const double p[3] = { s * f[0], s * f[1], s * f[2] };
     double xyz_f[3], px[2];
-    se3_act(&T_cur_ref, p, xyz_f);                                               /* :297 */
+    se3_act(&T_cur_ref, p, xyz_f);                                               /* :296 */
     int visible = !(xyz_f[2] < 0.0);
     if (visible) {
       plsvo_oracle_world2cam(&in->cam, xyz_f, px);
@@ -1521,7 +1521,7 @@ int plsvo_oracle_update_seeds(const plsvo_seeds_in* in, const plsvo_oracle_pyr* 
         const double tau = compute_tau(&T_ref_cur, f, z, px_error_angle);
         const double zm = z - tau;
         const double tau_inverse = 0.5 * (1.0 / (0.0000001 < zm ? zm : 0.0000001) - 1.0 / (z + tau));
-        /* updatePointSeed(1./z, tau_inverse*tau_inverse, &*it) :489-515 */
+        /* updatePointSeed(1./z, tau_inverse*tau_inverse, &*it) :489-512 */
         const float x = (float)(1. / z), tau2 = (float)(tau_inverse * tau_inverse);
         const float norm_scale = sqrtf(sigma2 + tau2);
         if (!isnan(norm_scale)) {
@@ -1531,10 +1531,10 @@ int plsvo_oracle_update_seeds(const plsvo_seeds_in* in, const plsvo_oracle_pyr* 
           b = a * (1.0f - fq) / fq;
         }
         status = PLSVO_SEED_UPDATED;
-        if (sqrtf(sigma2) < z_range / in->convergence_sigma2_thresh) {            /* :335 */
+        if (sqrtf(sigma2) < z_range / in->convergence_sigma2_thresh) {            /* :334 */
           const double sw = 1.0 / mu;
           const double pw[3] = { f[0] * sw, f[1] * sw, f[2] * sw };
-          const se3_t T_ref_inv = se3_inv(&T_ref);                              /* :338 */
+          const se3_t T_ref_inv = se3_inv(&T_ref);                              /* :337 */
           se3_act(&T_ref_inv, pw, xyz_world);
           status = PLSVO_SEED_CONVERGED;
         } else if (isnan(z_inv_min)) {
@@ -1551,7 +1551,7 @@ int plsvo_oracle_update_seeds(const plsvo_seeds_in* in, const plsvo_oracle_pyr* 
     if (out->pt_px_cur) { out->pt_px_cur[2 * i] = eo.px_cur[0]; out->pt_px_cur[2 * i + 1] = eo.px_cur[1]; }
     if (out->pt_depth) out->pt_depth[i] = z;
   }
-  /* ---- line seeds: updateLineSeeds :370-471 ---- */
+  /* ---- line seeds: updateLineSeeds :367-471 ---- */
   for (int i = 0; i < in->n_seg; ++i) {
     float a = in->seg_a[i], b = in->seg_b[i], mu_s = in->seg_mu_s[i], mu_e = in->seg_mu_e[i];
     float sigma2_s = in->seg_sigma2_s[i], sigma2_e = in->seg_sigma2_e[i];
@@ -1584,7 +1584,7 @@ int plsvo_oracle_update_seeds(const plsvo_seeds_in* in, const plsvo_oracle_pyr* 
       const float z_inv_max_e = te_ > 0.00000001f ? te_ : 0.00000001f;
       const double g0[2] = { 0, 0 };
       epi_out_t eo;
-      /* both searches take Feature::px / Feature::f of the segment feature (*it->ftr), :404-407; the second is not
+      /* both searches take Feature::px / Feature::f of the segment feature (*it->ftr), :411-414; the second is not
        * evaluated when the first fails */
       if (!find_epipolar_match_direct(in, frames, rf, cf, in->seg_px + 2 * i, in->seg_f + 3 * i, in->seg_level[i], PLSVO_FTR_CORNER, g0,
                                       1.0 / mu_s, 1.0 / z_inv_min_s, 1.0 / z_inv_max_s, 1, &z_s, &eo) ||
@@ -1599,7 +1599,7 @@ int plsvo_oracle_update_seeds(const plsvo_seeds_in* in, const plsvo_oracle_pyr* 
         const double tau_e = compute_tau(&T_ref_cur, ef, z_e, px_error_angle);
         const double zme = z_e - tau_e;
         const double tau_inverse_e = 0.5 * (1.0 / (0.0000001 < zme ? zme : 0.0000001) - 1.0 / (z_e + tau_e));
-        /* updateLineSeed :517-576 */
+        /* updateLineSeed :514-566 */
         const float x_s = (float)(1. / z_s), tau2_s = (float)(tau_inverse_s * tau_inverse_s);
         const float x_e = (float)(1. / z_e), tau2_e = (float)(tau_inverse_e * tau_inverse_e);
         const float norm_scale_s = sqrtf(sigma2_s + tau2_s), norm_scale_e = sqrtf(sigma2_e + tau2_e);
@@ -1649,7 +1649,7 @@ int plsvo_oracle_depth_from_triangulation(const double T_search_ref[7], const do
 double plsvo_oracle_compute_tau(const double T_ref_cur[7], const double f[3], double z, double px_error_angle) {
   const se3_t T = se3_load(T_ref_cur); return compute_tau(&T, f, z, px_error_angle);
 }
-/* updatePointSeed (src/depth_filter.cpp:489-515): state = {a, b, mu, z_range, sigma2} in/out */
+/* updatePointSeed (src/depth_filter.cpp:489-512): state = {a, b, mu, z_range, sigma2} in/out */
 void plsvo_oracle_update_point_seed(float x, float tau2, float state[5]) {
   float a = state[0], b = state[1], mu = state[2], sigma2 = state[4];
   const float norm_scale = sqrtf(sigma2 + tau2);

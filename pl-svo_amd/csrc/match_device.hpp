@@ -3,10 +3,10 @@
 // inverse-compositional alignment on that patch.  Everything here follows the reference's expression order and the
 // including translation units are compiled with -ffp-contract=off, so results are bit-identical to the CPU oracle.
 //
-//   warp::getWarpMatrixAffine / getBestSearchLevel / warpAffine        src/matcher.cpp:40-128
-//   Matcher::createPatchFromPatchWithBorder                            src/matcher.cpp:146-155 (implicit: the 8x8 patch is
+//   warp::getWarpMatrixAffine / getBestSearchLevel / warpAffine        src/matcher.cpp:44-129
+//   Matcher::createPatchFromPatchWithBorder                            src/matcher.cpp:148-157 (implicit: the 8x8 patch is
 //                                                                      the interior of the LDS-resident 10x10 one)
-//   feature_alignment::align2D                                         src/feature_alignment.cpp:159-283
+//   feature_alignment::align2D                                         src/feature_alignment.cpp:160-290
 //   [ext] vk::PinholeCamera::world2cam / cam2world, vk::interpolateMat_8u, Eigen 2x2 / 3x3 inverse()
 #pragma once
 #include <hip/hip_runtime.h>
@@ -75,7 +75,7 @@ __device__ __forceinline__ int row_byte(uint32_t a, uint32_t b, uint32_t c, int 
   return (int)((w >> (8 * (k & 3))) & 0xffu);
 }
 
-// warp::getWarpMatrixAffine (matcher.cpp:40-68); A is row-major {a00, a01, a10, a11}
+// warp::getWarpMatrixAffine (matcher.cpp:44-71); A is row-major {a00, a01, a10, a11}
 __device__ __forceinline__ void warp_matrix_affine(const CamDev& cam, double rpx0, double rpx1, const double* f_ref, double depth_ref,
                                                    const SE3d& T_cur_ref, int level, double* A) {
   const int halfpatch_size = 5;
@@ -93,7 +93,7 @@ __device__ __forceinline__ void warp_matrix_affine(const CamDev& cam, double rpx
   A[1] = (pdv[0] - pc[0]) / halfpatch_size; A[3] = (pdv[1] - pc[1]) / halfpatch_size;
 }
 
-// warp::getBestSearchLevel (matcher.cpp:70-84)
+// warp::getBestSearchLevel (matcher.cpp:73-86)
 __device__ __forceinline__ int best_search_level(const double* A, int max_level) {
   int search_level = 0;
   double D = A[0] * A[3] - A[2] * A[1];
@@ -101,8 +101,8 @@ __device__ __forceinline__ int best_search_level(const double* A, int max_level)
   return search_level;
 }
 
-// warp::warpAffine with halfpatch 5 into the lane's LDS patch (matcher.cpp:86-128).  False when the inverse warp is
-// NaN (the reference then keeps the Matcher's previous patch, :96-100; such a candidate is reported as not found).
+// warp::warpAffine with halfpatch 5 into the lane's LDS patch (matcher.cpp:88-129).  False when the inverse warp is
+// NaN (the reference then keeps the Matcher's previous patch, :99-103; such a candidate is reported as not found).
 __device__ __forceinline__ bool warp_affine_lds(const double* A, const uint8_t* img_ref, int rcols, int rrows, double rpx0, double rpx1,
                                                 int level, int search_level, uint32_t* my) {
   const double det = A[0] * A[3] - A[2] * A[1];
@@ -130,7 +130,7 @@ __device__ __forceinline__ bool warp_affine_lds(const double* A, const uint8_t* 
   return true;   // every lane reads back only its own words: no barrier needed
 }
 
-// feature_alignment::align2D (feature_alignment.cpp:159-283) on the lane's LDS patch; est = cur_px_estimate in/out,
+// feature_alignment::align2D (feature_alignment.cpp:160-290) on the lane's LDS patch; est = cur_px_estimate in/out,
 // returns `converged`, iters = residual passes executed.  ref_patch_dx/dy are never materialised: 0.5*(it[1]-it[-1])
 // is exact in float and is recomputed from the LDS bytes.
 __device__ __forceinline__ bool align2d_lds(const uint8_t* cur_img, int cols, int rows, const uint32_t* my, int n_iter,

@@ -1,12 +1,12 @@
 // match_kernels.hip -- direct feature matching on gfx950: one LANE per match candidate.
 //
 // Replaces (reference file:line):
-//   plsvo::Matcher::findMatchDirect (Point)     src/matcher.cpp:157-208
-//   plsvo::Matcher::findMatchDirect (LineSeg)   src/matcher.cpp:233-280   (two candidates, ANDed by the caller)
-//   Matcher::precomputeRefPatch                 src/matcher.cpp:210-231
-//   Matcher::createPatchFromPatchWithBorder     src/matcher.cpp:146-155
-//   warp::getWarpMatrixAffine / getBestSearchLevel / warpAffine   src/matcher.cpp:40-128
-//   feature_alignment::align1D / align2D        src/feature_alignment.cpp:41-157, :159-283
+//   plsvo::Matcher::findMatchDirect (Point)     src/matcher.cpp:159-207
+//   plsvo::Matcher::findMatchDirect (LineSeg)   src/matcher.cpp:232-275   (two candidates, ANDed by the caller)
+//   Matcher::precomputeRefPatch                 src/matcher.cpp:209-230
+//   Matcher::createPatchFromPatchWithBorder     src/matcher.cpp:148-157
+//   warp::getWarpMatrixAffine / getBestSearchLevel / warpAffine   src/matcher.cpp:44-129
+//   feature_alignment::align1D / align2D        src/feature_alignment.cpp:41-158, :159-283
 //   Patch::setPosition / computeInterpWeights / setRoi / isInFrame  src/feature.cpp:189-218, include/plsvo/feature.h:139-144
 //   [ext] vk::interpolateMat_8u, vk::AbstractCamera::isInFrame, Eigen 2x2 / 3x3 inverse()
 // called once per selected map point / segment per frame from Reprojector::refineBestCandidate
@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(MT) match_direct_kernel(const MatchBatchDev b)
   const double rpx0 = b.ref_px[2 * i], rpx1 = b.ref_px[2 * i + 1];
   int found = 0, search_level = -1, iters = 0;
 
-  // matcher.cpp:166-168  isInFrame(px.cast<int>()/(1<<level), halfpatch_size_+2, level)
+  // matcher.cpp:168-170  isInFrame(px.cast<int>()/(1<<level), halfpatch_size_+2, level)
   if (cam_is_in_frame(cam, (int)rpx0 / (1 << level), (int)rpx1 / (1 << level), 6, level)) {
     const SE3d T_ref = se3_load(b.frame_T + 7 * rf), T_cur = se3_load(b.frame_T + 7 * cf);
     const SE3d T_ref_inv = se3_inv(T_ref);
@@ -60,11 +60,11 @@ __global__ void __launch_bounds__(MT) match_direct_kernel(const MatchBatchDev b)
       const int cols = b.width >> search_level, rows = b.height >> search_level;
       const uint8_t* cur_img = b.pyr_base + (unsigned long long)b.frame_slot[cf] * b.slot_bytes + pyr_level_offset(b.width, b.height, search_level);
       const double scale = (double)(1 << search_level);
-      double est0 = px_cur[0] / scale, est1 = px_cur[1] / scale;     // px_scaled (matcher.cpp:183)
+      double est0 = px_cur[0] / scale, est1 = px_cur[1] / scale;     // px_scaled (matcher.cpp:187)
       const float min_update_squared = (float)(0.03 * 0.03);
       const int n_iter = b.align_max_iter;
       if (b.ref_type[i] == PLSVO_FTR_EDGELET) {
-        // ---- feature_alignment::align1D (feature_alignment.cpp:41-157) ----
+        // ---- feature_alignment::align1D (feature_alignment.cpp:41-158) ----
         double dc0 = A[0] * b.ref_grad[2 * i] + A[1] * b.ref_grad[2 * i + 1], dc1 = A[2] * b.ref_grad[2 * i] + A[3] * b.ref_grad[2 * i + 1];
         const double nrm = sqrt(dc0 * dc0 + dc1 * dc1);
         dc0 /= nrm; dc1 /= nrm;

@@ -1,12 +1,12 @@
 // seeds_kernels.hip -- depth-filter seed update on gfx950: one LANE per seed.
 //
 // Replaces (reference file:line) the per-seed bodies of
-//   DepthFilter::updatePointSeeds / updateLineSeeds          src/depth_filter.cpp:270-368, :370-471
+//   DepthFilter::updatePointSeeds / updateLineSeeds          src/depth_filter.cpp:270-365, :367-471
 // with everything they call:
-//   Matcher::findEpipolarMatchDirect                         src/matcher.cpp:276-416
-//   Matcher::findEpipolarMatchDirectSegmentEndpoint          src/matcher.cpp:418-611
-//   depthFromTriangulation                                   src/matcher.cpp:132-145
-//   DepthFilter::computeTau / updatePointSeed / updateLineSeed   src/depth_filter.cpp:604-620, :489-515, :517-576
+//   Matcher::findEpipolarMatchDirect                         src/matcher.cpp:277-420
+//   Matcher::findEpipolarMatchDirectSegmentEndpoint          src/matcher.cpp:422-586
+//   depthFromTriangulation                                   src/matcher.cpp:133-146
+//   DepthFilter::computeTau / updatePointSeed / updateLineSeed   src/depth_filter.cpp:568-584, :489-512, :514-566
 //   [ext] vk::patch_score::ZMSSD<4>, boost::math::pdf(normal_distribution<float>), warp::*, align2D (match_device.hpp)
 // The seed lists, their age test, the converged-seed callbacks and the detector's grid occupancy stay on the host.
 //
@@ -26,7 +26,7 @@ namespace plsvo_hip {
 
 #pragma clang fp contract(off)
 
-// depthFromTriangulation (src/matcher.cpp:132-145)
+// depthFromTriangulation (src/matcher.cpp:133-146)
 __device__ __forceinline__ bool depth_from_triangulation(const SE3d& T_search_ref, const double* f_ref, const double* f_cur, double* depth) {
   double R[9], c0[3];
   quat_to_matrix(T_search_ref.q, R);
@@ -65,7 +65,7 @@ __device__ __noinline__ bool epipolar_search(const SeedsBatchDev& b, uint32_t* m
   const SE3d T_ref = se3_load(b.frame_T + 7 * rf), T_cur = se3_load(b.frame_T + 7 * cf);
   const SE3d T_ref_inv = se3_inv(T_ref);
   const SE3d T_cur_ref = se3_mul(T_cur, T_ref_inv);
-  if (seg && (d_min != d_min || d_max != d_max)) return false;                                   // :433-437
+  if (seg && (d_min != d_min || d_max != d_max)) return false;                                   // :436-440
   const double pa[3] = { f_ref[0] * d_min, f_ref[1] * d_min, f_ref[2] * d_min }, pb[3] = { f_ref[0] * d_max, f_ref[1] * d_max, f_ref[2] * d_max };
   double ca[3], cb[3];
   se3_act(T_cur_ref, pa, ca); se3_act(T_cur_ref, pb, cb);
@@ -73,7 +73,7 @@ __device__ __noinline__ bool epipolar_search(const SeedsBatchDev& b, uint32_t* m
   const double e0 = A0 - B0, e1 = A1 - B1;                                                       // epi_dir_
   double Aw[4];
   warp_matrix_affine(cam, rpx0, rpx1, f_ref, d_estimate, T_cur_ref, level, Aw);
-  if (!seg && type == PLSVO_FTR_EDGELET && b.edgelet_filtering) {                                // :300-310
+  if (!seg && type == PLSVO_FTR_EDGELET && b.edgelet_filtering) {                                // :303-311
     double h0 = Aw[0] * g0 + Aw[1] * g1, h1 = Aw[2] * g0 + Aw[3] * g1;
     const double gn = sqrt(h0 * h0 + h1 * h1);
     h0 /= gn; h1 /= gn;
@@ -92,7 +92,7 @@ __device__ __noinline__ bool epipolar_search(const SeedsBatchDev& b, uint32_t* m
   const uint8_t* cur_img = b.pyr_base + (unsigned long long)b.frame_slot[cf] * b.slot_bytes + pyr_level_offset(b.width, b.height, search_level);
   const double sc = (double)(1 << search_level);
   int iters = 0;
-  if (epi_length < 2.0) {                                                                        // :331-350
+  if (epi_length < 2.0) {                                                                        // :325-344
     px_cur[0] = (pxA0 + pxB0) / 2.0; px_cur[1] = (pxA1 + pxB1) / 2.0;
     double est0 = px_cur[0] / sc, est1 = px_cur[1] / sc;
     if (align2d_lds(cur_img, cols, rows, my, b.align_max_iter, est0, est1, iters)) {
@@ -103,9 +103,9 @@ __device__ __noinline__ bool epipolar_search(const SeedsBatchDev& b, uint32_t* m
     }
     return false;
   }
-  unsigned long long n_steps = (unsigned long long)(epi_length / 0.7);                            // :352
+  unsigned long long n_steps = (unsigned long long)(epi_length / 0.7);                            // :347
   const double step0 = e0 / (double)n_steps, step1 = e1 / (double)n_steps;
-  if (n_steps > (unsigned long long)b.max_epi_search_steps) return false;                         // :355-360
+  if (n_steps > (unsigned long long)b.max_epi_search_steps) return false;                         // :350-355
   // ZMSSD<4>: the warped reference patch = interior of the LDS patch, as 2 dwords per row
   uint32_t ra[8], rb[8], sumA = 0, sumAA = 0;
 #pragma unroll
@@ -143,7 +143,7 @@ __device__ __noinline__ bool epipolar_search(const SeedsBatchDev& b, uint32_t* m
     const int z = (int)sumAA - 2 * (int)sumAB + (int)sumBB - (sA * sA - 2 * sA * sB + sB * sB) / 64;
     if (z < zmssd_best) { zmssd_best = z; uvb0 = uv0; uvb1 = uv1; }
   }
-  if (zmssd_best < threshold) {                                                                  // :394-414
+  if (zmssd_best < threshold) {                                                                  // :392-412
     px_cur[0] = b.fx * uvb0 + b.cx; px_cur[1] = b.fy * uvb1 + b.cy;
     double est0 = px_cur[0] / sc, est1 = px_cur[1] / sc;
     if (align2d_lds(cur_img, cols, rows, my, b.align_max_iter, est0, est1, iters)) {
@@ -156,7 +156,7 @@ __device__ __noinline__ bool epipolar_search(const SeedsBatchDev& b, uint32_t* m
   return false;
 }
 
-// DepthFilter::computeTau (src/depth_filter.cpp:604-620)
+// DepthFilter::computeTau (src/depth_filter.cpp:568-584)
 __device__ __forceinline__ double compute_tau(const SE3d& T_ref_cur, const double* f, double z, double px_error_angle) {
   const double* t = T_ref_cur.t;
   const double a[3] = { f[0] * z - t[0], f[1] * z - t[1], f[2] * z - t[2] };
@@ -170,7 +170,7 @@ __device__ __forceinline__ double compute_tau(const SE3d& T_ref_cur, const doubl
   return z_plus - z;
 }
 
-// one end of the Vogiatzis-Hernandez update (updatePointSeed :489-515 and each half of updateLineSeed :517-560), in the
+// one end of the Vogiatzis-Hernandez update (updatePointSeed :489-512 and each half of updateLineSeed :514-552), in the
 // reference's mix of float and double; [ext] boost::math::pdf(normal_distribution<float>) written out
 __device__ __forceinline__ void seed_update_end(float x, float tau2, float a, float b, float z_range, float& mu, float& sigma2, float norm_scale,
                                                 float& f_out, float& e_out) {
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(MT) update_seeds_kernel(const SeedsBatchDev b)
   uint32_t* my = s_patch + lane;
   const CamDev cam{b.fx, b.fy, b.cx, b.cy, b.cam_width, b.cam_height};
   if (gi < b.n_pt) {
-    // ---- DepthFilter::updatePointSeeds, one seed (:296-363) ----
+    // ---- DepthFilter::updatePointSeeds, one seed (:295-360) ----
     const int i = gi;
     float a = b.pt_a[i], bb = b.pt_b[i], mu = b.pt_mu[i], sigma2 = b.pt_sigma2[i];
     const float z_range = b.pt_z_range[i];

@@ -1,8 +1,8 @@
 // structopt_kernels.hip -- structure optimisation on gfx950: one LANE per 3-D landmark.
 //
 // Replaces (reference file:line):
-//   plsvo::Point::optimize      src/feature3D_impl.cpp:36-96
-//   plsvo::LineSeg::optimize    src/feature3D_impl.cpp:98-175
+//   plsvo::Point::optimize      src/feature3D_impl.cpp:36-95
+//   plsvo::LineSeg::optimize    src/feature3D_impl.cpp:97-174
 //   Point::jacobian_xyz2uv      include/plsvo/feature3D.h:126-140
 //   [ext] Eigen::LDLT<Matrix3d>::solve
 // called per frame from FrameHandlerBase::optimizeStructure (src/frame_handler_base.cpp:202-237) on <= 20 points
@@ -88,7 +88,7 @@ __device__ __forceinline__ double norm_max3(const double* v) {
 
 __global__ __launch_bounds__(64) void structopt_kernel(StructBatchDev s) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < s.n_pts) {                                     // Point::optimize :36-96
+  if (idx < s.n_pts) {                                     // Point::optimize :36-95
     const int i = idx;
     double pos[3] = { s.pt_pos[3 * i], s.pt_pos[3 * i + 1], s.pt_pos[3 * i + 2] };
     double old_point[3] = { pos[0], pos[1], pos[2] };
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64) void structopt_kernel(StructBatchDev s) {
     }
     s.pt_pos_out[3 * i] = pos[0]; s.pt_pos_out[3 * i + 1] = pos[1]; s.pt_pos_out[3 * i + 2] = pos[2];
     s.pt_iters[i] = iters;
-  } else if (idx < s.n_pts + s.n_seg) {                    // LineSeg::optimize :98-175
+  } else if (idx < s.n_pts + s.n_seg) {                    // LineSeg::optimize :97-174
     const int i = idx - s.n_pts;
     double sp[3], ep[3], old_s[3], old_e[3];
     for (int k = 0; k < 3; ++k) { sp[k] = old_s[k] = s.seg_spos[3 * i + k]; ep[k] = old_e[k] = s.seg_epos[3 * i + k]; }

@@ -359,8 +359,8 @@ namespace plsvo {
 namespace structure_optimizer {
 
 /// Batched replacement of the two loops of FrameHandlerBase::optimizeStructure (src/frame_handler_base.cpp:213-236):
-///     for (it in selected points)  (*it)->optimize(max_iter);          -> Point::optimize    (src/feature3D_impl.cpp:36-96)
-///     for (it in selected segs)    (*it)->optimize(max_iter_segs);     -> LineSeg::optimize  (src/feature3D_impl.cpp:98-175)
+///     for (it in selected points)  (*it)->optimize(max_iter);          -> Point::optimize    (src/feature3D_impl.cpp:36-95)
+///     for (it in selected segs)    (*it)->optimize(max_iter_segs);     -> LineSeg::optimize  (src/feature3D_impl.cpp:97-174)
 /// The selection (nth_element on last_structure_optim_) and the last_structure_optim_ bookkeeping stay with the
 /// caller.  Iterators range over Point* / LineSeg*; observations are read from Feature3D::obs_
 /// (include/plsvo/feature3D.h) as (feature->frame->T_f_w_, feature->f | sf | ef).  Writes pos_ / spos_ / epos_.
@@ -463,7 +463,7 @@ struct FrameRegistry {
 
 namespace plsvo {
 
-/// Batched replacement of Matcher::findMatchDirect (include/plsvo/matcher.h:120-131, src/matcher.cpp:157-280), the
+/// Batched replacement of Matcher::findMatchDirect (include/plsvo/matcher.h:120-131, src/matcher.cpp:159-275), the
 /// call Reprojector::refineBestCandidate makes once per candidate (src/reprojector.cpp:288, :348):
 ///
 ///     DirectMatcher m(Config::nPyrLevels());                       // options_.align_max_iter = 10
@@ -529,7 +529,7 @@ class DirectMatcher {
     return true;
   }
 
-  /// findMatchDirect's return value: a point's flag, or start & end for a segment (matcher.cpp:258-279)
+  /// findMatchDirect's return value: a point's flag, or start & end for a segment (matcher.cpp:253-274)
   bool found(int h) const {
     const Item& it = items_[(size_t)h];
     bool f = true;
@@ -574,7 +574,7 @@ class DirectMatcher {
 namespace plsvo {
 namespace depth_filter {
 
-/// The reference's defaults (DepthFilter::Options include/plsvo/depth_filter.h:112-131, Matcher::Options matcher.h:88-106)
+/// The reference's defaults (DepthFilter::Options include/plsvo/depth_filter.h:113-131, Matcher::Options matcher.h:88-106)
 struct SeedUpdateOptions {
   int n_pyr_levels;                  // Config::nPyrLevels()
   int max_n_kfs;                     // DepthFilter::Options::max_n_kfs
@@ -588,14 +588,14 @@ struct SeedUpdateOptions {
 
 /// Batched replacement of DepthFilter::updateSeeds(frame) (src/depth_filter.cpp:262-471): every seed of both lists is
 /// updated against `frame` in ONE launch, then the lists are walked once in the reference's order to apply exactly its
-/// mutations: seeds older than max_n_kfs batches are erased (:290-293, :386-389), `b++` on a failed search, the new
+/// mutations: seeds older than max_n_kfs batches are erased (:289-292, :386-389), `b++` on a failed search, the new
 /// a/b/mu/sigma2, converged seeds are handed to the callbacks with their world position(s) and erased (:335-358,
 /// :438-462), NaN seeds are erased.  The callbacks create the landmark (`new Point(xyz_world, it->ftr)`,
 /// `it->ftr->feat3D = point`, seed_converged_cb_) -- map objects stay host business:
 ///     on_point(seed, xyz_world[3]);   on_segment(seed, xyz_world_s[3], xyz_world_e[3]);
 /// Seed types are duck-typed on the reference's members (batch_id, ftr, a, b, mu, z_range, sigma2 / the _s _e pairs).
 /// Not reproduced: seeds_updating_halt_ (a launch is not interruptible) and the detector's setGridOccpuancy
-/// (:330-333; feature detection is outside this path).
+/// (:327-331; feature detection is outside this path).
 template <class FrameT, class PointSeedList, class LineSeedList, class OnPoint, class OnSegment>
 bool updateSeeds(const FrameT& frame, PointSeedList& pt_seeds, LineSeedList& seg_seeds, int batch_counter, const SeedUpdateOptions& opt,
                  OnPoint on_point, OnSegment on_segment) {

@@ -1,6 +1,6 @@
 """Depth-filter seed update (hot-path contract row (f) #4, last item): the per-seed bodies of
 DepthFilter::updatePointSeeds / updateLineSeeds (src/depth_filter.cpp:270-471) with the epipolar search of
-src/matcher.cpp:276-611, ZMSSD scoring, triangulation, computeTau and the Gaussian x Beta posterior update.
+src/matcher.cpp:277-586, ZMSSD scoring, triangulation, computeTau and the Gaussian x Beta posterior update.
 CPU: the oracle converges to the true depths on a synthetic sequence and honours the reference's status logic.
 GPU: statuses, integer-scored matches and triangulated depths equal the oracle's; the float posterior agrees to the
 last-bit differences of device exp/acos/sin."""
@@ -46,7 +46,7 @@ def test_oracle_seeds_converge_to_the_true_depth(P, ob, seqm):
     err = np.abs(1 / pt["mu"] - truth["pt_depth"]) / truth["pt_depth"]
     assert np.median(err) < 0.02 < err0 and np.median(np.sqrt(pt["sigma2"])) < 0.2 * sig0
     es = np.abs(1 / seg["mu_s"] - truth["seg_sdepth"]) / truth["seg_sdepth"]
-    assert np.isfinite(es).all() and np.median(es) < 0.15      # both end points are searched from the segment centre (:404-407)
+    assert np.isfinite(es).all() and np.median(es) < 0.15      # both end points are searched from the segment centre (:411-414)
 
 
 def test_oracle_seed_edge_cases(P, ob, seqm):
@@ -59,7 +59,7 @@ def test_oracle_seed_edge_cases(P, ob, seqm):
     pt["mu"][1] = 1.0 / truth["pt_depth"][1]
     # NaN variance: the search interval is NaN
     pt["sigma2"][2] = np.nan
-    # a segment seed with NaN depth bounds is rejected by the end-point search (:433-437)
+    # a segment seed with NaN depth bounds is rejected by the end-point search (:436-440)
     seg["sigma2_s"][0] = np.nan
     res = ob.update_seeds(P.abi.SeedsJob(seq["cam"], seq["poses_true"], np.arange(3), pt, seg), frames)
     assert res["pt_status"][0] == P.abi.SEED_NOT_VISIBLE and res["pt_mu"][0] == np.float32(pt["mu"][0])
@@ -122,7 +122,7 @@ def test_hip_update_seeds_edge_cases(P, ob, gpu_ctx, seqm):
     pt["mu"][3] = 1e-3                      # 1 km away: a short epipolar segment (< 2 px), no search, direct alignment
     pt["sigma2"][3] = 1e-10
     seg["sigma2_s"][0] = np.nan
-    for steps in (1000, 5):                 # 5: every longer search is skipped (:355-360)
+    for steps in (1000, 5):                 # 5: every longer search is skipped (:350-355)
         job = P.abi.SeedsJob(seq["cam"], seq["poses_true"], np.arange(3), pt, seg, max_epi_search_steps=steps)
         _assert_close(gpu_ctx.update_seeds(job), ob.update_seeds(job, frames))
     e = gpu_ctx.update_seeds(P.abi.SeedsJob(seq["cam"], seq["poses_true"], np.arange(3), None, None))
@@ -163,7 +163,7 @@ def test_triangulation_and_tau_known_answers(P, ob):
     ang = 2.0 * np.arctan(1.0 / (2.0 * 416.0))
     t5, t10 = ob.compute_tau(T_ref_cur, f_ref, 5.0, ang), ob.compute_tau(T_ref_cur, f_ref, 10.0, ang)
     assert 0 < t5 < t10 and 3.0 < t10 / t5 < 5.0
-    # closed form of :604-620 in NumPy
+    # closed form of :568-584 in NumPy
     t = T_ref_cur[4:]; a = f_ref * 5.0 - t
     alpha = np.arccos(f_ref @ t / np.linalg.norm(t)); beta = np.arccos(a @ (-t) / (np.linalg.norm(t) * np.linalg.norm(a)))
     zp = np.linalg.norm(t) * np.sin(beta + ang) / np.sin(3.14159265 - alpha - beta - ang)
@@ -171,7 +171,7 @@ def test_triangulation_and_tau_known_answers(P, ob):
 
 
 def test_point_seed_posterior_matches_numpy(ob):
-    """updatePointSeed (:489-515) in float64 NumPy: the float32 oracle must agree to float accuracy, an inlier measurement
+    """updatePointSeed (:489-512) in float64 NumPy: the float32 oracle must agree to float accuracy, an inlier measurement
     must pull mu towards x, shrink sigma2 and raise a/(a+b); an outlier far outside must do the opposite to the inlier ratio"""
     def ref(x, tau2, a, b, mu, zr, s2):
         ns = np.sqrt(s2 + tau2)

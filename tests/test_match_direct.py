@@ -1,6 +1,6 @@
 """Direct feature matching (hot-path contract row (f) "next" #2): plsvo::Matcher::findMatchDirect for points and line
-segments (src/matcher.cpp:157-280) with warp::* (:40-128) and feature_alignment::align1D/align2D
-(src/feature_alignment.cpp:41-283).
+segments (src/matcher.cpp:159-275) with warp::* (:40-128) and feature_alignment::align1D/align2D
+(src/feature_alignment.cpp:41-290).
 CPU: the C oracle against an independent NumPy (np.float32 / np.float64 scalar) restatement and known answers.
 GPU: the HIP kernel is compiled without fma contraction and must reproduce the oracle BIT FOR BIT."""
 import math
@@ -272,7 +272,7 @@ def test_known_answer_pure_image_shift(P, ob):
 def test_edge_cases(P, ob):
     st, d = P.synth.make_match_batch(5, 320, 240, n_pts=8, n_seg=2)
     frames = _frames(P, ob, st)
-    # reference observation too close to the border for its level: rejected, px_cur untouched (matcher.cpp:166-168)
+    # reference observation too close to the border for its level: rejected, px_cur untouched (matcher.cpp:168-170)
     d["ref_px"][0] = [5.0, 100.0]
     d["ref_level"][1] = 3
     d["ref_px"][1] = [40.0, 100.0]          # 40/8 = 5 < 6

@@ -1,5 +1,5 @@
 """Structure optimisation (hot-path contract row (f) "next" #3): plsvo::Point::optimize / LineSeg::optimize,
-src/feature3D_impl.cpp:36-175.  CPU: the C oracle against a NumPy restatement and known answers.
+src/feature3D_impl.cpp:36-174.  CPU: the C oracle against a NumPy restatement and known answers.
 GPU: the HIP kernel is compiled without fma contraction and must reproduce the oracle BIT FOR BIT."""
 import numpy as np
 import pytest
