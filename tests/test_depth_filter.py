@@ -193,3 +193,104 @@ def test_point_seed_posterior_matches_numpy(ob):
     a2, b2, mu2, _, s22 = ob.update_point_seed(0.45, 1e-4, *st)          # 2.4 sigma away: mostly explained as an outlier
     assert a2 / (a2 + b2) < a / (a + b) and abs(mu2 - 0.25) < abs(0.45 - 0.25)
     assert ob.update_point_seed(0.27, float("nan"), *st) == tuple(np.float32(v).item() for v in st)   # NaN norm_scale: untouched (:492-493)
+
+
+# ---- an independent NumPy restatement of the point-seed update, written from the reference source -------------------
+
+def _np_update_point_seed_once(P, seq, frames, i, pt, cur_k, n_pyr_levels=3, max_steps=1000):
+    """DepthFilter::updatePointSeeds for one seed (src/depth_filter.cpp:295-360) with Matcher::findEpipolarMatchDirect
+    (src/matcher.cpp:277-420) -> (status, depth z).  Reuses the NumPy warp / align2D of tests/test_match_direct.py."""
+    import math
+    import np_restatement as npr
+    import test_match_direct as tm
+    cam = seq["cam"]
+    fx, fy, cx, cy, W, H = cam
+    T_ref, T_cur = seq["poses_true"][0], seq["poses_true"][cur_k]
+    inv = lambda T: np.concatenate([[-T[0], -T[1], -T[2], T[3]], npr.q_rot(np.array([-T[0], -T[1], -T[2], T[3]]), -T[4:])])
+    T_ref_cur = npr.se3_mul(T_ref, inv(T_cur))
+    T_cur_ref = inv(T_ref_cur)
+    mu, sigma2 = np.float32(pt["mu"][i]), np.float32(pt["sigma2"][i])
+    f = pt["f"][i]
+    xyz_f = npr.se3_act(T_cur_ref, (1.0 / float(mu)) * f)
+    if xyz_f[2] < 0.0:
+        return 0, 0.0
+    px = np.array([fx * xyz_f[0] / xyz_f[2] + cx, fy * xyz_f[1] / xyz_f[2] + cy])
+    if not (0 <= int(px[0]) < W and 0 <= int(px[1]) < H):
+        return 0, 0.0
+    z_inv_min = np.float32(mu + np.sqrt(sigma2))
+    z_inv_max = max(np.float32(mu - np.sqrt(sigma2)), np.float32(0.00000001))
+    d_est, d_min, d_max = 1.0 / float(mu), 1.0 / float(z_inv_min), 1.0 / float(z_inv_max)
+    proj = lambda p: p[:2] / p[2]
+    A = proj(npr.se3_act(T_cur_ref, f * d_min))
+    B = proj(npr.se3_act(T_cur_ref, f * d_max))
+    epi_dir = A - B
+    level = int(pt["level"][i])
+    Aw = tm._np_warp_matrix(cam, pt["px"][i], f, d_est, T_cur_ref, level)
+    if pt["type"][i] == 1:
+        g = Aw @ pt["grad"][i]
+        g = g / np.linalg.norm(g)
+        if abs(g @ (epi_dir / np.linalg.norm(epi_dir))) < 0.7:
+            return 1, 0.0
+    D = Aw[0, 0] * Aw[1, 1] - Aw[1, 0] * Aw[0, 1]
+    sl = 0
+    while D > 3.0 and sl < n_pyr_levels - 1:
+        sl += 1
+        D *= 0.25
+    px_A = np.array([fx * A[0] + cx, fy * A[1] + cy]); px_B = np.array([fx * B[0] + cx, fy * B[1] + cy])
+    epi_length = np.linalg.norm(px_A - px_B) / (1 << sl)
+    pb = tm._np_warp_affine(Aw, frames[0][level], pt["px"][i], level, sl)
+    cur = frames[cur_k][sl]
+    rows, cols = cur.shape
+
+    def finish(px_cur):
+        ok, it, e = tm._np_align2d(cur, pb, 10, (px_cur[0] / (1 << sl), px_cur[1] / (1 << sl)))
+        if not ok:
+            return 1, 0.0
+        pc = np.array([e[0] * (1 << sl), e[1] * (1 << sl)])
+        r = np.array([(pc[0] - cx) / fx, (pc[1] - cy) / fy, 1.0]); f_cur = r / np.linalg.norm(r)
+        x, y, z, w = T_cur_ref[:4]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        Am = np.stack([R @ f, f_cur], axis=1)
+        AtA = Am.T @ Am
+        if np.linalg.det(AtA) < 0.000001:
+            return 1, 0.0
+        return 2, abs((-np.linalg.inv(AtA) @ Am.T @ T_cur_ref[4:])[0])
+    if epi_length < 2.0:
+        return finish((px_A + px_B) / 2.0)
+    n_steps = int(epi_length / 0.7)
+    step = epi_dir / n_steps
+    if n_steps > max_steps:
+        return 1, 0.0
+    ref = pb[1:9, 1:9].astype(np.int64).ravel()
+    sA, sAA = ref.sum(), (ref * ref).sum()
+    best, uv_best, last = 2000 * 64, None, (0, 0)
+    uv = B - step
+    for _ in range(n_steps + 1):
+        p = np.array([fx * uv[0] + cx, fy * uv[1] + cy])
+        pxi = (int(p[0] / (1 << sl) + 0.5), int(p[1] / (1 << sl) + 0.5))
+        if pxi != last:
+            last = pxi
+            if 8 <= pxi[0] < W // (1 << sl) - 8 and 8 <= pxi[1] < H // (1 << sl) - 8:
+                Bp = cur[pxi[1] - 4:pxi[1] + 4, pxi[0] - 4:pxi[0] + 4].astype(np.int64).ravel()
+                sc = sAA - 2 * (ref * Bp).sum() + (Bp * Bp).sum() - (sA * sA - 2 * sA * Bp.sum() + Bp.sum() ** 2) // 64
+                if sc < best:
+                    best, uv_best = sc, uv.copy()
+        uv = uv + step
+    if best < 2000 * 64:
+        return finish(np.array([fx * uv_best[0] + cx, fy * uv_best[1] + cy]))
+    return 1, 0.0
+
+
+def test_oracle_point_seed_search_matches_numpy_restatement(P, ob, seqm):
+    seq, frames, pt, seg, truth = _setup(P, ob, seqm, 9, n_frames=3, n_pts=40, n_seg=0)
+    res = ob.update_seeds(P.abi.SeedsJob(seq["cam"], seq["poses_true"], np.arange(3), pt, None), frames)
+    n_same_depth = 0
+    for i in range(len(pt["px"])):
+        st_np, z_np = _np_update_point_seed_once(P, seq, frames, i, pt, 1)
+        st_o = int(res["pt_status"][i])
+        assert (st_o >= 2) == (st_np == 2) and (st_o == 0) == (st_np == 0), (i, st_o, st_np)
+        if st_np == 2:
+            assert abs(z_np - res["pt_depth"][i]) <= 2e-3 * z_np, (i, z_np, res["pt_depth"][i])
+            n_same_depth += int(abs(z_np - res["pt_depth"][i]) <= 1e-9 * z_np)
+    assert n_same_depth >= 20          # same integer argmin, same alignment -> same triangulated depth to rounding
