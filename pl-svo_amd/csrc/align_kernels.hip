@@ -177,7 +177,7 @@ struct P1Fetch2 {
 // LDS was measured three ways on MI355X: all of them (one workgroup per CU fewer: -8 %), as many as fit beside the tables
 // at four workgroups per CU (no difference), none (this code).
 template <int T>
-__global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBatchDev b, int cap, int level_hi, int level_lo) {
+__global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBatchDev b, int cap, int fcap, int level_hi, int level_lo) {
   // longest-processing-time-first: the hardware hands out workgroups in blockIdx order, so the jobs with the most patches
   // start first and the launch tail is made of the cheapest frames
   const int job_id = b.order ? b.order[blockIdx.x] : (int)blockIdx.x;
@@ -198,8 +198,8 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   float2* s_uv = reinterpret_cast<float2*>(s_ctl + 32);                  // cap
   int2* s_meta = reinterpret_cast<int2*>(s_uv + cap);                    // cap
   float* s_abs = reinterpret_cast<float*>(s_meta + cap);                 // cap
-  int* s_dead = reinterpret_cast<int*>(s_abs + cap);                     // cap
-  int* s_cnt = s_dead + cap;                                             // cap + 4: per-feature patch count / offset (nfeat <= cap)
+  int* s_dead = reinterpret_cast<int*>(s_abs + cap);                     // fcap: per segment, "culled at this level"
+  int* s_cnt = s_dead + fcap;                                            // fcap + 4: per-feature patch count / offset
 
 #ifdef PLSVO_TIMING
   __shared__ unsigned long long s_time[8];
@@ -262,7 +262,6 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       if (f < job.n_pts) {
         const int i = job.pt_off + f;
         s_meta[p0] = make_int2(f, p0 | (1 << 20));                 // x >= 0: point index; y: first | N<<20
-        s_dead[p0] = 0;
         b.patch_uvref[2 * (pbase + p0)] = (float)(b.pt_px[2 * i] * scale);
         b.patch_uvref[2 * (pbase + p0) + 1] = (float)(b.pt_px[2 * i + 1] * scale);
         pxyz[3 * p0] = b.pt_xyz[3 * i];
@@ -282,10 +281,10 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           inc3[c] = (b.seg_q[3 * s + c] - pr) / (double)(N - 1);
           xr[c] = pr;
         }
+        s_dead[sl] = 0;
         for (int n = 0; n < N; ++n) {
           const int p = p0 + n;
           s_meta[p] = make_int2(-1 - sl, p0 | (N << 20));           // x < 0: segment index = -1 - x
-          s_dead[p] = 0;
           b.patch_uvref[2 * (pbase + p)] = (float)px;
           b.patch_uvref[2 * (pbase + p) + 1] = (float)py;
           pxyz[3 * p] = xr[0];
@@ -348,7 +347,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           const int2 meta = s_meta[p];
           const int first = meta.y & 0xfffff;
           float2 uv;
-          if (meta.x < 0 && s_dead[first]) {
+          if (meta.x < 0 && s_dead[-1 - meta.x]) {
             uv = make_float2(-2.0f, -2.0f);  // line already culled
           } else {
             const double x = pxyz[3 * p], y = pxyz[3 * p + 1], z = pxyz[3 * p + 2];
@@ -500,7 +499,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
             wj = (double)w;                                                    // :682  Jres += Jres_ * w
             if (p == first) { acc[27] += (double)__fmul_rn(__fmul_rn(res_, res_), w); n_meas += 1; }  // :683-684
           } else if (p == first) {
-            s_dead[first] = 1;                                                 // :687-688 it->feat3D = NULL
+            s_dead[-1 - meta.x] = 1;                                           // :687-688 it->feat3D = NULL
             b.seg_alive[job.seg_off + (-1 - meta.x)] = 0;
           }
         }
@@ -640,28 +639,28 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   }
 }
 
-// LDS bytes the kernel needs for a given patch capacity `cap` (host side helper)
-size_t align_level_lds_bytes(int threads, int cap) {
+// LDS bytes the kernel needs for patch capacity `cap` and feature capacity `fcap` (host side helper)
+size_t align_level_lds_bytes(int threads, int cap, int fcap) {
   size_t o = sizeof(double) * RED_N * (threads / 64) + sizeof(double) * 64 + sizeof(int) * 32;
-  o += (size_t)cap * (sizeof(float2) + sizeof(int2) + sizeof(float) + sizeof(int) + sizeof(int)) + 16;
+  o += (size_t)cap * (sizeof(float2) + sizeof(int2) + sizeof(float)) + (size_t)(2 * fcap + 4) * sizeof(int) + 16;
   return o;
 }
 
 template <int T>
-static hipError_t launch_fused_T(const AlignBatchDev& b, int cap, int level_hi, int level_lo, size_t lds, hipStream_t stream) {
+static hipError_t launch_fused_T(const AlignBatchDev& b, int cap, int fcap, int level_hi, int level_lo, size_t lds, hipStream_t stream) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_fused_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((align_fused_kernel<T>), dim3(b.n_jobs), dim3(T), lds, stream, b, cap, level_hi, level_lo);
+  hipLaunchKernelGGL((align_fused_kernel<T>), dim3(b.n_jobs), dim3(T), lds, stream, b, cap, fcap, level_hi, level_lo);
   return hipGetLastError();
 }
 
-hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream) {
+hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int fcap, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream) {
   switch (threads) {
-    case 64: return launch_fused_T<64>(b, cap, level_hi, level_lo, lds, stream);
-    case 128: return launch_fused_T<128>(b, cap, level_hi, level_lo, lds, stream);
-    case 256: return launch_fused_T<256>(b, cap, level_hi, level_lo, lds, stream);
-    case 512: return launch_fused_T<512>(b, cap, level_hi, level_lo, lds, stream);
-    case 1024: return launch_fused_T<1024>(b, cap, level_hi, level_lo, lds, stream);
+    case 64: return launch_fused_T<64>(b, cap, fcap, level_hi, level_lo, lds, stream);
+    case 128: return launch_fused_T<128>(b, cap, fcap, level_hi, level_lo, lds, stream);
+    case 256: return launch_fused_T<256>(b, cap, fcap, level_hi, level_lo, lds, stream);
+    case 512: return launch_fused_T<512>(b, cap, fcap, level_hi, level_lo, lds, stream);
+    case 1024: return launch_fused_T<1024>(b, cap, fcap, level_hi, level_lo, lds, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -19,8 +19,8 @@
 
 namespace plsvo_hip {
 // kernels (align_kernels.hip, poseopt_kernels.hip, pyramid_kernels.hip)
-size_t align_level_lds_bytes(int threads, int cap);
-hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream);
+size_t align_level_lds_bytes(int threads, int cap, int fcap);
+hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int fcap, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream);
 hipError_t launch_align_init(const AlignBatchDev& b, hipStream_t stream);
 hipError_t launch_align_finish(const AlignBatchDev& b, double* d_poses, hipStream_t stream);
 hipError_t launch_pose_opt(const PoseBatchDev& b, hipStream_t stream);
@@ -81,6 +81,7 @@ struct plsvo_ctx {
   int a_total_seg = 0;
   int a_gmax = -1, a_gmin = 99;
   int a_cap[PLSVO_MAX_LEVELS]{};
+  int a_fcap = 4;   // max features (points + segments) of one job
   int a_trace_cap = 0;
   DevBuf a_d_jobs, a_d_state, a_d_T0, a_d_ptpx, a_d_ptxyz, a_d_spx, a_d_epx, a_d_len, a_d_p, a_d_q, a_d_alive_in, a_d_alive;
   DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_cdx, a_d_cdy, a_d_partial, a_d_log, a_d_poses, a_d_order;
@@ -417,6 +418,8 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   c->a_jobs.swap(jobs);
   c->a_n = n; c->a_total_seg = (int)alive.size(); c->a_gmax = gmax; c->a_gmin = gmin;
   for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) c->a_cap[l] = caps[l];
+  c->a_fcap = 4;
+  for (int j = 0; j < n; ++j) c->a_fcap = std::max(c->a_fcap, in[j].n_pts + in[j].n_seg);
   c->a_staged = true;
   return PLSVO_OK;
 }
@@ -424,10 +427,10 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
 // Launch configuration of the fused alignment kernel (measured on MI355X): 128 threads per workgroup (two
 // waves per frame pair; four workgroups share a CU at ~225 VGPRs), LDS holds only the per-patch tables.
 // Environment overrides (experiments only): PLSVO_ALIGN_THREADS, PLSVO_ALIGN_PER_LEVEL, PLSVO_ALIGN_LDS_PAD.
-static void pick_align_config(int cap, int* threads, size_t* lds) {
+static void pick_align_config(int cap, int fcap, int* threads, size_t* lds) {
   int t = 128;
   if (const char* s = getenv("PLSVO_ALIGN_THREADS")) { const int v = atoi(s); if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) t = v; }
-  *threads = t; *lds = align_level_lds_bytes(t, cap);
+  *threads = t; *lds = align_level_lds_bytes(t, cap, fcap);
   if (const char* s = getenv("PLSVO_ALIGN_LDS_PAD")) *lds += (size_t)std::max(0, atoi(s));   // occupancy experiments: unused LDS bytes per workgroup
 }
 
@@ -444,18 +447,19 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
     int cap = 4;
     for (int l = c->a_gmin; l <= c->a_gmax; ++l) cap = std::max(cap, c->a_cap[l]);
     int threads; size_t lds;
-    pick_align_config(cap, &threads, &lds);
+    const int fcap = (c->a_fcap + 3) & ~3;
+    pick_align_config(cap, fcap, &threads, &lds);
     if (lds > c->lds_per_block) return fail(c, PLSVO_E_CAPACITY, "align_run: patch tables do not fit in LDS (too many features in one job)");
     bool per_level = false;
     if (const char* s = getenv("PLSVO_ALIGN_PER_LEVEL")) per_level = atoi(s) != 0;
     if (!per_level) {
       EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
-      HIP_TRY(c, launch_align_levels(c->a_b, cap, c->a_gmax, c->a_gmin, threads, lds, c->stream));
+      HIP_TRY(c, launch_align_levels(c->a_b, cap, fcap, c->a_gmax, c->a_gmin, threads, lds, c->stream));
       prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
     } else {
       for (int level = c->a_gmax; level >= c->a_gmin; --level) {
         EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
-        HIP_TRY(c, launch_align_levels(c->a_b, cap, level, level, threads, lds, c->stream));
+        HIP_TRY(c, launch_align_levels(c->a_b, cap, fcap, level, level, threads, lds, c->stream));
         prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
       }
     }
