@@ -24,7 +24,6 @@ into landmarks when they converge.
 pose_optimize(job), and for mapping structure_optimize(job), update_seeds(job).  The product backend is HipBackend (C ABI on the GPU, no fallback); tests pass an oracle-backed one
 to check the whole chain end to end."""
 import copy
-import math
 
 import numpy as np
 

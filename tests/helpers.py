@@ -1,6 +1,5 @@
 """Shared helpers for the parity tests (test infrastructure)."""
 import importlib
-import math
 
 import numpy as np
 

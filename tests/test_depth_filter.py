@@ -200,7 +200,6 @@ def test_point_seed_posterior_matches_numpy(ob):
 def _np_update_point_seed_once(P, seq, frames, i, pt, cur_k, n_pyr_levels=3, max_steps=1000):
     """DepthFilter::updatePointSeeds for one seed (src/depth_filter.cpp:295-360) with Matcher::findEpipolarMatchDirect
     (src/matcher.cpp:277-420) -> (status, depth z).  Reuses the NumPy warp / align2D of tests/test_match_direct.py."""
-    import math
     import np_restatement as npr
     import test_match_direct as tm
     cam = seq["cam"]

@@ -5,7 +5,6 @@ import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-import torch
 P = importlib.import_module("pl-svo_amd")
 from oracle import binding as ob
 

@@ -1,10 +1,10 @@
 """Per-phase cycle breakdown of align_fused_kernel (needs the instrumented build: make -C pl-svo_amd/csrc timing).
 Runs BASELINE config 2 streams one pyramid level at a time and prints s_memtime ticks per phase, per iteration."""
-import ctypes as C, importlib, os, sys, time
+import ctypes as C, importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("PLSVO_HIP_LIB", os.path.join(ROOT, "pl-svo_amd", "libplsvo_hip_timing.so"))
 sys.path.insert(0, ROOT)
-import numpy as np, torch
+import numpy as np
 P = importlib.import_module("pl-svo_amd")
 B = int(os.environ.get("TIMING_BATCH", "256"))
 ctx = P.capi.Context(0)
