@@ -185,7 +185,7 @@ def main():
         value = frames / elapsed
         errs = np.array([synth.se3_log_angle_dist(r.T, s.T_true) for r, s in zip(res[:64], streams[:64])])
         result = {
-            "metric": "sparse-align+pose-opt frames/sec, 640x480, ~200 pts+80 lines",
+            "metric": "sparse-align+pose-opt frames/sec, 640\u00d7480, ~200 pts+80 lines; 1/2/4/8 GPU",   # BASELINE.json's metric, verbatim
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
