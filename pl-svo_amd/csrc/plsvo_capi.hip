@@ -19,12 +19,10 @@
 
 namespace plsvo_hip {
 // kernels (align_kernels.hip, poseopt_kernels.hip, pyramid_kernels.hip)
-size_t align_level_lds_bytes(int threads, int cap, int fcap);
-hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int fcap, int level_hi, int level_lo, int threads, size_t lds, hipStream_t stream);
-hipError_t launch_align_init(const AlignBatchDev& b, hipStream_t stream);
-hipError_t launch_align_finish(const AlignBatchDev& b, double* d_poses, hipStream_t stream);
-hipError_t launch_pose_opt(const PoseBatchDev& b, hipStream_t stream);
-hipError_t launch_pose_finish(const PoseBatchDev& b, double* d_poses, hipStream_t stream);
+size_t align_level_lds_bytes(int threads, int cap, int scap);
+hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int scap, int level_hi, int level_lo, int do_init, int threads, size_t lds,
+                               hipStream_t stream);
+hipError_t launch_pose_opt(const PoseBatchDev& b, double* d_poses, int threads, hipStream_t stream);
 hipError_t launch_structopt(const StructBatchDev& s, hipStream_t stream);
 hipError_t launch_match_direct(const MatchBatchDev& b, hipStream_t stream);
 hipError_t launch_reproject(const ReprojBatchDev& b, hipStream_t stream);
@@ -81,10 +79,10 @@ struct plsvo_ctx {
   int a_total_seg = 0;
   int a_gmax = -1, a_gmin = 99;
   int a_cap[PLSVO_MAX_LEVELS]{};
-  int a_fcap = 4;   // max features (points + segments) of one job
+  int a_scap = 4;   // max segments of one job
   int a_trace_cap = 0;
   DevBuf a_d_jobs, a_d_state, a_d_T0, a_d_ptpx, a_d_ptxyz, a_d_spx, a_d_epx, a_d_len, a_d_p, a_d_q, a_d_alive_in, a_d_alive;
-  DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_cdx, a_d_cdy, a_d_partial, a_d_log, a_d_poses, a_d_order;
+  DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_cdx, a_d_cdy, a_d_segslot, a_d_log, a_d_poses, a_d_order;
   AlignBatchDev a_b{};
 
   // pose-opt batch
@@ -190,7 +188,7 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
   for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_upload, &c->a_d_jobs, &c->a_d_state, &c->a_d_T0, &c->a_d_ptpx, &c->a_d_ptxyz, &c->a_d_spx,
                      &c->a_d_epx, &c->a_d_len, &c->a_d_p, &c->a_d_q, &c->a_d_alive_in, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv,
-                     &c->a_d_cref, &c->a_d_cdx, &c->a_d_cdy, &c->a_d_partial, &c->a_d_log, &c->a_d_poses, &c->a_d_order, &c->p_d_jobs, &c->p_d_state,
+                     &c->a_d_cref, &c->a_d_cdx, &c->a_d_cdy, &c->a_d_segslot, &c->a_d_log, &c->a_d_poses, &c->a_d_order, &c->p_d_jobs, &c->p_d_state,
                      &c->p_d_f, &c->p_d_pos, &c->p_d_plevel, &c->p_d_line, &c->p_d_spos, &c->p_d_epos, &c->p_d_slevel,
                      &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64, &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out };
   for (DevBuf* b : bufs) b->release();
@@ -326,6 +324,7 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   int gmax = -1, gmin = 99;
   int caps[PLSVO_MAX_LEVELS] = { 0 };
   std::vector<long long> work((size_t)n, 0);   // patches summed over the levels, per job: the launch-order key
+  std::vector<int> seg_slot[PLSVO_MAX_LEVELS];   // per level, one entry per segment of the batch
   size_t patch_total = 0;
   for (int j = 0; j < n; ++j) {
     const plsvo_align_in& a = in[j];
@@ -352,31 +351,62 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
     sp.insert(sp.end(), a.seg_p_ref, a.seg_p_ref + 3 * (size_t)a.n_seg);
     sq.insert(sq.end(), a.seg_q_ref, a.seg_q_ref + 3 * (size_t)a.n_seg);
     for (int s = 0; s < a.n_seg; ++s) alive.push_back(a.seg_alive_in ? (a.seg_alive_in[s] ? 1 : 0) : 1);
-    // patch capacity per level: every point + every sample of every segment (upper bound; the kernel
-    // recomputes the same count on the device and checks it against this bound)
-    int ub_min = 0;
+    // static patch-slot layout, per level (align_kernels.hip header): points own slots [0, n_pts); segments follow from the
+    // next multiple of 32 in feature order, and a segment with N <= 32 samples never straddles a multiple of 32, so that all
+    // its samples sit in one wave-round of the kernel.  Segments without a landmark on entry, or whose end points fail the
+    // 3-pixel border test of the level (src/sparse_img_align.cpp:299-301), get no slots.
+    int ub_max = 0;
     long long ub_sum = 0;
+    J.long_mask = 0; J.reserved0 = 0;
+    for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) J.n_slots[l] = 0;
     for (int l = a.max_level; l >= a.min_level; --l) {
-      long long ub = a.n_pts;
-      for (int s = 0; s < a.n_seg; ++s)
-        ub += seg_num_samples(a.seg_spx[2 * s], a.seg_spx[2 * s + 1], a.seg_epx[2 * s], a.seg_epx[2 * s + 1], a.seg_len[s], l);
-      if (ub > (1 << 20) - 8) return fail(c, PLSVO_E_CAPACITY, "align_stage: more than 2^20 patches in one job");
-      const int ub4 = (int)((ub + 3) & ~3LL);
-      ub_sum += ub;
-      if (!J.skip) caps[l] = std::max(caps[l], ub4);
-      ub_min = std::max(ub_min, ub4);
+      long long cur = a.n_seg > 0 ? (((long long)a.n_pts + 31) & ~31LL) : (long long)a.n_pts;
+      long long used = a.n_pts, n_real = a.n_pts;
+      const double scale = 1.0 / (double)(1 << l);
+      const int cw = a.cam.width / (1 << l), ch = a.cam.height / (1 << l);
+      for (int s = 0; s < a.n_seg; ++s) {
+        int code = -1;
+        const bool alive_on_entry = a.seg_alive_in ? (a.seg_alive_in[s] != 0) : true;
+        const double sx = a.seg_spx[2 * s], sy = a.seg_spx[2 * s + 1], ex = a.seg_epx[2 * s], ey = a.seg_epx[2 * s + 1];
+        const int isx = (int)(sx * scale), isy = (int)(sy * scale), iex = (int)(ex * scale), iey = (int)(ey * scale);
+        const bool vis = isx >= 3 && isx < cw - 3 && isy >= 3 && isy < ch - 3 && iex >= 3 && iex < cw - 3 && iey >= 3 && iey < ch - 3;
+        if (alive_on_entry && vis) {
+          const int N = seg_num_samples(sx, sy, ex, ey, a.seg_len[s], l);
+          if (N > 2047) return fail(c, PLSVO_E_CAPACITY, "align_stage: a segment with more than 2047 samples");
+          if (N <= 32) { if ((cur & 31) + N > 32) cur = (cur + 31) & ~31LL; }
+          else J.long_mask |= 1 << l;
+          if (cur + N > (1 << 20) - 8) return fail(c, PLSVO_E_CAPACITY, "align_stage: more than 2^20 patch slots in one job");
+          code = (int)cur | (N << 20);
+          cur += N; used = cur; n_real += N;
+        }
+        seg_slot[(size_t)l].push_back(code);
+      }
+      const int slots4 = (int)((used + 3) & ~3LL);
+      J.n_slots[l] = (int)used;
+      ub_sum += n_real;
+      if (!J.skip) caps[l] = std::max(caps[l], slots4);
+      ub_max = std::max(ub_max, slots4);
     }
-    J.patch_off = (int)patch_total; J.patch_cap = ub_min;
+    J.patch_off = (int)patch_total; J.patch_cap = ub_max;
     work[(size_t)j] = J.skip ? 0 : ub_sum;
-    patch_total += (size_t)ub_min;
+    patch_total += (size_t)ub_max;
     if (patch_total > (size_t)0x7fffffff / 16) return fail(c, PLSVO_E_CAPACITY, "align_stage: batch too large (patch index overflow)");
     if (!J.skip) { gmax = std::max(gmax, a.max_level); gmin = std::min(gmin, a.min_level); }
+    // levels this job does not run still need an entry per segment: the table is indexed [level][segment of the batch]
+    for (int l = 0; l < PLSVO_MAX_LEVELS; ++l)
+      if (l > a.max_level || l < a.min_level) seg_slot[(size_t)l].insert(seg_slot[(size_t)l].end(), (size_t)a.n_seg, -1);
   }
   // launch order: most patches (summed over the levels) first; stable, so equal jobs keep their batch order
   std::vector<int> order((size_t)n);
   for (int j = 0; j < n; ++j) order[(size_t)j] = j;
   if (!getenv("PLSVO_ALIGN_NO_LPT")) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return work[(size_t)x] > work[(size_t)y]; });
   int rc;
+  const int slot_level0 = (gmax >= gmin && gmax >= 0) ? gmin : 0;
+  const size_t total_seg = len.size();
+  std::vector<int> slot_table;
+  for (int l = slot_level0; l <= std::max(gmax, slot_level0); ++l) slot_table.insert(slot_table.end(), seg_slot[(size_t)l].begin(), seg_slot[(size_t)l].end());
+  if (slot_table.empty()) slot_table.push_back(-1);
+  if ((rc = upload(c, c->a_d_segslot, slot_table))) return rc;
   if ((rc = upload(c, c->a_d_order, order))) return rc;
   if ((rc = upload(c, c->a_d_jobs, jobs))) return rc;
   if ((rc = upload(c, c->a_d_T0, T0))) return rc;
@@ -397,7 +427,6 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   HIP_TRY(c, c->a_d_cref.ensure(pt * 16 * sizeof(float)));
   HIP_TRY(c, c->a_d_cdx.ensure(pt * 16 * sizeof(float)));
   HIP_TRY(c, c->a_d_cdy.ensure(pt * 16 * sizeof(float)));
-  HIP_TRY(c, c->a_d_partial.ensure(pt * 6 * sizeof(double)));
   if (c->a_trace_cap > 0) HIP_TRY(c, c->a_d_log.ensure((size_t)n * c->a_trace_cap * sizeof(plsvo_align_iterlog)));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
 
@@ -409,7 +438,8 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   b.seg_alive_in = c->a_d_alive_in.as<uint8_t>(); b.seg_alive = c->a_d_alive.as<uint8_t>();
   b.patch_xyz = c->a_d_pxyz.as<double>(); b.patch_uvref = c->a_d_puv.as<float>();
   b.cache_ref = c->a_d_cref.as<float>(); b.cache_dx = c->a_d_cdx.as<float>(); b.cache_dy = c->a_d_cdy.as<float>();
-  b.partial = c->a_d_partial.as<double>();
+  b.seg_slot = c->a_d_segslot.as<int>(); b.slot_level0 = slot_level0; b.slot_stride = (int)total_seg;
+  b.poses = c->a_d_poses.as<double>();
   b.pyr = c->pyr;
   b.log = c->a_trace_cap > 0 ? c->a_d_log.as<plsvo_align_iterlog>() : nullptr;
   b.log_cap = c->a_trace_cap;
@@ -418,19 +448,24 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   c->a_jobs.swap(jobs);
   c->a_n = n; c->a_total_seg = (int)alive.size(); c->a_gmax = gmax; c->a_gmin = gmin;
   for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) c->a_cap[l] = caps[l];
-  c->a_fcap = 4;
-  for (int j = 0; j < n; ++j) c->a_fcap = std::max(c->a_fcap, in[j].n_pts + in[j].n_seg);
+  c->a_scap = 4;
+  for (int j = 0; j < n; ++j) c->a_scap = std::max(c->a_scap, in[j].n_seg);
   c->a_staged = true;
   return PLSVO_OK;
 }
 
-// Launch configuration of the fused alignment kernel (measured on MI355X): 128 threads per workgroup (two
-// waves per frame pair; four workgroups share a CU at ~225 VGPRs), LDS holds only the per-patch tables.
+// Launch configuration of the fused alignment kernel (measured on MI355X).  A frame pair is one workgroup;
+// how many threads it gets depends on how many frames there are to fill the chip with:
+//   large batches (throughput): 128 threads, several workgroups per CU hide each other's serial solve/update tails;
+//   small batches (latency):    512 threads, the whole CU works on one frame and a Gauss-Newton iteration is one or two rounds.
 // Environment overrides (experiments only): PLSVO_ALIGN_THREADS, PLSVO_ALIGN_PER_LEVEL, PLSVO_ALIGN_LDS_PAD.
-static void pick_align_config(int cap, int fcap, int* threads, size_t* lds) {
+static void pick_align_config(const plsvo_ctx* c, int n_jobs, int cap, int scap, int* threads, size_t* lds) {
+  const int cus = c->cu_count > 0 ? c->cu_count : 256;
   int t = 128;
-  if (const char* s = getenv("PLSVO_ALIGN_THREADS")) { const int v = atoi(s); if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) t = v; }
-  *threads = t; *lds = align_level_lds_bytes(t, cap, fcap);
+  if (n_jobs <= cus) t = 512;
+  else if (n_jobs <= 4 * cus) t = 256;
+  if (const char* s = getenv("PLSVO_ALIGN_THREADS")) { const int v = atoi(s); if (v == 64 || v == 128 || v == 256 || v == 512) t = v; }
+  *threads = t; *lds = align_level_lds_bytes(t, cap, scap);
   if (const char* s = getenv("PLSVO_ALIGN_LDS_PAD")) *lds += (size_t)std::max(0, atoi(s));   // occupancy experiments: unused LDS bytes per workgroup
 }
 
@@ -438,33 +473,28 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
   CTX_CHECK(c);
   if (!c->a_staged) return fail(c, PLSVO_E_STATE, "align_run: no staged batch");
   HIP_TRY(c, hipSetDevice(c->device));
-  {
-    EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_INIT, &ep);
-    HIP_TRY(c, launch_align_init(c->a_b, c->stream));
-    prof_end(c, PLSVO_K_ALIGN_INIT, &ep);
-  }
-  if (c->a_gmax >= c->a_gmin && c->a_gmax >= 0) {
-    int cap = 4;
-    for (int l = c->a_gmin; l <= c->a_gmax; ++l) cap = std::max(cap, c->a_cap[l]);
-    int threads; size_t lds;
-    const int fcap = (c->a_fcap + 3) & ~3;
-    pick_align_config(cap, fcap, &threads, &lds);
-    if (lds > c->lds_per_block) return fail(c, PLSVO_E_CAPACITY, "align_run: patch tables do not fit in LDS (too many features in one job)");
-    bool per_level = false;
-    if (const char* s = getenv("PLSVO_ALIGN_PER_LEVEL")) per_level = atoi(s) != 0;
-    if (!per_level) {
+  // one launch: the workgroup of a job resets its solver state, runs its levels and writes its pose
+  // (jobs without features, src/sparse_img_align.cpp:58-62, only do the first and the last)
+  int cap = 4;
+  const bool have_levels = c->a_gmax >= c->a_gmin && c->a_gmax >= 0;
+  if (have_levels) for (int l = c->a_gmin; l <= c->a_gmax; ++l) cap = std::max(cap, c->a_cap[l]);
+  int threads; size_t lds;
+  const int scap = (c->a_scap + 3) & ~3;
+  pick_align_config(c, c->a_n, cap, scap, &threads, &lds);
+  if (lds > c->lds_per_block) return fail(c, PLSVO_E_CAPACITY, "align_run: slot tables do not fit in LDS (too many features in one job)");
+  bool per_level = false;
+  if (const char* s = getenv("PLSVO_ALIGN_PER_LEVEL")) per_level = atoi(s) != 0;
+  if (!per_level || !have_levels) {
+    EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
+    HIP_TRY(c, launch_align_levels(c->a_b, cap, scap, have_levels ? c->a_gmax : 0, have_levels ? c->a_gmin : 0, 1, threads, lds, c->stream));
+    prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
+  } else {
+    for (int level = c->a_gmax; level >= c->a_gmin; --level) {   // debug: one launch per level, state carried in HBM
       EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
-      HIP_TRY(c, launch_align_levels(c->a_b, cap, fcap, c->a_gmax, c->a_gmin, threads, lds, c->stream));
+      HIP_TRY(c, launch_align_levels(c->a_b, cap, scap, level, level, level == c->a_gmax ? 1 : 0, threads, lds, c->stream));
       prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
-    } else {
-      for (int level = c->a_gmax; level >= c->a_gmin; --level) {
-        EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
-        HIP_TRY(c, launch_align_levels(c->a_b, cap, fcap, level, level, threads, lds, c->stream));
-        prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
-      }
     }
   }
-  HIP_TRY(c, launch_align_finish(c->a_b, c->a_d_poses.as<double>(), c->stream));
   return PLSVO_OK;
 }
 
@@ -635,10 +665,14 @@ extern "C" int plsvo_poseopt_run(plsvo_ctx* c) {
   CTX_CHECK(c);
   if (!c->p_staged) return fail(c, PLSVO_E_STATE, "poseopt_run: no staged batch");
   HIP_TRY(c, hipSetDevice(c->device));
+  // one wave per frame for large batches (8 frames per CU), four waves per frame when there are too few frames to fill the
+  // chip (the Gauss-Newton loop of one frame is then ~2x shorter); PLSVO_POSEOPT_THREADS overrides (experiments only)
+  const int cus = c->cu_count > 0 ? c->cu_count : 256;
+  int threads = c->p_n <= 2 * cus ? 256 : 64;
+  if (const char* s = getenv("PLSVO_POSEOPT_THREADS")) { const int v = atoi(s); if (v == 64 || v == 256) threads = v; }
   EventPair ep{}; prof_begin(c, PLSVO_K_POSEOPT, &ep);
-  HIP_TRY(c, launch_pose_opt(c->p_b, c->stream));
+  HIP_TRY(c, launch_pose_opt(c->p_b, c->p_d_poses.as<double>(), threads, c->stream));
   prof_end(c, PLSVO_K_POSEOPT, &ep);
-  HIP_TRY(c, launch_pose_finish(c->p_b, c->p_d_poses.as<double>(), c->stream));
   return PLSVO_OK;
 }
 

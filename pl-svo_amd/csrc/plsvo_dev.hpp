@@ -42,7 +42,10 @@ struct AlignJobDev {
   int max_level, min_level, n_iter, skip;   // skip: no features at all (src/sparse_img_align.cpp:58-62)
   double eps;
   int pt_off, n_pts, seg_off, n_seg;        // into the batch feature arrays
-  int patch_off, patch_cap;                 // into the batch patch-cache arrays
+  int patch_off, patch_cap;                 // into the batch patch-cache arrays (slots)
+  int n_slots[PLSVO_MAX_LEVELS];            // patch slots of the static layout, per level (host: align_slot_layout)
+  int long_mask;                            // bit l: some segment has more than 32 samples at level l (two-pass level)
+  int reserved0;
 };
 
 struct AlignStateDev {
@@ -72,13 +75,16 @@ struct AlignBatchDev {
   const double* seg_q;         // 3
   const uint8_t* seg_alive_in; // 1 (may be null)
   uint8_t* seg_alive;          // 1, working copy / result
-  // per-level patch cache (capacity = sum over jobs of patch_cap)
-  double* patch_xyz;           // 3 per patch: 3-D point in the ref frame
-  float* patch_uvref;          // 2 per patch: ref pixel position at the level (float, as Patch::setPosition)
-  float* cache_ref;            // 16 per patch: interpolated reference intensity
-  float* cache_dx;             // 16 per patch
-  float* cache_dy;             // 16 per patch
-  double* partial;             // 6 per patch: per-iteration patch sums A,B,C,D,E,chi2
+  // static slot layout of the segments: seg_slot[(level - slot_level0) * slot_stride + segment] = first slot | N << 20, or -1
+  const int* seg_slot;
+  int slot_level0, slot_stride;
+  // per-level patch cache (capacity = sum over jobs of patch_cap slots)
+  double* patch_xyz;           // 3 per slot: 3-D point in the ref frame
+  float* patch_uvref;          // 2 per slot: ref pixel position at the level (float, as Patch::setPosition)
+  float* cache_ref;            // 16 per slot: interpolated reference intensity
+  float* cache_dx;             // 16 per slot
+  float* cache_dy;             // 16 per slot
+  double* poses;               // 7 per job: final model, contiguous (what a device-side consumer / the RCCL gather reads)
   PyrDesc pyr;
   plsvo_align_iterlog* log;    // log_cap per job, or null
   int log_cap;

@@ -193,6 +193,43 @@ PLSVO_HD void inv6(const double* A, double* Ainv) {
   }
 }
 
+#if defined(__HIPCC__)
+// inv6 for a single device lane with the LU factors in LDS: the pivot rows are indexed dynamically, which in private
+// memory means scratch (same arithmetic and pivot order as inv6)
+__device__ __forceinline__ void inv6_lds(const double* A, double* Ainv, double* lu /*36, LDS*/, int* perm /*6, LDS*/) {
+  for (int i = 0; i < 6; ++i) { perm[i] = i; for (int j = 0; j < 6; ++j) lu[i * 6 + j] = A[i * 6 + j]; }
+  for (int k = 0; k < 6; ++k) {
+    int piv = k; double pv = fabs(lu[k * 6 + k]);
+    for (int i = k + 1; i < 6; ++i) { const double v = fabs(lu[i * 6 + k]); if (v > pv) { pv = v; piv = i; } }
+    if (piv != k) {
+      for (int j = 0; j < 6; ++j) { const double t = lu[k * 6 + j]; lu[k * 6 + j] = lu[piv * 6 + j]; lu[piv * 6 + j] = t; }
+      const int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    }
+    for (int i = k + 1; i < 6; ++i) {
+      lu[i * 6 + k] /= lu[k * 6 + k];
+      for (int j = k + 1; j < 6; ++j) lu[i * 6 + j] -= lu[i * 6 + k] * lu[k * 6 + j];
+    }
+  }
+  for (int c = 0; c < 6; ++c) {
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y[i] = (perm[i] == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < i; ++j) y[i] -= lu[i * 6 + j] * y[j];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+#pragma unroll
+      for (int j = i + 1; j < 6; ++j) y[i] -= lu[i * 6 + j] * y[j];
+      y[i] /= lu[i * 6 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Ainv[i * 6 + c] = y[i];
+  }
+}
+#endif
+
 PLSVO_HD double norm_max6(const double* v) {
   double m = 0; for (int i = 0; i < 6; ++i) { const double a = fabs(v[i]); if (a > m) m = a; } return m;
 }

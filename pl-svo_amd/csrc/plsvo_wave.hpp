@@ -73,6 +73,61 @@ __device__ __forceinline__ void wave_sum_array(double* v) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Reduce-scatter of 32 lane-private doubles over the 16 lanes of every DPP row (butterfly, fixed shape):
+// step s halves the number of values a lane carries and pairs it with the lane whose index differs in bit s,
+// so after four steps lane l holds the ROW totals of the two values k0, k0+1 with
+//   k0 = 16*bit0(l) + 8*bit1(l) + 4*bit2(l) + 2*bit3(l).
+// 30 exchanges + adds instead of the 4 x 32 of a plain all-lanes tree; the four rows of a wave (and the waves
+// of a workgroup) are then combined through LDS by reduce_rows_finish().  Deterministic: the pairing is fixed.
+// lane^4 / lane^8 have no single DPP pattern: two bank-masked row shifts fill the two halves of the pairing.
+// ------------------------------------------------------------------------------------------------
+#define DPP_ROW_SHL(n) (0x100 + (n))   // lane l reads lane l+n of its row
+#define DPP_ROW_SHR(n) (0x110 + (n))   // lane l reads lane l-n of its row
+template <int SHIFT, int BANKS_LO, int BANKS_HI>
+__device__ __forceinline__ double dpp_row_xor_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  int rlo = __builtin_amdgcn_update_dpp(0, lo, DPP_ROW_SHL(SHIFT), 0xf, BANKS_LO, false);
+  rlo = __builtin_amdgcn_update_dpp(rlo, lo, DPP_ROW_SHR(SHIFT), 0xf, BANKS_HI, false);
+  int rhi = __builtin_amdgcn_update_dpp(0, hi, DPP_ROW_SHL(SHIFT), 0xf, BANKS_LO, false);
+  rhi = __builtin_amdgcn_update_dpp(rhi, hi, DPP_ROW_SHR(SHIFT), 0xf, BANKS_HI, false);
+  return __hiloint2double(rhi, rlo);
+}
+__device__ __forceinline__ double dpp_xor4_f64(double v) { return dpp_row_xor_f64<4, 0x5, 0xA>(v); }   // banks = groups of 4 lanes
+__device__ __forceinline__ double dpp_xor8_f64(double v) { return dpp_row_xor_f64<8, 0x3, 0xC>(v); }
+
+__device__ __forceinline__ void row_reduce_scatter32(const double* v, double* out2) {
+  const int lane = threadIdx.x & 63;
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0, b3 = (lane & 8) != 0;
+  double w[16], u[8], t[4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { const double keep = b0 ? v[i + 16] : v[i], send = b0 ? v[i] : v[i + 16]; w[i] = keep + dpp_mov_f64<DPP_QUAD_XOR1>(send); }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const double keep = b1 ? w[i + 8] : w[i], send = b1 ? w[i] : w[i + 8]; u[i] = keep + dpp_mov_f64<DPP_QUAD_XOR2>(send); }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const double keep = b2 ? u[i + 4] : u[i], send = b2 ? u[i] : u[i + 4]; t[i] = keep + dpp_xor4_f64(send); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const double keep = b3 ? t[i + 2] : t[i], send = b3 ? t[i] : t[i + 2]; out2[i] = keep + dpp_xor8_f64(send); }
+}
+// index of the first of the two values lane `lane` holds after row_reduce_scatter32
+__device__ __forceinline__ int row_reduce_scatter32_index(int lane) {
+  return ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2);
+}
+// Combine `rows` row partials (32 doubles each, written to LDS as s_rows[row * 32 + k]) in a fixed order:
+// must be called by one full wave after the partials are visible; lane l (and l ^ 32) returns the total of value l & 31.
+template <int ROWS>
+__device__ __forceinline__ double reduce_rows_finish(const double* s_rows) {
+  const int lane = threadIdx.x & 63, k = lane & 31, h = lane >> 5;
+  const double* src = s_rows + (h * (ROWS / 2)) * 32 + k;
+  double v[ROWS / 2];
+#pragma unroll
+  for (int r = 0; r < ROWS / 2; ++r) v[r] = src[r * 32];     // independent LDS reads, issued back to back
+  double mine = v[0];
+#pragma unroll
+  for (int r = 1; r < ROWS / 2; ++r) mine += v[r];
+  return mine + __shfl_xor(mine, 32, 64);
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int src_lane /*wave-uniform*/) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
@@ -85,14 +140,44 @@ __device__ __forceinline__ int sym6_index(int r, int c) {
   return a * 6 - (a * (a - 1)) / 2 + (b - a);
 }
 
+// 1/b and a/b without the IEEE division's scaling and fix-up steps (v_rcp_f64 / v_rsq_f64 + two Newton steps): results
+// within 1 ulp for normal, finite operands.  Used only where the reference's own libraries leave the last bit open
+// (Eigen's LDLT column scaling, Sophus' quaternion normalisation) and the value is O(1): the serial part of a Gauss-Newton
+// iteration is latency-bound and an IEEE f64 division is a chain of ~14 dependent instructions.
+__device__ __forceinline__ double fast_rcp(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double fast_div(double a, double b) {
+  const double r = fast_rcp(b);
+  const double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ double fast_sqrt(double x) {   // x >= 0, finite; sqrt(0) = 0
+  if (!(x > 0.0)) return x == 0.0 ? 0.0 : sqrt(x);
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  return fma(fma(-g, g, x), h, g);
+}
+
 // Solve H x = rhs for a symmetric 6x6 H, cooperatively by ONE FULL WAVE (all 64 lanes must be active).
-//   tot[0..20]  upper triangle of H (row-major), tot[21..26] rhs  -- readable by every lane (LDS)
+//   tot[0..20]  upper triangle of H (row-major), tot[21..26] rhs
 //   x[0..5]     result, returned in registers of every lane (wave-uniform)
-// Method: Gauss-Jordan elimination of the augmented 6x7 system with the pivot order of Eigen's LDLT
-// (largest remaining |diagonal| of the Schur complement, src/sparse_img_align.cpp:699 and
-// src/pose_optimizer.cpp:170 call H.ldlt().solve()).  Lane 8*i+j holds entry (i,j); column 6 is the rhs.
-// The pivots are exactly LDLT's D entries; like Eigen's solve, a pivot that is zero (or below 1/DBL_MAX)
-// yields a zero component, so an all-zero system returns x = 0.  NaN/Inf propagate into x.
+// Method: Gauss-Jordan elimination of the augmented 6x7 system with the pivot order of Eigen's LDLT (largest remaining
+// |diagonal| of the Schur complement, lowest index on ties; src/sparse_img_align.cpp:699 and src/pose_optimizer.cpp:170
+// call H.ldlt().solve()).  Lane 8*i+j holds entry (i,j); column 6 is the rhs.
+// The serial part of a Gauss-Newton iteration is one wave issuing dependent instructions at ~4-5 cycles each, so a step
+// is written for instruction count: the pivot is a DPP max over the lanes' own |diagonal| keys + one ballot (no per-row
+// readlanes, no compare chain), its reciprocal comes from fast_rcp while the two ds_bpermute round trips (row p, column p)
+// are in flight, and the update is one multiply + one fma per lane.
+// The pivots are LDLT's D entries; like Eigen's solve, a pivot that is zero (or below 1/DBL_MAX) yields a zero component,
+// so an all-zero system returns x = 0.  NaN/Inf propagate into x.
 __device__ __forceinline__ void wave_solve6_core(double m, double* x);
 
 __device__ __forceinline__ void wave_solve6(const double* tot, double* x) {
@@ -114,34 +199,55 @@ __device__ __forceinline__ void wave_solve6_reg(double tot_lane, double* x) {
   wave_solve6_core(m, x);
 }
 
+__device__ __forceinline__ double bpermute_f64(int byte_addr, double v) {
+  const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+// max over the 64 lanes; the result is valid in lane 63 (v_max_f64: a NaN operand loses against a number)
+__device__ __forceinline__ double wave_max_to_lane63(double v) {
+  v = fmax(v, dpp_mov_f64<DPP_QUAD_XOR1>(v));
+  v = fmax(v, dpp_mov_f64<DPP_QUAD_XOR2>(v));
+  v = fmax(v, dpp_mov_f64<DPP_ROW_HALF_MIRROR>(v));
+  v = fmax(v, dpp_mov_f64<DPP_ROW_MIRROR>(v));
+  // lanes outside the row mask receive 0 from the broadcast: harmless, every key of interest is >= 0 and lane 63 is inside
+  v = fmax(v, dpp_bcast_f64<DPP_ROW_BCAST15, 0xA>(v));
+  v = fmax(v, dpp_bcast_f64<DPP_ROW_BCAST31, 0xC>(v));
+  return v;
+}
+
 __device__ __forceinline__ void wave_solve6_core(double m, double* x) {
   const int lane = threadIdx.x & 63;
   const int i = lane >> 3, j = lane & 7;
-  unsigned done = 0u, zero_piv = 0u;
-#pragma unroll 1
-  for (int step = 0; step < 6; ++step) {
-    int p = -1; double best = -1.0, piv = 0.0;
+  const int addr_row = 4 * j, addr_col = 4 * 8 * i;      // byte addresses of lanes (p,j) / (i,p) once 32p / 4p is added
+  bool diag_active = (i == j) && (i < 6);                // this lane holds a diagonal entry not yet used as pivot
+  const bool in_system = (i < 6) && (j <= 6);
+  unsigned zero_piv = 0u;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const double dg = readlane_f64(m, 9 * r);
-      const double a = fabs(dg);
-      if (!((done >> r) & 1u) && (p < 0 || a > best)) { best = a; p = r; piv = dg; }
-    }
-    done |= 1u << p;
+  for (int step = 0; step < 6; ++step) {
+    // pivot: largest |diagonal| among the rows not yet eliminated, lowest index on ties
+    const double key = diag_active ? fabs(m) : -1.0;
+    const double kmax = readlane_f64(wave_max_to_lane63(key), 63);
+    unsigned long long cand = __ballot(diag_active && key == kmax);
+    if (cand == 0ull) cand = __ballot(diag_active);      // every remaining diagonal is NaN: take the first (as a compare chain would)
+    const int plane = __builtin_ctzll(cand);             // lane 9p
+    const int p = (plane * 57) >> 9;                     // plane / 9 for plane in {0, 9, .., 45}
+    const double piv = readlane_f64(m, plane);
     if (fabs(piv) > 0.0) {
-      const double mp_j = __shfl(m, 8 * p + j, 64);  // M[p][j]
-      const double mi_p = __shfl(m, 8 * i + p, 64);  // M[i][p]
-      if (i != p && i < 6) m -= (mi_p / piv) * mp_j;
+      const double mp_j = bpermute_f64(addr_row + 32 * p, m);   // M[p][j]
+      const double mi_p = bpermute_f64(addr_col + 4 * p, m);    // M[i][p]
+      const double rinv = fast_rcp(piv);
+      if (in_system && i != p) m = fma(-(mi_p * mp_j), rinv, m);
     } else {
       zero_piv |= 1u << p;
     }
+    diag_active = diag_active && (i != p);
   }
-  const double rhs = __shfl(m, 8 * i + 6, 64);
-  const double dgi = __shfl(m, 9 * (i < 6 ? i : 0), 64);
+  const double dgi = bpermute_f64(addr_col + 4 * i, m);     // M[i][i]
   const double tolerance = 1.0 / 1.7976931348623157e308;
-  const double xi = (((zero_piv >> i) & 1u) || !(fabs(dgi) > tolerance)) ? ((dgi != dgi || rhs != rhs) ? (rhs + dgi) : 0.0) : rhs / dgi;
+  const double xi = (((zero_piv >> i) & 1u) || !(fabs(dgi) > tolerance)) ? ((dgi != dgi || m != m) ? (m + dgi) : 0.0) : m / dgi;   // lanes 8i+6: m = rhs
 #pragma unroll
-  for (int r = 0; r < 6; ++r) x[r] = readlane_f64(xi, 8 * r);
+  for (int r = 0; r < 6; ++r) x[r] = readlane_f64(xi, 8 * r + 6);
 }
 
 // sin and cos of a small angle (|x| <= pi/4: Taylor/Horner to x^17 / x^16, < 1 ulp); larger angles use ocml.
@@ -171,37 +277,77 @@ __device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
   }
 }
 
-// Sophus::SE3::exp with the small-angle sincos above (same formulas as plsvo_math.hpp::se3_exp)
+__device__ __forceinline__ Quat quat_normalized_fast(const Quat& a) {
+  const double inv = fast_rcp(fast_sqrt(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w));
+  Quat r = { a.x * inv, a.y * inv, a.z * inv, a.w * inv };
+  return r;
+}
+
+// Sophus::SE3::exp (same formulas as plsvo_math.hpp::se3_exp).  Gauss-Newton updates are tiny rotations: for
+// theta^2 <= 0.01 the four functions of theta the formulas need -- cos(theta/2), sin(theta/2)/theta, (1 - cos theta)/theta^2
+// and (theta - sin theta)/theta^3 -- are evaluated as series in z = theta^2 (truncation < 3e-19 relative), which costs 24 fma
+// and needs neither theta itself, nor a division, nor the cancellation of the closed forms.  Larger angles take the closed forms.
 __device__ __forceinline__ SE3d se3_exp_dev(const double* u) {
   SE3d r;
   const double ox = u[3], oy = u[4], oz = u[5];
-  const double theta = sqrt(ox * ox + oy * oy + oz * oz);
-  double sh, ch, st, ct;
-  sincos_small(0.5 * theta, &sh, &ch);
-  sincos_small(theta, &st, &ct);
-  double imag_factor;
-  if (theta < 1e-10) {
-    const double theta_sq = theta * theta;
-    imag_factor = 0.5 - 0.0208333 * theta_sq + 0.000260417 * (theta_sq * theta_sq);
+  const double z = ox * ox + oy * oy + oz * oz;
+  double real_factor, imag_factor, a, b;
+  if (z <= 0.01) {
+    // cos(t/2) = sum (-1)^k z^k / (4^k (2k)!)
+    real_factor = 1.0 / 3715891200.0;                           // 1/(4^5 10!)
+    real_factor = fma(real_factor, -z, 1.0 / 10321920.0);       // 1/(4^4 8!)
+    real_factor = fma(real_factor, -z, 1.0 / 46080.0);          // 1/(4^3 6!)
+    real_factor = fma(real_factor, -z, 1.0 / 384.0);            // 1/(4^2 4!)
+    real_factor = fma(real_factor, -z, 1.0 / 8.0);              // 1/(4 2!)
+    real_factor = fma(real_factor, -z, 1.0);
+    // sin(t/2)/t = sum (-1)^k z^k / (2 4^k (2k+1)!)
+    imag_factor = 1.0 / 81749606400.0;                          // 1/(2 4^5 11!)
+    imag_factor = fma(imag_factor, -z, 1.0 / 185794560.0);      // 1/(2 4^4 9!)
+    imag_factor = fma(imag_factor, -z, 1.0 / 645120.0);         // 1/(2 4^3 7!)
+    imag_factor = fma(imag_factor, -z, 1.0 / 3840.0);           // 1/(2 4^2 5!)
+    imag_factor = fma(imag_factor, -z, 1.0 / 48.0);             // 1/(2 4 3!)
+    imag_factor = fma(imag_factor, -z, 0.5);
+    // (1 - cos t)/t^2 = sum (-1)^k z^k / (2k+2)!
+    a = 1.0 / 479001600.0;                                      // 1/12!
+    a = fma(a, -z, 1.0 / 3628800.0);                            // 1/10!
+    a = fma(a, -z, 1.0 / 40320.0);                              // 1/8!
+    a = fma(a, -z, 1.0 / 720.0);                                // 1/6!
+    a = fma(a, -z, 1.0 / 24.0);                                 // 1/4!
+    a = fma(a, -z, 0.5);
+    // (t - sin t)/t^3 = sum (-1)^k z^k / (2k+3)!
+    b = 1.0 / 6227020800.0;                                     // 1/13!
+    b = fma(b, -z, 1.0 / 39916800.0);                           // 1/11!
+    b = fma(b, -z, 1.0 / 362880.0);                             // 1/9!
+    b = fma(b, -z, 1.0 / 5040.0);                               // 1/7!
+    b = fma(b, -z, 1.0 / 120.0);                                // 1/5!
+    b = fma(b, -z, 1.0 / 6.0);
   } else {
-    imag_factor = sh / theta;
+    const double theta = sqrt(z);
+    real_factor = cos(0.5 * theta);
+    imag_factor = sin(0.5 * theta) / theta;
+    a = (1 - cos(theta)) / z;
+    b = (theta - sin(theta)) / (z * theta);
   }
-  Quat q = { imag_factor * ox, imag_factor * oy, imag_factor * oz, ch };
-  r.q = quat_normalized(q);
+  Quat q = { imag_factor * ox, imag_factor * oy, imag_factor * oz, real_factor };
+  r.q = quat_normalized_fast(q);
+  // V = I + a hat(omega) + b hat(omega)^2   (theta < 1e-10 in the reference uses the rotation matrix itself: equal to rounding)
+  const double O2_00 = -(oy * oy + oz * oz), O2_11 = -(ox * ox + oz * oz), O2_22 = -(ox * ox + oy * oy);
+  const double O2_01 = ox * oy, O2_02 = ox * oz, O2_12 = oy * oz;
   double V[9];
-  if (theta < 1e-10) {
-    quat_to_matrix(r.q, V);
-  } else {
-    const double theta_sq = theta * theta;
-    const double a = (1 - ct) / theta_sq;
-    const double b = (theta - st) / (theta_sq * theta);
-    const double O2_00 = -(oy * oy + oz * oz), O2_11 = -(ox * ox + oz * oz), O2_22 = -(ox * ox + oy * oy);
-    const double O2_01 = ox * oy, O2_02 = ox * oz, O2_12 = oy * oz;
-    V[0] = 1.0 + b * O2_00;      V[1] = a * -oz + b * O2_01;  V[2] = a * oy + b * O2_02;
-    V[3] = a * oz + b * O2_01;   V[4] = 1.0 + b * O2_11;      V[5] = a * -ox + b * O2_12;
-    V[6] = a * -oy + b * O2_02;  V[7] = a * ox + b * O2_12;   V[8] = 1.0 + b * O2_22;
-  }
+  V[0] = 1.0 + b * O2_00;      V[1] = a * -oz + b * O2_01;  V[2] = a * oy + b * O2_02;
+  V[3] = a * oz + b * O2_01;   V[4] = 1.0 + b * O2_11;      V[5] = a * -ox + b * O2_12;
+  V[6] = a * -oy + b * O2_02;  V[7] = a * ox + b * O2_12;   V[8] = 1.0 + b * O2_22;
   for (int i = 0; i < 3; ++i) r.t[i] = V[i * 3 + 0] * u[0] + V[i * 3 + 1] * u[1] + V[i * 3 + 2] * u[2];
+  return r;
+}
+
+// Sophus::SE3::operator* on the device: the quaternion product is renormalised by multiplying with 1/|q| (fast_rcp of
+// fast_sqrt) instead of four IEEE divisions -- last-bit differences only
+__device__ __forceinline__ SE3d se3_mul_dev(const SE3d& A, const SE3d& B) {
+  SE3d r; double rt[3];
+  quat_rotate(A.q, B.t, rt);
+  r.t[0] = A.t[0] + rt[0]; r.t[1] = A.t[1] + rt[1]; r.t[2] = A.t[2] + rt[2];
+  r.q = quat_normalized_fast(quat_mul(A.q, B.q));
   return r;
 }
 

@@ -9,9 +9,12 @@
 // Work per call is tiny (hundreds of features x ~100 flops x <=10 iterations): this kernel is
 // latency-bound by construction; it exists so that a batch of frames is one launch and the pose never
 // leaves the device between the alignment and the optimisation.  One lane per feature, lane-private
-// 6x6 (upper) + 6x1 accumulators in double, fixed-shape DPP/LDS reduction, one lane solves.
+// 6x6 (upper) + 6x1 accumulators in double, fixed-shape reduction (butterfly reduce-scatter inside the DPP
+// rows, rows and waves through LDS), wave-cooperative 6x6 solve.  The workgroup is ONE wave per frame for
+// large batches (nothing to gain from cross-wave work on ~300 features: 8 frames per CU) and four waves for
+// small ones (the Gauss-Newton loop of a single frame is then ~2x shorter).
 // Medians (vk::getMedian = element floor(n/2) of the sorted vector) are exact: block-wide radix
-// select over the IEEE bit patterns (all values are non-negative), 11 bits per pass.
+// select over the IEEE bit patterns (all values are non-negative), 8 bits per pass.
 #include <hip/hip_runtime.h>
 
 #include "plsvo_dev.hpp"
@@ -20,9 +23,6 @@
 
 namespace plsvo_hip {
 
-#ifndef PO_T
-#define PO_T 64    // one wave per frame: measured 0.46 ms vs 0.83 ms (256 threads) per 4096-frame batch -- no cross-wave work, 8 frames per CU
-#endif
 #define PO_RED 32
 #ifndef PO_RADIX_BITS
 #define PO_RADIX_BITS 8    // bits per radix-select pass (measured on MI355X: 8 -> 0.72 ms, 11 -> 0.81 ms, 6 -> 0.74 ms per 8192 frames)
@@ -31,7 +31,7 @@ namespace plsvo_hip {
 
 // k-th smallest (0-based) of n non-negative IEEE values given as unsigned bit patterns of BITS bits.
 // get(i) returns the pattern of element i (invalid elements must return all-ones).
-template <int BITS, typename U, typename GET>
+template <int PO_T, int BITS, typename U, typename GET>
 __device__ U block_radix_select(GET get, int n, int k, int* s_hist, int* s_sel) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   U prefix = 0, mask = 0;
@@ -74,40 +74,20 @@ __device__ U block_radix_select(GET get, int n, int k, int* s_hist, int* s_sel) 
   return prefix;
 }
 
-// k-th smallest (0-based) of n <= PO_RANK_MAX values by rank counting: element i's rank is the number of elements
-// that sort before it (ties broken by index); exact, one barrier, O(n^2 / T) LDS broadcasts.  `vals` is an LDS
-// array of bit patterns (non-negative IEEE values order like unsigned integers).
-#define PO_RANK_MAX 0   // rank counting measured slower than the 11-bit radix select on MI355X (64-bit compares); kept for reference
-template <typename U>
-__device__ U block_rank_select(const U* vals, int n, int k, U* s_out) {
-  for (int i = threadIdx.x; i < n; i += PO_T) {
-    const U vi = vals[i];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) { const U vj = vals[j]; rank += (vj < vi || (vj == vi && j < i)) ? 1 : 0; }
-    if (rank == k) *s_out = vi;
-  }
-  __syncthreads();
-  const U r = *s_out;
-  __syncthreads();
-  return r;
-}
-
-// LDS roles: s_red PO_RED*(PO_T/64) doubles; s_pose 0..8 R, 9..11 t, 12..18 model, 19..25 T_old, 26 chi2;
+// LDS roles: s_red 32*(PO_T/16) doubles (row partials); s_pose 0..8 R, 9..11 t, 12..18 model, 19..25 T_old, 26 chi2;
 // s_ctl[0] break flag
 
 // one GN loop (src/pose_optimizer.cpp:103-195 and the identical text at :469-563)
+template <int PO_T>
 __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseStateDev* st, int job_id, double* s_red,
                              double* s_pose, int* s_ctl, int n_iter, int phase, double scale_pt, double scale_ls,
                              double* init_vec, double* s_tot) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int np = job.n_pts, ns = job.n_seg, nf = np + ns;
   for (int iter = 0; iter < n_iter; ++iter) {
-    double aH[21], aB[6], aChi = 0.0;
+    double acc[32];   // 0..20 A (upper, row-major), 21..26 b, 27 chi2, 28 #points, 29 #segments, 30..31 unused
 #pragma unroll
-    for (int k = 0; k < 21; ++k) aH[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) aB[k] = 0.0;
-    int cpt = 0, cls = 0;
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
     const double R0 = s_pose[0], R1 = s_pose[1], R2 = s_pose[2], R3 = s_pose[3], R4 = s_pose[4], R5 = s_pose[5],
                  R6 = s_pose[6], R7 = s_pose[7], R8 = s_pose[8], t0 = s_pose[9], t1 = s_pose[10], t2 = s_pose[11];
     for (int f = tid; f < nf; f += PO_T) {
@@ -127,7 +107,7 @@ __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseS
 #pragma unroll
         for (int k = 0; k < 12; ++k) J[k] *= sic;
         weight = (double)tukey_weight((float)(sqrt(e0 * e0 + e1 * e1) / scale_pt));
-        ++cpt;
+        acc[28] += 1.0;
       } else {
         const int s = job.seg_off + (f - np);
         if (!b.seg_keep[s]) continue;
@@ -152,35 +132,26 @@ __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseS
           J[6 + c] = l0 * (Je[c] * ks) + l1 * (Je[6 + c] * ks);
         }
         weight = (double)tukey_weight((float)(en / scale_ls));
-        ++cls;
+        acc[29] += 1.0;
       }
       int k = 0;
 #pragma unroll
       for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int jj = i; jj < 6; ++jj) { aH[k] += (J[i] * J[jj] + J[6 + i] * J[6 + jj]) * weight; ++k; }
+        for (int jj = i; jj < 6; ++jj) { acc[k] += (J[i] * J[jj] + J[6 + i] * J[6 + jj]) * weight; ++k; }
 #pragma unroll
-      for (int i = 0; i < 6; ++i) aB[i] -= (J[i] * e0 + J[6 + i] * e1) * weight;
-      aChi += (e0 * e0 + e1 * e1) * weight;
+      for (int i = 0; i < 6; ++i) acc[21 + i] -= (J[i] * e0 + J[6 + i] * e1) * weight;
+      acc[27] += (e0 * e0 + e1 * e1) * weight;
     }
     {
-      double acc[30];
-#pragma unroll
-      for (int k = 0; k < 21; ++k) acc[k] = aH[k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) acc[21 + k] = aB[k];
-      acc[27] = aChi; acc[28] = (double)cpt; acc[29] = (double)cls;
-      wave_sum_array<30>(acc);
-      if (lane == 63) {
-        double* dst = s_red + PO_RED * wave;
-#pragma unroll
-        for (int k = 0; k < 30; ++k) dst[k] = acc[k];
-      }
+      double out2[2];
+      row_reduce_scatter32(acc, out2);
+      *reinterpret_cast<double2*>(s_red + (tid >> 4) * 32 + row_reduce_scatter32_index(lane)) = make_double2(out2[0], out2[1]);
     }
     __syncthreads();
     if (wave == 0) {
-      double tot = 0.0;
-      if (lane < 30) { for (int w = 0; w < PO_T / 64; ++w) tot += s_red[PO_RED * w + lane]; s_tot[lane] = tot; }
+      const double tot = reduce_rows_finish<PO_T / 16>(s_red);
+      if (lane < 30) s_tot[lane] = tot;
       double dT[6];
       wave_solve6_reg(tot, dT);                                              // A.ldlt().solve(b) :170
       const double new_chi2 = readlane_f64(tot, 27), npt = readlane_f64(tot, 28), nls = readlane_f64(tot, 29);
@@ -192,7 +163,7 @@ __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseS
         if ((iter > 0 && new_chi2 > s_pose[26]) || isnan(dT[0])) {          // :173-180
           model = se3_load(s_pose + 19); accepted = 0; brk = 1;
         } else {
-          const SE3d Tn = se3_mul(se3_exp_dev(dT), model);                   // :183 left update
+          const SE3d Tn = se3_mul_dev(se3_exp_dev(dT), model);               // :183 left update
           se3_store(model, s_pose + 19);
           model = Tn; s_pose[26] = new_chi2;
           if (norm_max6(dT) <= 0.0000000001) brk = 1;                        // EPS, global.h:99
@@ -225,20 +196,22 @@ __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseS
   }
 }
 
-__global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b) {
+template <int PO_T>
+__global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* poses) {
   const int job_id = blockIdx.x;
   const PoseJobDev job = b.jobs[job_id];
   PoseStateDev* st = b.state + job_id;
   const int tid = threadIdx.x;
   const int np = job.n_pts, ns = job.n_seg, nf = np + ns;
 
-  __shared__ double s_red[PO_RED * (PO_T / 64)];
+  __shared__ __align__(16) double s_red[32 * (PO_T / 16)];
+  __shared__ double s_lu[36];     // covariance: the LU factors live in LDS (dynamic pivot indexing would put them in scratch)
+  __shared__ int s_perm[8];
   __shared__ double s_pose[32];   // 27: point-iterations, 28: line-iterations
   __shared__ double s_tot[32];
   __shared__ int s_ctl[32];
   __shared__ int s_hist[PO_BINS];                           // 8 KB: radix histogram, or staging for the rank select
   __shared__ int s_sel[16];
-  __shared__ unsigned long long s_rank_out;
 
   // scratch: floats [0,np) point errors, [np, np+ns) line errors; doubles [0,nf) init (first loop),
   // [nf,2nf) init (refinement), [2nf,3nf) final
@@ -260,7 +233,10 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b) {
   for (int i = tid; i < np; i += PO_T) b.pt_keep[job.pt_off + i] = 1;
   for (int s = tid; s < ns; s += PO_T) b.seg_keep[job.seg_off + s] = 1;
   __syncthreads();
-  if (nf == 0) { if (tid == 0) st->status = 1; return; }                      // errors.empty() :88-89
+  if (nf == 0) {                                                              // errors.empty() :88-89
+    if (tid == 0) { st->status = 1; if (poses) for (int k = 0; k < 7; ++k) poses[7 * job_id + k] = job.T0[k]; }
+    return;
+  }
 
   // ---- scale pass :57-95 ----
   {
@@ -292,31 +268,22 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b) {
   __syncthreads();
   // MAD scale = 1.48f * median (float).  Zero points: the reference is undefined (:70); we define 1.0.
   double scale_pt = 1.0, scale_ls = 1.0;
-  unsigned long long* s_vals = reinterpret_cast<unsigned long long*>(s_hist);   // PO_RANK_MAX 64-bit patterns fit in 8 KB
   auto median_f32 = [&](const float* v, int n) -> float {
-    uint32_t bits;
-    if (n <= PO_RANK_MAX) {
-      for (int i = tid; i < n; i += PO_T) s_vals[i] = (unsigned long long)__float_as_uint(v[i]);
-      __syncthreads();
-      bits = (uint32_t)block_rank_select<unsigned long long>(s_vals, n, n / 2, &s_rank_out);
-    } else {
-      bits = block_radix_select<32, uint32_t>([&](int i) { return (uint32_t)__float_as_uint(v[i]); }, n, n / 2, s_hist, s_sel);
-    }
-    return __uint_as_float(bits);
+    return __uint_as_float(block_radix_select<PO_T, 32, uint32_t>([&](int i) { return (uint32_t)__float_as_uint(v[i]); }, n, n / 2, s_hist, s_sel));
   };
   if (np > 0) scale_pt = (double)__fmul_rn(1.48f, median_f32(errs, np));
   if (ns > 0) scale_ls = (double)__fmul_rn(1.48f, median_f32(errs + np, ns));
 
   // ---- first GN loop ----
   if (job.n_iter <= 0) for (int f = tid; f < nf; f += PO_T) vec[f] = __longlong_as_double(0x7ff0000000000000LL);
-  popt_gn_loop(b, job, st, job_id, s_red, s_pose, s_ctl, job.n_iter, 0, scale_pt, scale_ls, vec, s_tot);
+  popt_gn_loop<PO_T>(b, job, st, job_id, s_red, s_pose, s_ctl, job.n_iter, 0, scale_pt, scale_ls, vec, s_tot);
 
   // ---- covariance :197-199 (from the last assembled A, even if that iteration was rolled back) ----
   if (tid == 0) {
     double Af[36];
     const double f2 = job.fx * job.fx;
     for (int i = 0; i < 6; ++i) for (int jj = 0; jj < 6; ++jj) Af[i * 6 + jj] = s_tot[sym6_index(i, jj)] * f2;
-    inv6(Af, st->cov);
+    inv6_lds(Af, st->cov, s_lu, s_perm);
   }
 
   // ---- cull :201-242 ----
@@ -368,25 +335,21 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b) {
   // ---- refinement with inliers :469-563 (10-argument overload) ----
   int n_init = job.n_iter > 0 ? nf : 0;
   if (job.n_iter_ref >= 0) {
-    popt_gn_loop(b, job, st, job_id, s_red, s_pose, s_ctl, job.n_iter_ref, 1, scale_pt, scale_ls, vec + nf, s_tot);
+    popt_gn_loop<PO_T>(b, job, st, job_id, s_red, s_pose, s_ctl, job.n_iter_ref, 1, scale_pt, scale_ls, vec + nf, s_tot);
     if (job.n_iter_ref > 0) n_init += nf - n_del_pt - n_del_ls;
   }
   __syncthreads();
 
   // ---- medians :244-249 ----
   auto kth_f64 = [&](const double* v, int n, int k) -> unsigned long long {
-    if (n <= PO_RANK_MAX) {
-      for (int i = tid; i < n; i += PO_T) s_vals[i] = (unsigned long long)__double_as_longlong(v[i]);
-      __syncthreads();
-      return block_rank_select<unsigned long long>(s_vals, n, k, &s_rank_out);
-    }
-    return block_radix_select<64, unsigned long long>([&](int i) { return (unsigned long long)__double_as_longlong(v[i]); }, n, k, s_hist, s_sel);
+    return block_radix_select<PO_T, 64, unsigned long long>([&](int i) { return (unsigned long long)__double_as_longlong(v[i]); }, n, k, s_hist, s_sel);
   };
   unsigned long long mi = 0;
   if (n_init > 0) mi = kth_f64(vec, (job.n_iter_ref > 0) ? 2 * nf : nf, n_init / 2);   // unwritten refinement entries hold +inf and sort last
   const unsigned long long mf = kth_f64(vec + 2 * nf, nf, nf / 2);
   if (tid == 0) {
     for (int k = 0; k < 7; ++k) st->T[k] = s_pose[12 + k];
+    if (poses) for (int k = 0; k < 7; ++k) poses[7 * job_id + k] = s_pose[12 + k];
     st->error_init = sqrt(__longlong_as_double((long long)mi)) * job.fx;
     st->error_final = sqrt(__longlong_as_double((long long)mf)) * job.fx;
     st->estimated_scale = scale_pt * job.fx;
@@ -397,19 +360,12 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b) {
   }
 }
 
-__global__ void pose_finish_kernel(PoseBatchDev b, double* poses) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= b.n_jobs) return;
-  for (int k = 0; k < 7; ++k) poses[7 * j + k] = b.state[j].T[k];
-}
-
-hipError_t launch_pose_finish(const PoseBatchDev& b, double* d_poses, hipStream_t stream) {
-  hipLaunchKernelGGL(pose_finish_kernel, dim3((b.n_jobs + 63) / 64), dim3(64), 0, stream, b, d_poses);
-  return hipGetLastError();
-}
-
-hipError_t launch_pose_opt(const PoseBatchDev& b, hipStream_t stream) {
-  hipLaunchKernelGGL(pose_opt_kernel, dim3(b.n_jobs), dim3(PO_T), 0, stream, b);
+hipError_t launch_pose_opt(const PoseBatchDev& b, double* d_poses, int threads, hipStream_t stream) {
+  switch (threads) {
+    case 64: hipLaunchKernelGGL((pose_opt_kernel<64>), dim3(b.n_jobs), dim3(64), 0, stream, b, d_poses); break;
+    case 256: hipLaunchKernelGGL((pose_opt_kernel<256>), dim3(b.n_jobs), dim3(256), 0, stream, b, d_poses); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

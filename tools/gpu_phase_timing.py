@@ -13,7 +13,7 @@ imgs = P.synth.render_streams(streams, device="cuda")
 ctx.config_pyramids(2 * B, 640, 480, 4)
 ctx.build_pyramids_dev(0, 2 * B, imgs.data_ptr(), 640, 640 * 480, 0)
 ctx.synchronize()
-names = ["setup+precompute", "phase0 uv", "phase1 pixels", "phase2 expand", "reduce", "solve+update"]
+names = ["setup+precompute", "fused pass", "reduce", "rows finish", "solve6", "update", "barrier"]
 L = ctx.L
 L.plsvo_align_phase_ticks.restype = C.c_int
 L.plsvo_align_phase_ticks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -32,7 +32,7 @@ for threads in os.environ.get("TIMING_THREADS", "256,512,1024").split(","):
         pl, pi = ctx.align_work()
         t = (C.c_uint64 * 8)()
         L.plsvo_align_phase_ticks(ctx.h, t)
-        t = np.array(t[:6], dtype=np.float64)
+        t = np.array(t[:7], dtype=np.float64)
         per_iter = t.copy(); per_iter[0] /= B; per_iter[1:] /= max(iters, 1)
         print(f"T={threads} level {level}: kernel {ms:.3f} ms, B={B}, mean iters {iters / B:.2f}, patches/frame {pl / B:.0f}, "
               f"ticks: " + ", ".join(f"{nm} {v:.0f}" for nm, v in zip(names, per_iter)) +
