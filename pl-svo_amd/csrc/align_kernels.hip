@@ -103,13 +103,7 @@ __device__ __forceinline__ PatchW patch_weights(float u, float v) {
 
 #define SLOT_HOLE ((int)0x80000000)   // s_meta[p].x of a slot no live feature owns at this level
 
-// LDS exchange between the lanes of ONE wave: the LDS pipeline keeps a wave's accesses in order, the fences keep the
-// compiler from moving them (no s_barrier is emitted)
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
+__device__ __forceinline__ void wave_lds_sync() { wave_lds_fence(); }
 // workgroup barrier; a one-wave workgroup needs only the wave-level form
 template <int T>
 __device__ __forceinline__ void block_sync() {
@@ -136,7 +130,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 
   extern __shared__ __align__(16) unsigned char smem[];
   double* s_red = reinterpret_cast<double*>(smem);                       // ROWS * 32: row partials
-  double* s_pose = s_red + ROWS * 32;                                    // 0..8 R, 9..11 t, 12..18 model, 19..25 old model, 26 chi2_, 27 #evals
+  double* s_pose = s_red + ROWS * 32;                                    // 0..8 R, 9..11 t, 12..18 model, 19..25 old model, 26 chi2_, 27 #evals, 28/29 work counters
   double* s_tot = s_pose + 32;                                           // block totals of the last iteration: 21 H, 6 Jres, chi2, n_meas, evals
   int* s_ctl = reinterpret_cast<int*>(s_tot + 32);                       // 0 break, 1 stop, 2 iterations done, 3 error, 5 #patches of the level
   int2* s_meta = reinterpret_cast<int2*>(s_ctl + 32);                    // cap: x = feature (>= 0 point, < 0 segment -1-x, SLOT_HOLE), y = first slot | N << 20
@@ -168,7 +162,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   block_sync<T>();   // seg_alive / state of this job initialised (same workgroup: visible after the barrier)
   if (tid == 0) {
     for (int k = 0; k < 7; ++k) { s_pose[12 + k] = st->T[k]; s_pose[19 + k] = st->T[k]; }
-    s_pose[26] = st->chi2;
+    s_pose[26] = st->chi2; s_pose[28] = 0.0; s_pose[29] = 0.0;
     for (int k = 0; k < 32; ++k) s_tot[k] = 0.0;
     s_ctl[1] = st->stop; s_ctl[3] = 0;
   }
@@ -522,10 +516,10 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       if (s_ctl[0]) break;
     }
 
-    if (tid == 0) {
+    if (tid == 0) {   // work counters stay in LDS until the end of the launch (a global read-modify-write here would stall every level)
       st->iters[level] = s_ctl[2];
-      st->patch_levels += (unsigned long long)s_ctl[5];
-      st->patch_iters += (unsigned long long)(s_pose[27] + 0.5);
+      s_pose[28] += (double)s_ctl[5];
+      s_pose[29] += s_pose[27];
     }
   }  // levels
 
@@ -534,6 +528,8 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     for (int k = 0; k < 7; ++k) st->T[k] = s_pose[12 + k];
     if (b.poses) for (int k = 0; k < 7; ++k) b.poses[7 * job_id + k] = s_pose[12 + k];
     st->chi2 = s_pose[26];
+    st->patch_levels += (unsigned long long)(s_pose[28] + 0.5);
+    st->patch_iters += (unsigned long long)(s_pose[29] + 0.5);
     st->stop = s_ctl[1];
     st->n_meas = (unsigned long long)(s_tot[28] + 0.5);
     for (int i = 0; i < 6; ++i) for (int jj = 0; jj < 6; ++jj) st->H[i * 6 + jj] = s_tot[sym6_index(i, jj)];

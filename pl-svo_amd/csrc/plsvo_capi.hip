@@ -461,9 +461,10 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
 // Environment overrides (experiments only): PLSVO_ALIGN_THREADS, PLSVO_ALIGN_PER_LEVEL, PLSVO_ALIGN_LDS_PAD.
 static void pick_align_config(const plsvo_ctx* c, int n_jobs, int cap, int scap, int* threads, size_t* lds) {
   const int cus = c->cu_count > 0 ? c->cu_count : 256;
-  int t = 128;
+  int t = 64;                            // >= 64 frames per CU: one wave per frame, no workgroup barrier at all
   if (n_jobs <= cus) t = 512;
   else if (n_jobs <= 4 * cus) t = 256;
+  else if (n_jobs < 64 * cus) t = 128;
   if (const char* s = getenv("PLSVO_ALIGN_THREADS")) { const int v = atoi(s); if (v == 64 || v == 128 || v == 256 || v == 512) t = v; }
   *threads = t; *lds = align_level_lds_bytes(t, cap, scap);
   if (const char* s = getenv("PLSVO_ALIGN_LDS_PAD")) *lds += (size_t)std::max(0, atoi(s));   // occupancy experiments: unused LDS bytes per workgroup
@@ -578,6 +579,16 @@ extern "C" int plsvo_align_phase_ticks(plsvo_ctx* c, unsigned long long* out8) {
   return PLSVO_OK;
 }
 
+extern "C" int plsvo_poseopt_phase_ticks(plsvo_ctx* c, unsigned long long* out8) {
+  CTX_CHECK(c);
+  if (!c->p_staged || !out8) return fail(c, PLSVO_E_STATE, "phase_ticks: no staged batch");
+  std::vector<PoseStateDev> st((size_t)c->p_n);
+  HIP_TRY(c, hipMemcpyAsync(st.data(), c->p_d_state.p, (size_t)c->p_n * sizeof(PoseStateDev), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 8; ++k) { out8[k] = 0; for (auto& s : st) out8[k] += s.phase_ticks[k]; }
+  return PLSVO_OK;
+}
+
 extern "C" int plsvo_align_copy_poses(plsvo_ctx* c, double* d_dst) {
   CTX_CHECK(c);
   if (!c->a_staged || !d_dst) return fail(c, PLSVO_E_STATE, "align_copy_poses: no staged batch / null destination");
@@ -669,7 +680,7 @@ extern "C" int plsvo_poseopt_run(plsvo_ctx* c) {
   // chip (the Gauss-Newton loop of one frame is then ~2x shorter); PLSVO_POSEOPT_THREADS overrides (experiments only)
   const int cus = c->cu_count > 0 ? c->cu_count : 256;
   int threads = c->p_n <= 2 * cus ? 256 : 64;
-  if (const char* s = getenv("PLSVO_POSEOPT_THREADS")) { const int v = atoi(s); if (v == 64 || v == 256) threads = v; }
+  if (const char* s = getenv("PLSVO_POSEOPT_THREADS")) { const int v = atoi(s); if (v == 64 || v == 256 || v == 512) threads = v; }
   EventPair ep{}; prof_begin(c, PLSVO_K_POSEOPT, &ep);
   HIP_TRY(c, launch_pose_opt(c->p_b, c->p_d_poses.as<double>(), threads, c->stream));
   prof_end(c, PLSVO_K_POSEOPT, &ep);

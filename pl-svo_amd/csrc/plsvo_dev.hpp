@@ -106,6 +106,7 @@ struct PoseStateDev {
   unsigned long long num_obs_pt, num_obs_ls;
   int iters, iters_ref, status, log_count;
   unsigned long long pt_iters, seg_iters;   // work counters
+  unsigned long long phase_ticks[8];        // only filled by -DPLSVO_TIMING builds (s_memtime ticks per phase)
 };
 
 struct PoseBatchDev {

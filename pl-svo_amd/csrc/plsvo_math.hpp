@@ -194,10 +194,11 @@ PLSVO_HD void inv6(const double* A, double* Ainv) {
 }
 
 #if defined(__HIPCC__)
-// inv6 for a single device lane with the LU factors in LDS: the pivot rows are indexed dynamically, which in private
-// memory means scratch (same arithmetic and pivot order as inv6)
-__device__ __forceinline__ void inv6_lds(const double* A, double* Ainv, double* lu /*36, LDS*/, int* perm /*6, LDS*/) {
-  for (int i = 0; i < 6; ++i) { perm[i] = i; for (int j = 0; j < 6; ++j) lu[i * 6 + j] = A[i * 6 + j]; }
+// inv6 on the device with the LU factors in LDS (the pivot rows are indexed dynamically, which in private memory means
+// scratch): one lane factorises in place (lu6_lds), then six lanes solve for one column of the inverse each
+// (inv6_column_lds).  Same arithmetic and pivot order as inv6.
+__device__ __forceinline__ void lu6_lds(double* lu /*36, LDS, in: A, out: LU*/, int* perm /*6, LDS*/) {
+  for (int i = 0; i < 6; ++i) perm[i] = i;
   for (int k = 0; k < 6; ++k) {
     int piv = k; double pv = fabs(lu[k * 6 + k]);
     for (int i = k + 1; i < 6; ++i) { const double v = fabs(lu[i * 6 + k]); if (v > pv) { pv = v; piv = i; } }
@@ -210,23 +211,23 @@ __device__ __forceinline__ void inv6_lds(const double* A, double* Ainv, double* 
       for (int j = k + 1; j < 6; ++j) lu[i * 6 + j] -= lu[i * 6 + k] * lu[k * 6 + j];
     }
   }
-  for (int c = 0; c < 6; ++c) {
-    double y[6];
+}
+__device__ __forceinline__ void inv6_column_lds(const double* lu, const int* perm, int c, double* Ainv) {
+  double y[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) y[i] = (perm[i] == c) ? 1.0 : 0.0;
+  for (int i = 0; i < 6; ++i) y[i] = (perm[i] == c) ? 1.0 : 0.0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int j = 0; j < i; ++j) y[i] -= lu[i * 6 + j] * y[j];
+    for (int j = 0; j < i; ++j) y[i] -= lu[i * 6 + j] * y[j];
 #pragma unroll
-    for (int i = 5; i >= 0; --i) {
+  for (int i = 5; i >= 0; --i) {
 #pragma unroll
-      for (int j = i + 1; j < 6; ++j) y[i] -= lu[i * 6 + j] * y[j];
-      y[i] /= lu[i * 6 + i];
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) Ainv[i * 6 + c] = y[i];
+    for (int j = i + 1; j < 6; ++j) y[i] -= lu[i * 6 + j] * y[j];
+    y[i] /= lu[i * 6 + i];
   }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Ainv[i * 6 + c] = y[i];
 }
 #endif
 

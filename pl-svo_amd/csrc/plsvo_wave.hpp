@@ -128,6 +128,14 @@ __device__ __forceinline__ double reduce_rows_finish(const double* s_rows) {
   return mine + __shfl_xor(mine, 32, 64);
 }
 
+// LDS (and global) exchange between the lanes of ONE wave: the memory pipelines keep a wave's accesses in order, the fences
+// keep the compiler from moving them (no s_barrier is emitted)
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int src_lane /*wave-uniform*/) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);

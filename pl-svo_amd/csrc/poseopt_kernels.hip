@@ -23,6 +23,13 @@
 
 namespace plsvo_hip {
 
+// optional per-phase timing (compile with -DPLSVO_TIMING): thread 0 accumulates s_memtime deltas
+#ifdef PLSVO_TIMING
+#define PTICK(slot) do { if (threadIdx.x == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); s_time[slot] += t__ - s_tlast; s_tlast = t__; } } while (0)
+#else
+#define PTICK(slot) do { } while (0)
+#endif
+
 #define PO_RED 32
 #ifndef PO_RADIX_BITS
 #define PO_RADIX_BITS 8    // bits per radix-select pass (measured on MI355X: 8 -> 0.72 ms, 11 -> 0.81 ms, 6 -> 0.74 ms per 8192 frames)
@@ -48,10 +55,11 @@ __device__ U block_radix_select(GET get, int n, int k, int* s_hist, int* s_sel) 
     }
     __syncthreads();
     // block scan over the bins: each thread owns PO_BINS/PO_T consecutive bins
-    constexpr int PER = PO_BINS / PO_T;
+    constexpr int PER = PO_BINS >= PO_T ? PO_BINS / PO_T : 1;   // more threads than bins: the surplus threads own no bin
+    const bool owner = tid * PER < PO_BINS;
     int loc[PER]; int local = 0;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) { loc[j] = s_hist[tid * PER + j]; local += loc[j]; }
+    for (int j = 0; j < PER; ++j) { loc[j] = owner ? s_hist[tid * PER + j] : 0; local += loc[j]; }
     int incl = local;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
@@ -62,14 +70,26 @@ __device__ U block_radix_select(GET get, int n, int k, int* s_hist, int* s_sel) 
     int cum = wave_off + incl - local;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
-      if (k >= cum && k < cum + loc[j]) { s_sel[0] = tid * PER + j; s_sel[1] = k - cum; }
+      if (owner && k >= cum && k < cum + loc[j]) { s_sel[0] = tid * PER + j; s_sel[1] = k - cum; s_sel[2] = loc[j]; }
       cum += loc[j];
     }
     __syncthreads();
     prefix |= ((U)s_sel[0]) << shift;
     mask |= ((U)(nb - 1)) << shift;
     k = s_sel[1];
+    const int survivors = s_sel[2];
     __syncthreads();
+    if (survivors == 1 && shift > 0) {
+      // one candidate left: it is the answer, the remaining digits need no histogram (typical after 2-3 of the 4 / 8 passes)
+      for (int i = tid; i < n; i += PO_T) {
+        const U v = get(i);
+        if ((v & mask) == prefix) { s_hist[0] = (int)(unsigned)(v & (U)0xffffffffu); s_hist[1] = (int)(unsigned)((unsigned long long)v >> 32); }
+      }
+      __syncthreads();
+      const U r = (U)(((unsigned long long)(unsigned)s_hist[1] << 32) | (unsigned long long)(unsigned)s_hist[0]);
+      __syncthreads();
+      return r;
+    }
   }
   return prefix;
 }
@@ -219,6 +239,11 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* 
   float* errs = b.scratch_f32 + fbase;
   double* vec = b.scratch_f64 + 3 * fbase;
 
+#ifdef PLSVO_TIMING
+  __shared__ unsigned long long s_time[8];
+  __shared__ unsigned long long s_tlast;
+  if (tid == 0) { for (int k = 0; k < 8; ++k) s_time[k] = 0; s_tlast = __builtin_amdgcn_s_memtime(); }
+#endif
   if (tid == 0) {
     SE3d m = se3_load(job.T0);
     se3_store(m, s_pose + 12); se3_store(m, s_pose + 19); s_pose[26] = 0.0; s_pose[27] = 0.0; s_pose[28] = 0.0;
@@ -266,6 +291,7 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* 
     }
   }
   __syncthreads();
+  PTICK(0);
   // MAD scale = 1.48f * median (float).  Zero points: the reference is undefined (:70); we define 1.0.
   double scale_pt = 1.0, scale_ls = 1.0;
   auto median_f32 = [&](const float* v, int n) -> float {
@@ -274,16 +300,20 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* 
   if (np > 0) scale_pt = (double)__fmul_rn(1.48f, median_f32(errs, np));
   if (ns > 0) scale_ls = (double)__fmul_rn(1.48f, median_f32(errs + np, ns));
 
+  PTICK(1);
   // ---- first GN loop ----
   if (job.n_iter <= 0) for (int f = tid; f < nf; f += PO_T) vec[f] = __longlong_as_double(0x7ff0000000000000LL);
   popt_gn_loop<PO_T>(b, job, st, job_id, s_red, s_pose, s_ctl, job.n_iter, 0, scale_pt, scale_ls, vec, s_tot);
 
+  PTICK(2);
   // ---- covariance :197-199 (from the last assembled A, even if that iteration was rolled back) ----
-  if (tid == 0) {
-    double Af[36];
+  if (tid < 64) {   // wave 0: lane 0 factorises, lanes 0..5 each solve for one column of the inverse
     const double f2 = job.fx * job.fx;
-    for (int i = 0; i < 6; ++i) for (int jj = 0; jj < 6; ++jj) Af[i * 6 + jj] = s_tot[sym6_index(i, jj)] * f2;
-    inv6_lds(Af, st->cov, s_lu, s_perm);
+    if (tid < 36) s_lu[tid] = s_tot[sym6_index(tid / 6, tid % 6)] * f2;
+    wave_lds_fence();
+    if (tid == 0) lu6_lds(s_lu, s_perm);
+    wave_lds_fence();
+    if (tid < 6) inv6_column_lds(s_lu, s_perm, tid, st->cov);
   }
 
   // ---- cull :201-242 ----
@@ -340,6 +370,7 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* 
   }
   __syncthreads();
 
+  PTICK(3);
   // ---- medians :244-249 ----
   auto kth_f64 = [&](const double* v, int n, int k) -> unsigned long long {
     return block_radix_select<PO_T, 64, unsigned long long>([&](int i) { return (unsigned long long)__double_as_longlong(v[i]); }, n, k, s_hist, s_sel);
@@ -357,6 +388,10 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* 
     st->num_obs_ls = (unsigned long long)(ns - n_del_ls);
     st->iters = s_ctl[1]; st->iters_ref = s_ctl[2];
     st->pt_iters = (unsigned long long)(s_pose[27] + 0.5); st->seg_iters = (unsigned long long)(s_pose[28] + 0.5);
+#ifdef PLSVO_TIMING
+    { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); s_time[4] += t__ - s_tlast; }
+    for (int k = 0; k < 8; ++k) st->phase_ticks[k] = s_time[k];
+#endif
   }
 }
 
@@ -364,6 +399,7 @@ hipError_t launch_pose_opt(const PoseBatchDev& b, double* d_poses, int threads, 
   switch (threads) {
     case 64: hipLaunchKernelGGL((pose_opt_kernel<64>), dim3(b.n_jobs), dim3(64), 0, stream, b, d_poses); break;
     case 256: hipLaunchKernelGGL((pose_opt_kernel<256>), dim3(b.n_jobs), dim3(256), 0, stream, b, d_poses); break;
+    case 512: hipLaunchKernelGGL((pose_opt_kernel<512>), dim3(b.n_jobs), dim3(512), 0, stream, b, d_poses); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
