@@ -3,22 +3,30 @@
 One "step" = one pass of the hot path over one batch of B independent synthetic streams resident in HBM:
   plsvo::SparseImgAlign::run (3 pyramid levels, <=30 GN iterations each) followed by
   plsvo::pose_optimizer::optimizeGaussNewton (<=10 iterations), per stream, through the C ABI.
-Workload = BASELINE.json configs[1]: 640x480, 200 points + 80 line segments, 4-image pyramid
+Default workload = BASELINE.json configs[1]: 640x480, 200 points + 80 line segments, 4-image pyramid
 (alignment levels 3..1).  Per-GPU batch is fixed as N grows ("weak" scaling); streams are independent, so
 ranks exchange nothing on the data path -- the only collective is the RCCL all-gather of the per-stream
-result poses (7 doubles each), once per step.
+result poses (7 doubles each), once per step (pl-svo_amd/dist.py::timed_sharded_steps is the timed region).
 
   python bench.py --gpus 1 --steps K --warmup W            (single process)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`, `cpu_baseline` and -- default
+workload, one GPU -- `latency`: the small-batch operating points (1 / 8 / 64 streams resident, what a live camera or
+BASELINE config 4's 8 streams per GPU see) and the C++ drop-in's per-call wall time including the PCIe upload.
+Other workloads (extra lines for profiles/, the driver's invocation is the default one):
+  --config 3   BASELINE configs[2]: 1280x720, 400 points + 150 segments, 5-image pyramid, levels 4..2
+  --config 5   BASELINE configs[4]: pose_optimizer only, 500 points + 200 segments, 10 iterations
 """
 import argparse
 import math
 import importlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -30,9 +38,30 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_PATCH_LEVEL = 497     # precompute, per patch-level
 BYTES_PER_PATCH_ITER = 485      # residual/Jacobian, per patch-iteration
-W, H = 640, 480
-N_PTS, N_SEG = 200, 80
-N_PYR, MAX_LEVEL, MIN_LEVEL = 4, 3, 1
+BYTES_PER_POINT_ITER = 24       # pose-opt, per point-iteration
+BYTES_PER_SEG_ITER = 40         # pose-opt, per segment-iteration
+# what align_fused_kernel itself requests: per patch-iteration 192 B of ref/dx/dy cache + 24 B 3-D point
+# + 2 lanes x 3 rows x 2 aligned dwords of the current image; per patch-level 4 lanes x 4 rows x 3 dwords of the reference
+# image read, 192 + 24 + 8 B written
+OWN_BYTES_PER_PATCH_ITER = 192 + 24 + 48
+OWN_BYTES_PER_PATCH_LEVEL = 192 + 192 + 24 + 8
+
+METRIC = "sparse-align+pose-opt frames/sec, 640×480, ~200 pts+80 lines; 1/2/4/8 GPU"   # BASELINE.json's metric, verbatim
+CONFIGS = {
+    2: dict(W=640, H=480, pts=200, seg=80, pyr=4, maxl=3, minl=1, batch=32768, pose_pts=200, pose_seg=80, metric=METRIC,
+            workload="BASELINE configs[1]: 640x480, 200 points + 80 line segments, 4-image pyramid (levels 3..1), "
+                     "sparse_img_align (<=30 GN it/level) + pose_optimizer (<=10 it, Tukey/MAD)"),
+    3: dict(W=1280, H=720, pts=400, seg=150, pyr=5, maxl=4, minl=2, batch=8192, pose_pts=400, pose_seg=150,
+            metric="sparse-align+pose-opt frames/sec, 1280×720, 400 pts+150 lines (BASELINE configs[2])",
+            workload="BASELINE configs[2]: 1280x720, 400 points + 150 line segments, 5-image pyramid (levels 4..2 = the reference's "
+                     "defaults, src/config.cpp:98-99), sparse_img_align (<=30 GN it/level) + pose_optimizer (<=10 it, Tukey/MAD)"),
+    5: dict(W=640, H=480, pts=0, seg=0, pyr=0, maxl=0, minl=0, batch=32768, pose_pts=500, pose_seg=200,
+            metric="pose-opt frames/sec, 500 pts+200 lines, 10 GN iterations (BASELINE configs[4])",
+            workload="BASELINE configs[4]: pose_optimizer::optimizeGaussNewton only, 500 points + 200 line segments, <=10 iterations, "
+                     "Tukey weights / MAD scale, outlier cull, covariance, medians"),
+}
+ORACLE_FLAGS = ("gcc -O3 -march=x86-64-v3 -fno-signed-zeros -fno-math-errno -funroll-loops -ffp-contract=off -fno-tree-slp-vectorize "
+                "(the reference's Release flags, CMakeLists.txt:25-36, with -march=native -> x86-64-v3 and fma contraction off: oracle/Makefile)")
 
 
 def host_cores():
@@ -53,17 +82,107 @@ def host_cores():
     return n
 
 
+def offline_traffic(B):
+    """HBM-side traffic of the dominant kernel from the committed PMC passes (profiles/hbm_traffic.json): measured OFFLINE with
+    rocprofv3 on this same command, stored per stream so that it follows --batch.  Returns (bytes per launch or None, source)."""
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        d = json.load(open(tfile))
+        per_stream = d.get("align_fused_kernel_bytes_per_stream")
+        if per_stream is None:
+            return None, None, None
+        src = f"offline rocprofv3 PMC passes, profiles/hbm_traffic.json ({d.get('measured_at', 'commit unknown')}), scaled from {d.get('batch')} streams"
+        raw = d.get("align_fused_kernel_bytes_per_stream_uncorrected")
+        return int(round(per_stream * B)), src, (int(round(raw * B)) if raw is not None else None)
+    except (OSError, ValueError, TypeError):
+        return None, None, None
+
+
+def latency_leg(P, ctx, align_jobs, pose_jobs, streams, pose_frames, cfg, single_thread_fps):
+    """Small-batch operating points on one GPU (inputs resident in HBM, as in the headline number) + the drop-in's per-call time."""
+    abi = P.abi
+    out = {"note": "b streams resident in HBM; step = plsvo_align_run + plsvo_poseopt_run; frames_per_s / us_per_step: 60 steps enqueued without "
+                   "host synchronisation; *_synced: one step + hipStreamSynchronize, per step; mean over the groups (min / max beside it)"}
+    def measure(lo, hi):
+        ctx.align_stage(align_jobs[lo:hi])
+        ctx.poseopt_stage(pose_jobs[lo:hi])
+        ctx.synchronize()
+
+        def step():
+            ctx.align_run()
+            ctx.poseopt_run()
+        for _ in range(5):
+            step()
+        ctx.synchronize()
+        K = 60
+        t0 = time.perf_counter()
+        for _ in range(K):
+            step()
+        ctx.synchronize()
+        bb = (time.perf_counter() - t0) / K
+        t0 = time.perf_counter()
+        for _ in range(K // 2):
+            step()
+            ctx.synchronize()
+        sy = (time.perf_counter() - t0) / (K // 2)
+        ctx.set_profiling(True)
+        ctx.reset_profiling()
+        for _ in range(20):
+            step()
+        ctx.synchronize()
+        ctx.set_profiling(False)
+        ka, na = ctx.kernel_time(abi.K_ALIGN_LEVEL)
+        kp, npo = ctx.kernel_time(abi.K_POSEOPT)
+        return bb, sy, 1e3 * ka / max(na, 1), 1e3 * kp / max(npo, 1)
+
+    for b in (1, 8, 64):
+        # a launch lasts as long as its slowest frame (3 levels x up to 30 GN iterations), so a small batch depends on which
+        # streams are in it: every size is measured on up to 8 disjoint groups of the timed batch's first streams
+        groups = [(g * b, (g + 1) * b) for g in range(8) if (g + 1) * b <= min(len(align_jobs), 64 if b < 64 else 512)]
+        if not groups:
+            continue
+        rows = [measure(lo, hi) for lo, hi in groups]
+        bb = np.array([r[0] for r in rows]); sy = np.array([r[1] for r in rows])
+        out[f"B{b}"] = {"groups": len(rows), "frames_per_s": round(float(np.mean(b / bb)), 1), "frames_per_s_min": round(float(np.min(b / bb)), 1),
+                        "frames_per_s_max": round(float(np.max(b / bb)), 1), "us_per_step": round(float(np.mean(bb)) * 1e6, 1),
+                        "frames_per_s_synced": round(float(np.mean(b / sy)), 1), "us_per_step_synced": round(float(np.mean(sy)) * 1e6, 1),
+                        "align_kernel_us": round(float(np.mean([r[2] for r in rows])), 1), "poseopt_kernel_us": round(float(np.mean([r[3] for r in rows])), 1)}
+    # the C++ drop-in (pl-svo_amd/host/plsvo/hip_adapter.hpp) called like FrameHandlerMono::processFrame does: every call
+    # flattens the feature lists, uploads the NEW frame's pyramid over PCIe (the previous frame's is cached on the device),
+    # launches, synchronises and writes the results back
+    drv = os.path.join(ROOT, "pl-svo_amd", "host", "adapter_driver")
+    if os.path.exists(drv):
+        try:
+            ref = ctx.download_pyramid(0)
+            cur = ctx.download_pyramid(1)
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "in.bin")
+                P.adapter_io.write_adapter_input(path, streams[0], ref, cur, pose_frames[0], cfg["pyr"], cfg["maxl"], cfg["minl"])
+                r = subprocess.run([drv, "--bench", "200", path], check=True, capture_output=True, text=True, timeout=300)
+            a = json.loads(r.stdout.strip().splitlines()[-1])
+            a["what"] = ("adapter_driver --bench 200: wall time per SparseImgAlign::run / optimizeGaussNewton call of the C++ drop-in, "
+                         "feature flattening + PCIe upload of one 408 KB pyramid + launch + synchronise + write-back included")
+            if single_thread_fps:
+                a["cpu_single_thread_us_per_frame"] = round(1e6 / single_thread_fps, 1)
+            out["adapter_per_call"] = a
+        except Exception as e:   # the latency leg must never take the headline line down
+            out["adapter_per_call"] = {"error": str(e)[:200]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PLSVO_BENCH_BATCH", "32768")), help="streams per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[] number (1-based): 2 = the metric's workload")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PLSVO_BENCH_BATCH", "0")), help="streams per GPU (0 = the config's default)")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU-baseline budget (rank 0, N=1 only): half single-thread, half all cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", type=int, default=int(os.environ.get("PLSVO_BENCH_OVERLAP", "0")),
-                    help="1: pose-opt runs on a second ctx/stream concurrently with the alignment kernel of the same step")
+    ap.add_argument("--no-latency", action="store_true", help="skip the small-batch / per-call latency leg")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    pose_only = args.config == 5
 
     import torch
     import torch.distributed as dist
@@ -71,165 +190,149 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     P = importlib.import_module("pl-svo_amd")
-    capi, synth, abi = P.capi, P.synth, P.abi
-    B = args.batch
+    capi, synth, abi, D = P.capi, P.synth, P.abi, P.dist
+    B = args.batch if args.batch > 0 else cfg["batch"]
+    W, H = cfg["W"], cfg["H"]
 
-    # every launch goes on torch's current stream, so torch.cuda.synchronize()/events/RCCL see it
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    ctx = capi.Context(local_rank, stream=stream)
+    # ONE stream for everything: the library enqueues on it (plsvo_hip_create_on_stream), it is torch's current stream while the
+    # benchmark runs, so torch.cuda.synchronize / the RCCL all-gather are ordered after the library's kernels and copies
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        ctx = capi.Context(local_rank, stream=stream.cuda_stream)
 
-    # ---- synthetic inputs, generated in HBM (untimed) ----
-    seed0 = 1234 + rank * B
-    streams = [synth.make_align_stream(seed0 + i, W, H, N_PTS, N_SEG, max_level=MAX_LEVEL) for i in range(B)]
-    ctx.config_pyramids(2 * B, W, H, N_PYR)
-    chunk = 256
-    for c0 in range(0, B, chunk):
-        sub = streams[c0:c0 + chunk]
-        imgs = synth.render_streams(sub, device=dev)                      # [b, 2, H, W] u8 in HBM
-        ctx.build_pyramids_dev(2 * c0, 2 * len(sub), imgs.data_ptr(), W, W * H, 0)   # device half-sampler
+        # ---- synthetic inputs, generated in HBM (untimed) ----
+        seeds = D.rank_seeds(rank, world, B)          # 1234 + global stream index
+        streams, align_jobs = [], []
+        if not pose_only:
+            streams = [synth.make_align_stream(s, W, H, cfg["pts"], cfg["seg"], max_level=cfg["maxl"]) for s in seeds]
+            ctx.config_pyramids(2 * B, W, H, cfg["pyr"])
+            chunk = 256 if W <= 640 else 64
+            for c0 in range(0, B, chunk):
+                sub = streams[c0:c0 + chunk]
+                imgs = synth.render_streams(sub, device=dev)                      # [b, 2, H, W] u8 in HBM
+                ctx.build_pyramids_dev(2 * c0, 2 * len(sub), imgs.data_ptr(), W, W * H, 0)   # device half-sampler
+                ctx.synchronize()
+                del imgs
+            align_jobs = [P.align_job_from_stream(s, cfg["maxl"], cfg["minl"], ref_slot=2 * i, cur_slot=2 * i + 1) for i, s in enumerate(streams)]
+            ctx.align_stage(align_jobs)      # features + job descriptors -> HBM; the timed region only launches kernels
+        pose_frames = [synth.make_poseopt_frame(s, cfg["pose_pts"], cfg["pose_seg"], W, H) for s in seeds]
+        pose_jobs = [P.poseopt_job_from_frame(f) for f in pose_frames]
+        ctx.poseopt_stage(pose_jobs)
         ctx.synchronize()
-        del imgs
-    align_jobs = [P.align_job_from_stream(s, MAX_LEVEL, MIN_LEVEL, ref_slot=2 * i, cur_slot=2 * i + 1) for i, s in enumerate(streams)]
-    pose_frames = [synth.make_poseopt_frame(seed0 + i, N_PTS, N_SEG, W, H) for i in range(B)]
-    pose_jobs = [P.poseopt_job_from_frame(f) for f in pose_frames]
-    ctx.align_stage(align_jobs)      # features + job descriptors -> HBM; the timed region only launches kernels
-    main_stream = torch.cuda.current_stream(dev)
-    if args.overlap:
-        # the two halves of a step work on independent data: run them on two HIP streams so that pose-opt waves fill the
-        # issue slots and the launch tail the alignment kernel leaves idle
-        side_stream = torch.cuda.Stream(dev)
-        pctx = capi.Context(local_rank, stream=side_stream.cuda_stream)
-    else:
-        side_stream, pctx = None, ctx
-    pctx.poseopt_stage(pose_jobs)
-    ctx.synchronize()
-    pctx.synchronize()
 
-    gathered = None
-    local_poses = None
-    if world > 1:
+        def step_local():
+            if not pose_only:
+                ctx.align_run()
+            ctx.poseopt_run()
+
         local_poses = torch.empty((B, 7), dtype=torch.float64, device=dev)
-        gathered = torch.empty((world * B, 7), dtype=torch.float64, device=dev)
+        def timers_on():                        # hipEvent pairs around every launch of the timed steps only
+            ctx.set_profiling(True)
+            ctx.reset_profiling()
+        elapsed, gathered = D.timed_sharded_steps(step_local, lambda t: ctx.poseopt_copy_poses(t.data_ptr()), local_poses,
+                                                  args.steps, args.warmup, device_sync=lambda: torch.cuda.synchronize(dev), before_timed=timers_on)
+        ctx.set_profiling(False)
 
-    def step():
-        if side_stream is not None:
-            side_stream.wait_stream(main_stream)                  # a step starts when the previous one has finished
-        ctx.align_run()
-        pctx.poseopt_run()
-        if world > 1:
-            pctx.poseopt_copy_poses(local_poses.data_ptr())       # final per-stream poses, device to device
-        if side_stream is not None:
-            main_stream.wait_stream(side_stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, local_poses)   # RCCL over xGMI: the only collective
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-
-    ctx.set_profiling(True)
-    ctx.reset_profiling()
-    if pctx is not ctx:
-        pctx.set_profiling(True)
-        pctx.reset_profiling()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
-    ctx.set_profiling(False)
-    elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- roofline of the dominant kernel (align_fused_kernel), from live hipEvent timings ----
-    lvl_ms, lvl_launches = ctx.kernel_time(abi.K_ALIGN_LEVEL)
-    pose_ms, pose_launches = pctx.kernel_time(abi.K_POSEOPT)
-    patch_levels, patch_iters = ctx.align_work()       # counted on the device, per run of the staged batch
-    alg_bytes_per_step = patch_levels * BYTES_PER_PATCH_LEVEL + patch_iters * BYTES_PER_PATCH_ITER
-    launches_per_step = max(lvl_launches // max(args.steps, 1), 1)
-    avg_launch_ms = lvl_ms / max(lvl_launches, 1)
-    achieved = (alg_bytes_per_step / launches_per_step) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            # measured offline with rocprofv3 PMC passes on this same command (see profiles/hbm_traffic.json);
-            # stored per stream so that it follows --batch
-            traffic = round(json.load(open(tfile)).get("align_fused_kernel_bytes_per_stream") * B)
-        except Exception:
-            traffic = None
-
-    res = ctx.align_fetch()
-    pres = pctx.poseopt_fetch()
-    result = None
-    if rank == 0:
-        frames = world * B * args.steps
-        value = frames / elapsed
-        errs = np.array([synth.se3_log_angle_dist(r.T, s.T_true) for r, s in zip(res[:64], streams[:64])])
-        result = {
-            "metric": "sparse-align+pose-opt frames/sec, 640\u00d7480, ~200 pts+80 lines; 1/2/4/8 GPU",   # BASELINE.json's metric, verbatim
-            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 640x480, 200 points + 80 line segments, 4-image pyramid (levels 3..1), "
-                                   "sparse_img_align (<=30 GN it/level) + pose_optimizer (<=10 it, Tukey/MAD)",
-                       "streams_per_gpu": B, "global_batch": world * B,
-                       "parallelism": f"streams sharded x{world}, RCCL all-gather of poses" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "align_fused_kernel", "avg_launch_ms": round(avg_launch_ms, 4),
-                         "launches": int(lvl_launches), "algorithmic_bytes_per_launch": int(alg_bytes_per_step // launches_per_step),
-                         "patch_levels_per_step": int(patch_levels), "patch_iters_per_step": int(patch_iters)},
-            "kernel_ms_per_step": {"align_level": round(lvl_ms / args.steps, 4), "pose_opt": round(pose_ms / args.steps, 4)},
-            "accuracy_vs_truth": {"median_rot_rad": float(np.median(errs[:, 0])), "median_trans_m": float(np.median(errs[:, 1]))},
-        }
-        # ---- CPU baseline: the oracle (single thread) on a bounded sample of the same streams ----
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import binding as ob
-            ob.build()
-            n_s = min(B, 64)
-            pyrs = [(ctx.download_pyramid(2 * i), ctx.download_pyramid(2 * i + 1)) for i in range(n_s)]
-            for i in range(min(4, n_s)):   # warm-up, and a parity spot check of the timed batch against the oracle
-                ro, _ = ob.sparse_align(align_jobs[i], pyrs[i][0], pyrs[i][1])
-                ang, dist_ = synth.se3_log_angle_dist(ro.T, res[i].T)
-                po, _ = ob.pose_optimize(pose_jobs[i])
-                ang2, dist2 = synth.se3_log_angle_dist(po.T, pres[i].T)
-                assert ang < 1e-4 and ang2 < 1e-4, "bench batch disagrees with the oracle"
-            # the timed loops run inside the oracle library (POSIX threads, no Python between frames)
-            half = 0.5 * args.cpu_seconds
-            done1, tc1 = ob.bench(align_jobs[:n_s], [p[0] for p in pyrs], [p[1] for p in pyrs], pose_jobs[:n_s], 1, half)
-            cores = host_cores()
-            doneN, tcN = ob.bench(align_jobs[:n_s], [p[0] for p in pyrs], [p[1] for p in pyrs], pose_jobs[:n_s], cores, half)
-            result["cpu_baseline"] = {"value": round(doneN / tcN, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-                                      "sample": f"{doneN} frames on {cores} threads in {tcN:.1f} s (independent streams, round-robin over the first "
-                                                f"{n_s} streams of the timed batch), oracle/libplsvo_oracle.so, timed inside the library",
-                                      "scaling_over_one_thread": round((doneN / tcN) / (done1 / tc1), 2),
-                                      "single_thread_value": round(done1 / tc1, 2),
-                                      "single_thread_sample": f"{done1} frames in {tc1:.1f} s on one thread"}
-            result["speedup_vs_cpu_all_cores"] = round(value / (doneN / tcN), 1)
-            result["speedup_vs_cpu_1core"] = round(value / (done1 / tc1), 1)
-        print(json.dumps(result), flush=True)
-    if pctx is not ctx:
-        pctx.close()
-    ctx.close()
+        # ---- roofline of the dominant kernel, from live hipEvent timings on the launch stream ----
+        lvl_ms, lvl_launches = (0.0, 0) if pose_only else ctx.kernel_time(abi.K_ALIGN_LEVEL)
+        pose_ms, pose_launches = ctx.kernel_time(abi.K_POSEOPT)
+        res = [] if pose_only else ctx.align_fetch()
+        pres = ctx.poseopt_fetch()
+        result = None
+        if rank == 0:
+            frames = world * B * args.steps
+            value = frames / elapsed
+            if pose_only:
+                pt_it, seg_it = ctx.poseopt_work()
+                alg_bytes = pt_it * BYTES_PER_POINT_ITER + seg_it * BYTES_PER_SEG_ITER
+                avg_ms = pose_ms / max(pose_launches, 1)
+                achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+                roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                            "traffic": None, "kernel": "pose_opt_kernel", "avg_launch_ms": round(avg_ms, 4), "launches": int(pose_launches),
+                            "algorithmic_bytes_per_launch": int(alg_bytes),
+                            "definition": "SURVEY.md 8(d) algorithmic bytes (24 B per point-iteration, 40 B per segment-iteration, device-side counters) / "
+                                          "hipEvent time of the launch; informational: the kernel is latency-bound by construction (DESIGN.md 3.2)"}
+            else:
+                patch_levels, patch_iters = ctx.align_work()       # counted on the device, per run of the staged batch
+                alg_bytes = patch_levels * BYTES_PER_PATCH_LEVEL + patch_iters * BYTES_PER_PATCH_ITER
+                own_bytes = patch_levels * OWN_BYTES_PER_PATCH_LEVEL + patch_iters * OWN_BYTES_PER_PATCH_ITER
+                avg_ms = lvl_ms / max(lvl_launches, 1)
+                achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+                traffic, traffic_src, traffic_raw = offline_traffic(B) if args.config == 2 else (None, None, None)
+                roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                            "traffic": traffic, "traffic_source": traffic_src, "traffic_uncorrected": traffic_raw,
+                            "kernel": "align_fused_kernel", "avg_launch_ms": round(avg_ms, 4), "launches": int(lvl_launches),
+                            "algorithmic_bytes_per_launch": int(alg_bytes),
+                            "definition": "ALGORITHMIC bytes per SURVEY.md 8(d) (485 B per patch-iteration, 497 B per patch-level, fixed figures that "
+                                          "charge a 384-B per-pixel Jacobian cache this kernel never materialises; device-side work counters) / "
+                                          "hipEvent time of the launch on the launch stream.  NOT measured DRAM bandwidth: see kernel_requested_*, traffic",
+                            "kernel_requested_bytes_per_launch": int(own_bytes),
+                            "kernel_requested_GBps": round(own_bytes / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
+                            "patch_levels_per_step": int(patch_levels), "patch_iters_per_step": int(patch_iters)}
+            result = {
+                "metric": cfg["metric"],
+                "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": cfg["workload"], "streams_per_gpu": B, "global_batch": world * B,
+                           "parallelism": f"streams sharded x{world}, RCCL all-gather of poses" if world > 1 else "single GPU"},
+                "roofline": roofline,
+                "kernel_ms_per_step": {"align_fused": round(lvl_ms / args.steps, 4), "pose_opt": round(pose_ms / args.steps, 4)},
+            }
+            if not pose_only:
+                errs = np.array([synth.se3_log_angle_dist(r.T, s.T_true) for r, s in zip(res[:64], streams[:64])])
+                result["accuracy_vs_truth"] = {"median_rot_rad": float(np.median(errs[:, 0])), "median_trans_m": float(np.median(errs[:, 1]))}
+            # ---- CPU baseline: the oracle on a bounded sample of the same streams, on this box's host cores ----
+            single_fps = None
+            if world == 1 and not args.no_cpu_baseline:
+                from oracle import binding as ob
+                ob.build()
+                n_s = min(B, 64)
+                what = 2 if pose_only else 3
+                pyrs = [] if pose_only else [(ctx.download_pyramid(2 * i), ctx.download_pyramid(2 * i + 1)) for i in range(n_s)]
+                for i in range(min(4, n_s)):   # warm-up, and a parity spot check of the timed batch against the oracle
+                    if not pose_only:
+                        ro, _ = ob.sparse_align(align_jobs[i], pyrs[i][0], pyrs[i][1])
+                        ang, _ = synth.se3_log_angle_dist(ro.T, res[i].T)
+                        assert ang < 1e-4, "bench batch disagrees with the oracle (alignment)"
+                    po, _ = ob.pose_optimize(pose_jobs[i])
+                    ang2, _ = synth.se3_log_angle_dist(po.T, pres[i].T)
+                    assert ang2 < 1e-4, "bench batch disagrees with the oracle (pose optimisation)"
+                # the timed loops run inside the oracle library (POSIX threads, no Python between frames)
+                half = 0.5 * args.cpu_seconds
+                rp, cp = [p[0] for p in pyrs], [p[1] for p in pyrs]
+                done1, tc1, lat = ob.bench(align_jobs[:n_s], rp, cp, pose_jobs[:n_s], 1, half, what=what, latencies=True)
+                cores = host_cores()
+                doneN, tcN = ob.bench(align_jobs[:n_s], rp, cp, pose_jobs[:n_s], cores, half, what=what)
+                single_fps = done1 / tc1
+                result["cpu_baseline"] = {
+                    "value": round(doneN / tcN, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+                    "sample": f"{doneN} frames on {cores} threads in {tcN:.1f} s (independent streams, round-robin over the first "
+                              f"{n_s} streams of the timed batch), oracle/libplsvo_oracle.so, timed inside the library; the reference itself is "
+                              f"single-threaded on this path; threads not pinned (the container's CPU quota allows {cores})",
+                    "scaling_over_one_thread": round((doneN / tcN) / single_fps, 2),
+                    "single_thread_value": round(single_fps, 2),
+                    "single_thread_sample": f"{done1} frames in {tc1:.1f} s on one thread",
+                    "single_thread_median_us_per_frame": round(float(np.median(lat)), 1) if len(lat) else None,
+                    "build_flags": ORACLE_FLAGS}
+                result["speedup_vs_cpu_all_cores"] = round(value / (doneN / tcN), 1)
+                result["speedup_vs_cpu_1core"] = round(value / single_fps, 1)
+            # ---- small batches and the drop-in's per-call latency (default workload, one GPU) ----
+            if world == 1 and args.config == 2 and not args.no_latency:
+                result["latency"] = latency_leg(P, ctx, align_jobs, pose_jobs, streams, pose_frames, cfg, single_fps)
+                cb = result.get("cpu_baseline")
+                if cb and "B8" in result["latency"]:
+                    result["latency"]["B8_vs_cpu_all_cores"] = round(result["latency"]["B8"]["frames_per_s"] / cb["value"], 2)
+            print(json.dumps(result), flush=True)
+        ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

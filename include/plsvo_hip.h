@@ -57,6 +57,11 @@ typedef struct plsvo_pinhole {
 /* device_id: HIP ordinal.  stream: a hipStream_t (as void*) to enqueue on, or NULL to let the
  * ctx create its own non-blocking stream. */
 int plsvo_hip_create(int device_id, void* stream, plsvo_ctx** out);
+/* The same, but `stream` is ALWAYS the stream to enqueue on -- including the NULL handle, which is HIP's default (legacy)
+ * stream and what e.g. torch.cuda.current_stream().cuda_stream returns when no other stream is current.  A caller that
+ * orders other work (an RCCL collective, its own kernels) against the library's launches must use this form, or pass a
+ * non-NULL stream: plsvo_hip_create(.., NULL, ..) enqueues on a private stream the caller's work is not ordered with. */
+int plsvo_hip_create_on_stream(int device_id, void* stream, plsvo_ctx** out);
 void plsvo_hip_destroy(plsvo_ctx* ctx);
 const char* plsvo_hip_last_error(const plsvo_ctx* ctx);   /* ctx may be NULL: last create error */
 void* plsvo_hip_stream(plsvo_ctx* ctx);                   /* the hipStream_t all work is enqueued on */

@@ -210,20 +210,31 @@ def update_seeds(job, frame_levels):
     return job.trim(bufs)
 
 
-def bench(align_jobs, ref_pyrs, cur_pyrs, pose_jobs, n_threads, seconds):
-    """SparseImgAlign::run + optimizeGaussNewton over the given streams on n_threads POSIX threads (no Python in the loop).
-    Returns (frames completed, wall seconds)."""
-    n = len(align_jobs)
-    aj = (abi.AlignIn * n)(*[j.c for j in align_jobs])
-    pj = (abi.PoseOptIn * n)(*[j.c for j in pose_jobs])
+def bench(align_jobs, ref_pyrs, cur_pyrs, pose_jobs, n_threads, seconds, what=3, latencies=False):
+    """SparseImgAlign::run (what & 1) and/or optimizeGaussNewton (what & 2) over the given streams on n_threads POSIX threads
+    (no Python in the loop).  Returns (frames completed, wall seconds) and, with latencies=True, also the per-frame wall
+    times in microseconds of thread 0 (first 4096 frames)."""
+    n = len(pose_jobs) if not (what & 1) else len(align_jobs)
+    L = lib()
+    L.plsvo_oracle_bench_mode.restype = C.c_longlong
+    L.plsvo_oracle_bench_mode.argtypes = [C.c_int, C.POINTER(abi.AlignIn), C.POINTER(OraclePyr), C.POINTER(OraclePyr), C.POINTER(abi.PoseOptIn),
+                                          C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
+    aj = (abi.AlignIn * n)(*[j.c for j in align_jobs[:n]]) if (what & 1) else (abi.AlignIn * n)()
+    pj = (abi.PoseOptIn * n)(*[j.c for j in pose_jobs[:n]]) if (what & 2) else (abi.PoseOptIn * n)()
     rp, cp, keep = (OraclePyr * n)(), (OraclePyr * n)(), []
-    for i in range(n):
-        a, k1 = make_pyr(ref_pyrs[i])
-        b, k2 = make_pyr(cur_pyrs[i])
-        rp[i], cp[i] = a, b
-        keep += [k1, k2]
+    if what & 1:
+        for i in range(n):
+            a, k1 = make_pyr(ref_pyrs[i])
+            b, k2 = make_pyr(cur_pyrs[i])
+            rp[i], cp[i] = a, b
+            keep += [k1, k2]
     el = C.c_double(0.0)
-    done = lib().plsvo_oracle_bench(n, aj, rp, cp, pj, int(n_threads), float(seconds), C.byref(el))
+    cap = 4096
+    lat = (C.c_double * cap)()
+    n_lat = C.c_int(0)
+    done = L.plsvo_oracle_bench_mode(n, aj, rp, cp, pj, int(n_threads), float(seconds), int(what), C.byref(el), lat, cap, C.byref(n_lat))
+    if latencies:
+        return int(done), float(el.value), np.array(lat[:n_lat.value], dtype=np.float64)
     return int(done), float(el.value)
 
 

@@ -1672,6 +1672,8 @@ typedef struct {
   int tid, n_threads, n_streams, max_seg, max_pts;
   const plsvo_align_in* aj; const plsvo_oracle_pyr* ref; const plsvo_oracle_pyr* cur; const plsvo_poseopt_in* pj;
   double seconds; long long done;
+  int what;                 /* bit 0: SparseImgAlign::run, bit 1: optimizeGaussNewton */
+  double* lat_us; int lat_cap, n_lat;   /* per-frame wall times of this thread (first lat_cap frames), or NULL */
 } bench_arg_t;
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
@@ -1686,10 +1688,16 @@ static void* bench_worker(void* p) {
   int n_log = 0;
   for (int i = a->tid; now_s() < t_end; i += a->n_threads) {
     const int s = i % a->n_streams;
-    plsvo_align_out ao; memset(&ao, 0, sizeof(ao)); ao.seg_alive_out = alive;
-    plsvo_oracle_sparse_align(&a->aj[s], &a->ref[s], &a->cur[s], &ao, NULL, 0, &n_log);
-    plsvo_poseopt_out po; memset(&po, 0, sizeof(po)); po.pt_keep = pk; po.seg_keep = sk;
-    plsvo_oracle_pose_optimize(&a->pj[s], &po, NULL, 0, &n_log);
+    const double t_frame = now_s();
+    if (a->what & 1) {
+      plsvo_align_out ao; memset(&ao, 0, sizeof(ao)); ao.seg_alive_out = alive;
+      plsvo_oracle_sparse_align(&a->aj[s], &a->ref[s], &a->cur[s], &ao, NULL, 0, &n_log);
+    }
+    if (a->what & 2) {
+      plsvo_poseopt_out po; memset(&po, 0, sizeof(po)); po.pt_keep = pk; po.seg_keep = sk;
+      plsvo_oracle_pose_optimize(&a->pj[s], &po, NULL, 0, &n_log);
+    }
+    if (a->lat_us && a->n_lat < a->lat_cap) a->lat_us[a->n_lat++] = 1e6 * (now_s() - t_frame);
     ++done;
   }
   free(alive); free(pk); free(sk);
@@ -1699,26 +1707,36 @@ static void* bench_worker(void* p) {
 
 /* runs SparseImgAlign::run + optimizeGaussNewton on streams 0..n_streams-1 (round-robin over the threads) for `seconds`;
  * returns the number of frames completed by all threads, *elapsed gets the wall time */
+long long plsvo_oracle_bench_mode(int n_streams, const plsvo_align_in* aj, const plsvo_oracle_pyr* ref, const plsvo_oracle_pyr* cur,
+                                  const plsvo_poseopt_in* pj, int n_threads, double seconds, int what, double* elapsed,
+                                  double* lat_us, int lat_cap, int* n_lat);
 long long plsvo_oracle_bench(int n_streams, const plsvo_align_in* aj, const plsvo_oracle_pyr* ref, const plsvo_oracle_pyr* cur,
                              const plsvo_poseopt_in* pj, int n_threads, double seconds, double* elapsed) {
-  if (n_streams <= 0 || n_threads <= 0) return -1;
+  return plsvo_oracle_bench_mode(n_streams, aj, ref, cur, pj, n_threads, seconds, 3, elapsed, NULL, 0, NULL);
+}
+/* what: bit 0 = SparseImgAlign::run, bit 1 = optimizeGaussNewton; lat_us/lat_cap/n_lat: per-frame wall times of thread 0 */
+long long plsvo_oracle_bench_mode(int n_streams, const plsvo_align_in* aj, const plsvo_oracle_pyr* ref, const plsvo_oracle_pyr* cur,
+                                  const plsvo_poseopt_in* pj, int n_threads, double seconds, int what, double* elapsed,
+                                  double* lat_us, int lat_cap, int* n_lat) {
+  if (n_streams <= 0 || n_threads <= 0 || !(what & 3)) return -1;
   int max_seg = 1, max_pts = 1;
   for (int s = 0; s < n_streams; ++s) {
-    if (aj[s].n_seg > max_seg) max_seg = aj[s].n_seg;
-    if (pj[s].n_seg > max_seg) max_seg = pj[s].n_seg;
-    if (pj[s].n_pts > max_pts) max_pts = pj[s].n_pts;
+    if ((what & 1) && aj[s].n_seg > max_seg) max_seg = aj[s].n_seg;
+    if ((what & 2) && pj[s].n_seg > max_seg) max_seg = pj[s].n_seg;
+    if ((what & 2) && pj[s].n_pts > max_pts) max_pts = pj[s].n_pts;
   }
   pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
   bench_arg_t* args = (bench_arg_t*)malloc(sizeof(bench_arg_t) * (size_t)n_threads);
   const double t0 = now_s();
   for (int t = 0; t < n_threads; ++t) {
-    bench_arg_t a = { t, n_threads, n_streams, max_seg, max_pts, aj, ref, cur, pj, seconds, 0 };
+    bench_arg_t a = { t, n_threads, n_streams, max_seg, max_pts, aj, ref, cur, pj, seconds, 0, what, t == 0 ? lat_us : NULL, lat_cap, 0 };
     args[t] = a;
     pthread_create(&th[t], NULL, bench_worker, &args[t]);
   }
   long long total = 0;
   for (int t = 0; t < n_threads; ++t) { pthread_join(th[t], NULL); total += args[t].done; }
   if (elapsed) *elapsed = now_s() - t0;
+  if (n_lat) *n_lat = args[0].n_lat;
   free(th); free(args);
   return total;
 }

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PLSVO_HIP_LIB", os.path.join(_HERE, "libplsvo_hip.so"
 
 # every symbol include/plsvo_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "plsvo_hip_create", "plsvo_hip_destroy", "plsvo_hip_last_error", "plsvo_hip_stream", "plsvo_hip_synchronize",
+    "plsvo_hip_create", "plsvo_hip_create_on_stream", "plsvo_hip_destroy", "plsvo_hip_last_error", "plsvo_hip_stream", "plsvo_hip_synchronize",
     "plsvo_hip_config_pyramids", "plsvo_hip_upload_pyramid", "plsvo_hip_build_pyramid", "plsvo_hip_build_pyramids_dev",
     "plsvo_hip_download_level",
     "plsvo_sparse_align", "plsvo_sparse_align_batch", "plsvo_align_stage", "plsvo_align_run", "plsvo_align_fetch",
@@ -51,6 +51,7 @@ def lib():
     vp = C.c_void_p
     sig = {
         "plsvo_hip_create": (C.c_int, [C.c_int, vp, C.POINTER(ctxp)]),
+        "plsvo_hip_create_on_stream": (C.c_int, [C.c_int, vp, C.POINTER(ctxp)]),
         "plsvo_hip_destroy": (None, [ctxp]),
         "plsvo_hip_last_error": (C.c_char_p, [ctxp]),
         "plsvo_hip_stream": (vp, [ctxp]),
@@ -104,9 +105,14 @@ class Context:
     """One plsvo_ctx: a device + stream + HBM buffers.  Mirrors the C ABI one-to-one."""
 
     def __init__(self, device=0, stream=None):
+        """stream: None -> the ctx creates a private non-blocking stream; an integer hipStream_t handle -> every launch goes
+        on THAT stream, 0 included (0 is HIP's default stream, e.g. torch.cuda.current_stream().cuda_stream)."""
         self.L = lib()
         h = C.c_void_p()
-        rc = self.L.plsvo_hip_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if stream is None:
+            rc = self.L.plsvo_hip_create(int(device), None, C.byref(h))
+        else:
+            rc = self.L.plsvo_hip_create_on_stream(int(device), C.c_void_p(int(stream)), C.byref(h))
         if rc != 0:
             raise PlsvoError(rc, (self.L.plsvo_hip_last_error(None) or b"").decode())
         self.h = h

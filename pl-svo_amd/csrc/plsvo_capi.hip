@@ -3,6 +3,7 @@
 // hipEvent timing, RCCL gather.  All device work is enqueued on the ctx stream; nothing here computes
 // any part of the hot path on the CPU (there is no fallback).
 #include <hip/hip_runtime.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -146,7 +147,11 @@ static void prof_collect(plsvo_ctx* c) {
 // ---- context ---------------------------------------------------------------------------------
 extern "C" const char* plsvo_hip_version(void) { return "plsvo_hip 0.1 (gfx950)"; }
 
-extern "C" int plsvo_hip_create(int device_id, void* stream, plsvo_ctx** out) {
+static int create_ctx(int device_id, void* stream, bool use_given_stream, plsvo_ctx** out);
+extern "C" int plsvo_hip_create(int device_id, void* stream, plsvo_ctx** out) { return create_ctx(device_id, stream, stream != nullptr, out); }
+extern "C" int plsvo_hip_create_on_stream(int device_id, void* stream, plsvo_ctx** out) { return create_ctx(device_id, stream, true, out); }
+
+static int create_ctx(int device_id, void* stream, bool use_given_stream, plsvo_ctx** out) {
   if (!out) return PLSVO_E_INVALID;
   *out = nullptr;
   int n = 0;
@@ -168,7 +173,7 @@ extern "C" int plsvo_hip_create(int device_id, void* stream, plsvo_ctx** out) {
     if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && optin > 0)
       c->lds_per_block = std::max(c->lds_per_block, (size_t)optin);
   }
-  if (stream) { c->stream = reinterpret_cast<hipStream_t>(stream); c->own_stream = false; }
+  if (use_given_stream) { c->stream = reinterpret_cast<hipStream_t>(stream); c->own_stream = false; }   // NULL = HIP's default stream
   else {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
       g_create_error = hipGetErrorString(e); delete c; return PLSVO_E_HIP;
@@ -470,8 +475,12 @@ static void pick_align_config(const plsvo_ctx* c, int n_jobs, int cap, int scap,
   if (const char* s = getenv("PLSVO_ALIGN_LDS_PAD")) *lds += (size_t)std::max(0, atoi(s));   // occupancy experiments: unused LDS bytes per workgroup
 }
 
+// roctx range around the host side of an ABI call (rocprofv3 --marker-trace shows it; free when no tool is attached)
+namespace { struct RoctxRange { explicit RoctxRange(const char* name) { roctxRangePush(name); } ~RoctxRange() { roctxRangePop(); } }; }
+
 extern "C" int plsvo_align_run(plsvo_ctx* c) {
   CTX_CHECK(c);
+  RoctxRange range("sparse_img_align");
   if (!c->a_staged) return fail(c, PLSVO_E_STATE, "align_run: no staged batch");
   HIP_TRY(c, hipSetDevice(c->device));
   // one launch: the workgroup of a job resets its solver state, runs its levels and writes its pose
@@ -674,6 +683,7 @@ extern "C" int plsvo_poseopt_stage(plsvo_ctx* c, int n, const plsvo_poseopt_in* 
 
 extern "C" int plsvo_poseopt_run(plsvo_ctx* c) {
   CTX_CHECK(c);
+  RoctxRange range("pose_optimizer");
   if (!c->p_staged) return fail(c, PLSVO_E_STATE, "poseopt_run: no staged batch");
   HIP_TRY(c, hipSetDevice(c->device));
   // one wave per frame for large batches (8 frames per CU), four waves per frame when there are too few frames to fill the

@@ -1,8 +1,22 @@
 """Multi-GPU sharding of independent streams: one process per GPU, static block assignment,
 no data-path collective; the only exchange is an all-gather of the per-stream result poses.
-Backend-agnostic (torch.distributed): "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests."""
+Backend-agnostic (torch.distributed): "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+
+`timed_sharded_steps` is the control flow bench.py times -- warm-up, barrier, K steps of {local hot path, pose copy,
+all-gather}, barrier, MAX over ranks -- kept here so that the CPU suite can run it with two gloo ranks and a recorded
+result table in place of the kernels (tests/test_dist_cpu.py)."""
+import time
+
 import torch
 import torch.distributed as dist
+
+
+def world_size():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
 
 def stream_block(rank, world, streams_per_rank):
@@ -18,16 +32,69 @@ def stream_seed(global_stream_index, base_seed=1234):
     return base_seed + int(global_stream_index)
 
 
+def rank_seeds(rank, world, streams_per_rank, base_seed=1234):
+    """seeds of the streams `rank` owns: base_seed + rank * streams_per_rank + i"""
+    return [stream_seed(g, base_seed) for g in stream_block(rank, world, streams_per_rank)]
+
+
 def gather_poses(local_poses, out=None):
     """All-gather [n_local, 7] pose records -> [world * n_local, 7], rank-major.  Works un-initialised
     (single process) by returning the local tensor."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if world_size() == 1:
         if out is not None:
             out.copy_(local_poses)
             return out
         return local_poses
-    world = dist.get_world_size()
+    world = world_size()
     if out is None:
         out = torch.empty((world * local_poses.shape[0], local_poses.shape[1]), dtype=local_poses.dtype, device=local_poses.device)
     dist.all_gather_into_tensor(out, local_poses.contiguous())
     return out
+
+
+def timed_sharded_steps(step_local, copy_local_poses, local_poses, steps, warmup, device_sync=lambda: None, before_timed=lambda: None):
+    """The timed region of one benchmark run over a sharded batch of independent streams.
+
+    step_local():            enqueue one pass of the hot path over this rank's streams
+    copy_local_poses(t):     enqueue the copy of this rank's result poses into tensor t ([n_local, 7]), on the SAME stream
+                             as step_local's kernels, so that the collective that follows is ordered after them
+    local_poses:             the [n_local, 7] tensor (device of the backend: HBM for nccl, host for gloo)
+    device_sync():           wait for everything enqueued (torch.cuda.synchronize on a GPU, nothing on the CPU)
+    before_timed():          called once between the warm-up and the timed steps (bench.py switches its kernel timers on here)
+
+    One step = step_local, and with more than one rank: copy_local_poses + the all-gather of the poses (the only collective).
+    Returns (elapsed seconds of the K timed steps, MAX over ranks; the gathered [world * n_local, 7] tensor or None)."""
+    world = world_size()
+    gathered = None
+    if world > 1:
+        gathered = torch.empty((world * local_poses.shape[0], local_poses.shape[1]), dtype=local_poses.dtype, device=local_poses.device)
+
+    def step():
+        step_local()
+        if world > 1:
+            copy_local_poses(local_poses)
+            gather_poses(local_poses, out=gathered)
+
+    for _ in range(warmup):
+        step()
+    device_sync()
+    before_timed()
+    if world > 1:
+        dist.barrier()
+    device_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    device_sync()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=local_poses.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the gathered table must hold this rank's poses in this rank's block (guards the copy -> all-gather ordering)
+        r, n = rank(), local_poses.shape[0]
+        if not torch.equal(gathered[r * n:(r + 1) * n], local_poses):
+            raise RuntimeError("all-gather returned stale poses for this rank's block: the collective was not ordered after the pose copy")
+    return elapsed, gathered

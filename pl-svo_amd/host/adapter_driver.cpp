@@ -2,8 +2,14 @@
 // FrameHandlerMono::processFrame does (src/frame_handler_mono.cpp:266-274, 327-329), on frames built from a
 // binary dump written by tests/test_gpu_adapter.py.  Prints the mutated state for the test to compare with
 // the oracle.  Usage: adapter_driver <input.bin> <output.txt> [structure.bin]
+//             adapter_driver --bench K <input.bin>     per-call wall time of run() and optimizeGaussNewton() over K calls,
+//                                                      every call with a NEW current frame (so its pyramid is uploaded, as
+//                                                      in a live pipeline; the reference frame is the cached previous one)
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "plsvo/hip_adapter.hpp"
@@ -13,8 +19,12 @@ typedef plsvo::SparseImgAlignT<mini::FramePtr> SparseImgAlign;
 
 static std::vector<double> read_doubles(FILE* f, size_t n) { std::vector<double> v(n); if (n && fread(v.data(), 8, n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } return v; }
 
+static double median_of(std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; }
+
 int main(int argc, char** argv) {
-  if (argc < 3) { fprintf(stderr, "usage: %s in.bin out.txt\n", argv[0]); return 2; }
+  int bench_calls = 0;
+  if (argc >= 4 && !strcmp(argv[1], "--bench")) { bench_calls = atoi(argv[2]); argv += 2; argc -= 2; }
+  if (argc < (bench_calls ? 2 : 3)) { fprintf(stderr, "usage: %s in.bin out.txt [structure.bin] | --bench K in.bin\n", argv[0]); return 2; }
   FILE* f = fopen(argv[1], "rb");
   if (!f) { perror("open"); return 2; }
   std::vector<double> hdr = read_doubles(f, 12);
@@ -56,6 +66,56 @@ int main(int argc, char** argv) {
     L.feat3D = (i < n_dead_seg) ? nullptr : &lss[(size_t)i];   // the first n_dead_seg segments have no landmark
     ref->seg_fts_.push_back(&L);
   }
+  if (bench_calls > 0) {
+    // ---- per-call latency of the drop-in, as FrameHandlerMono::processFrame pays it (src/frame_handler_mono.cpp:266-274, 327-329) ----
+    std::vector<double> Tp = read_doubles(f, 7);
+    mini::FramePtr fr(new mini::Frame());
+    fr->cam_ = &cam;
+    std::vector<mini::Point> qpts((size_t)po_pts); std::vector<mini::PointFeat> qpfs((size_t)po_pts);
+    std::vector<double> qd = read_doubles(f, (size_t)po_pts * 7);
+    std::vector<mini::LineSeg> qls((size_t)po_seg); std::vector<mini::LineFeat> qlf((size_t)po_seg);
+    std::vector<double> qs = read_doubles(f, (size_t)po_seg * 10);
+    fclose(f);
+    for (int i = 0; i < po_pts; ++i) {
+      const double* d = &qd[(size_t)i * 7];
+      qpfs[(size_t)i].f = mini::Vec3(d[0], d[1], d[2]); qpts[(size_t)i].pos_ = mini::Vec3(d[3], d[4], d[5]); qpfs[(size_t)i].level = (int)d[6];
+      fr->pt_fts_.push_back(&qpfs[(size_t)i]);
+    }
+    for (int i = 0; i < po_seg; ++i) {
+      const double* d = &qs[(size_t)i * 10];
+      qlf[(size_t)i].line = mini::Vec3(d[0], d[1], d[2]); qls[(size_t)i].spos_ = mini::Vec3(d[3], d[4], d[5]); qls[(size_t)i].epos_ = mini::Vec3(d[6], d[7], d[8]);
+      qlf[(size_t)i].level = (int)d[9];
+      fr->seg_fts_.push_back(&qlf[(size_t)i]);
+    }
+    ref->id_ = 1;
+    std::vector<double> t_run, t_opt;
+    size_t tracked = 0;
+    for (int k = -3; k < bench_calls; ++k) {   // three untimed warm-up calls (context creation, first allocations)
+      cur->id_ = 1000 + k + 3;                 // a NEW frame identity: its pyramid is uploaded; ref stays cached
+      cur->T_f_w_ = mini::SE3(mini::Quat(Tc[3], Tc[0], Tc[1], Tc[2]), mini::Vec3(Tc[4], Tc[5], Tc[6]));
+      for (int i = 0; i < n_seg; ++i) lfs[(size_t)i].feat3D = (i < n_dead_seg) ? nullptr : &lss[(size_t)i];
+      fr->T_f_w_ = mini::SE3(mini::Quat(Tp[3], Tp[0], Tp[1], Tp[2]), mini::Vec3(Tp[4], Tp[5], Tp[6]));
+      for (int i = 0; i < po_pts; ++i) qpfs[(size_t)i].feat3D = &qpts[(size_t)i];
+      for (int i = 0; i < po_seg; ++i) qlf[(size_t)i].feat3D = &qls[(size_t)i];
+      const auto t0 = std::chrono::steady_clock::now();
+      SparseImgAlign img_align(max_level, min_level, 30, SparseImgAlign::GaussNewton, false, false);
+      tracked = img_align.run(ref, cur);
+      const auto t1 = std::chrono::steady_clock::now();
+      size_t n_pt = 0, n_ls = 0; double thresh = 0, e0 = 0, e1 = 0;
+      plsvo::pose_optimizer::optimizeGaussNewton(2.0, (size_t)10, false, fr, thresh, e0, e1, n_pt, n_ls);
+      const auto t2 = std::chrono::steady_clock::now();
+      if (k >= 0) {
+        t_run.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+        t_opt.push_back(std::chrono::duration<double, std::micro>(t2 - t1).count());
+      }
+    }
+    double m_run = 0, m_opt = 0;
+    for (double v : t_run) m_run += v;
+    for (double v : t_opt) m_opt += v;
+    printf("{\"calls\": %d, \"n_tracked\": %zu, \"run_us_mean\": %.1f, \"run_us_median\": %.1f, \"poseopt_us_mean\": %.1f, \"poseopt_us_median\": %.1f}\n",
+           bench_calls, tracked, m_run / t_run.size(), median_of(t_run), m_opt / t_opt.size(), median_of(t_opt));
+    return 0;
+  }
   FILE* o = fopen(argv[2], "w");
   // ---- step 2 of processFrame: sparse image alignment ----
   SparseImgAlign img_align(max_level, min_level, 30, SparseImgAlign::GaussNewton, false, false);
@@ -66,8 +126,10 @@ int main(int argc, char** argv) {
   fprintf(o, "alive");
   for (int i = 0; i < n_seg; ++i) fprintf(o, " %d", lfs[(size_t)i].feat3D != nullptr ? 1 : 0);
   fprintf(o, "\n");
-  mini::Mat66 I; img_align.getFisherInformation(I);
+  const mini::Mat66 I = img_align.getFisherInformation();   // by value, as include/plsvo/sparse_img_align.h:69 declares it
+  mini::Mat66 I2; img_align.getFisherInformation(I2);
   fprintf(o, "fisher00 %.17g\n", I(0, 0));
+  if (I(0, 0) != I2(0, 0) || I(5, 5) != I2(5, 5)) { fprintf(stderr, "getFisherInformation overloads disagree\n"); return 3; }
 
   // ---- step 4 of processFrame: pose optimisation on a second frame ----
   std::vector<double> Tp = read_doubles(f, 7);

@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <list>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../../include/plsvo_hip.h"
@@ -35,12 +36,31 @@
 namespace plsvo_hip_adapter {
 
 // ---- customisation points --------------------------------------------------------------------
+// true when the camera exposes radial/tangential coefficients d0()..d3() (vk::PinholeCamera does) and one of them is not
+// zero: the device projects with the UNDISTORTED pinhole model only (what app/run_pipeline.cpp:786-795 hands the VO), so a
+// distorted camera must be refused, not silently projected wrongly
+template <class Cam>
+inline auto camera_is_distorted(const Cam& c, int) -> decltype(c.d0(), c.d1(), c.d2(), c.d3(), bool()) {
+  return c.d0() != 0.0 || c.d1() != 0.0 || c.d2() != 0.0 || c.d3() != 0.0;
+}
+template <class Cam>
+inline bool camera_is_distorted(const Cam&, long) { return false; }   // no coefficients to look at: the caller vouches for it
+
 template <class Cam>
 struct camera_traits {  // default: the camera type has fx()/fy()/cx()/cy()/width()/height() (vk::PinholeCamera does)
   static plsvo_pinhole get(const Cam& c) {
     plsvo_pinhole p;
     p.fx = c.fx(); p.fy = c.fy(); p.cx = c.cx(); p.cy = c.cy(); p.width = c.width(); p.height = c.height();
     return p;
+  }
+  /// false -> the adapter refuses the camera (prints why, behaves like the reference's failure path)
+  static bool supported(const Cam& c) {
+    if (camera_is_distorted(c, 0)) {
+      std::fprintf(stderr, "[plsvo_hip] camera has non-zero distortion coefficients: only the undistorted pinhole model is implemented "
+                           "(hand the VO the undistorted camera, as app/run_pipeline.cpp does)\n");
+      return false;
+    }
+    return true;
   }
 };
 template <class Img>
@@ -79,6 +99,7 @@ struct Context {
   struct CachedFrame { const void* frame; long id; unsigned long stamp; };
   std::vector<CachedFrame> cache;
   unsigned long clock = 0;
+  unsigned long generation = 0;   // bumped whenever the pyramid slab is re-allocated: every slot index handed out before is void
   ~Context() { if (ctx) plsvo_hip_destroy(ctx); }
   static int cache_slots() { const char* e = std::getenv("PLSVO_KF_SLOTS"); const int n = e ? std::atoi(e) : 16; return n > 1 ? n : 2; }
   /// slot holding `frame`'s pyramid, or -1 on a miss; on a miss *victim gets the least recently used slot not stamped
@@ -109,9 +130,14 @@ struct Context {
       }
       width = w; height = h; levels = n_levels;
       cache.assign((size_t)n_cache, CachedFrame{nullptr, 0, 0ul});   // reconfiguring drops the slab
+      ++generation;
     }
     return true;
   }
+  /// pyramid slot of `fr` (uploaded on first sight, cached by (address, id_)); -1 on failure.  `batch_start` protects the
+  /// slots already handed out to the same batch from eviction (0 = start a new batch at the current clock).
+  template <class FrameT>
+  int slot_for(const FrameT* fr, int n_levels, unsigned long* batch_start);
 };
 inline Context& default_context() { static thread_local Context c; return c; }
 
@@ -133,6 +159,22 @@ inline bool upload_frame_pyramid(Context& c, int slot, const Frame& f, int n_lev
     return false;
   }
   return true;
+}
+
+template <class FrameT>
+int Context::slot_for(const FrameT* fr, int n_levels, unsigned long* batch_start) {
+  if (*batch_start == 0) *batch_start = clock + 1;
+  int victim = -1;
+  int slot = lookup((const void*)fr, (long)fr->id_, *batch_start, &victim);
+  if (slot >= 0) return slot;
+  if (victim < 0) {
+    std::fprintf(stderr, "[plsvo_hip] more than %d distinct frames in one batch (raise PLSVO_KF_SLOTS)\n", (int)cache.size());
+    return -1;
+  }
+  slot = 2 + victim;
+  if (!upload_frame_pyramid(*this, slot, *fr, n_levels)) { cache[(size_t)victim] = CachedFrame{nullptr, 0, 0ul}; return -1; }
+  cache[(size_t)victim] = CachedFrame{(const void*)fr, (long)fr->id_, ++clock};
+  return slot;
 }
 
 }  // namespace plsvo_hip_adapter
@@ -167,12 +209,22 @@ class SparseImgAlignT {
     }
     typedef typename std::remove_reference<decltype(*ref_frame->cam_)>::type Cam;
     plsvo_align_in in;
+    if (!camera_traits<Cam>::supported(*ref_frame->cam_)) return 0;
     in.cam = camera_traits<Cam>::get(*ref_frame->cam_);
     const int n_levels = max_level_ + 1;
     Context& c = default_context();
     if ((int)ref_frame->img_pyr_.size() < n_levels || (int)cur_frame->img_pyr_.size() < n_levels) return 0;
-    if (!c.ensure(in.cam.width, in.cam.height, n_levels)) return 0;
-    if (!upload_frame_pyramid(c, 0, *ref_frame, n_levels) || !upload_frame_pyramid(c, 1, *cur_frame, n_levels)) return 0;
+    // the slab holds every level a frame has, so that the matcher / depth filter can share the cached pyramids
+    const int slab_levels = (int)ref_frame->img_pyr_.size() > n_levels ? (int)ref_frame->img_pyr_.size() : n_levels;
+    if (!c.ensure(in.cam.width, in.cam.height, slab_levels)) return 0;
+    // pyramids: cached on the device by (frame address, id_).  The previous call's cur_frame is this call's ref_frame
+    // (src/frame_handler_mono.cpp:272-274), so in steady state only ONE pyramid crosses PCIe per frame.
+    unsigned long batch_start = 0;
+    const int ref_levels = (int)ref_frame->img_pyr_.size() < c.levels ? (int)ref_frame->img_pyr_.size() : c.levels;
+    const int cur_levels = (int)cur_frame->img_pyr_.size() < c.levels ? (int)cur_frame->img_pyr_.size() : c.levels;
+    const int ref_slot = c.slot_for(&*ref_frame, ref_levels, &batch_start);
+    const int cur_slot = ref_slot < 0 ? -1 : c.slot_for(&*cur_frame, cur_levels, &batch_start);
+    if (ref_slot < 0 || cur_slot < 0) return 0;
 
     // poses: T_cur_from_ref = cur.T_f_w * ref.T_f_w^-1 (:80); ref_pos = ref.T_f_w^-1 translation (frame.h:131)
     double Tr[7], Tc[7];
@@ -213,7 +265,7 @@ class SparseImgAlignT {
       for (int k = 0; k < 3; ++k) { pref.push_back(p[k]); qref.push_back(q[k]); }
       alive.push_back(s->feat3D != NULL ? 1 : 0);
     }
-    in.ref_slot = 0; in.cur_slot = 1;
+    in.ref_slot = ref_slot; in.cur_slot = cur_slot;
     in.max_level = max_level_; in.min_level = min_level_; in.n_iter = n_iter_; in.reserved0 = 0; in.eps = eps_;
     se3_store(T_cfr, in.T_cur_from_ref);
     in.n_pts = (int)(pt_px.size() / 2); in.n_seg = (int)len.size();
@@ -244,7 +296,16 @@ class SparseImgAlignT {
     return (size_t)out.n_tracked;                                                  // :94
   }
 
-  /// Fisher information H_/sigma_i^2 (src/sparse_img_align.cpp:97-102), row-major 6x6 into `I`
+  /// Fisher information H_/sigma_i^2 (src/sparse_img_align.cpp:97-102), returned BY VALUE like the reference's
+  /// `Matrix<double,6,6> getFisherInformation()` (include/plsvo/sparse_img_align.h:69); the matrix type is the frame's own
+  /// 6x6 type (Frame::Cov_, include/plsvo/frame.h:67)
+  typedef typename std::decay<decltype(std::declval<FramePtrT>()->Cov_)>::type Matrix66;
+  Matrix66 getFisherInformation() const {
+    Matrix66 I;
+    getFisherInformation(I);
+    return I;
+  }
+  /// the same into a caller-provided matrix of any type mat66_traits knows
   template <class Mat66>
   void getFisherInformation(Mat66& I) const {
     const double sigma_i_sq = 5e-4 * 255 * 255;
@@ -423,32 +484,32 @@ struct FrameRegistry {
   plsvo_pinhole cam;
   bool ok;
   unsigned long batch_start;
-  FrameRegistry() : ok(true), batch_start(0) {}
-  void clear() { frames.clear(); frame_T.clear(); frame_slot.clear(); ok = true; batch_start = 0; }
+  unsigned long generation;   // Context::generation when the first frame was registered
+  FrameRegistry() : ok(true), batch_start(0), generation(0) {}
+  void clear() { frames.clear(); frame_T.clear(); frame_slot.clear(); ok = true; batch_start = 0; generation = 0; }
+  /// the slots handed out are only valid while the slab they index has not been re-allocated
+  bool valid() const { return ok && (frames.empty() || generation == default_context().generation); }
   template <class FrameT>
   int index(const FrameT* fr) {
     for (size_t k = 0; k < frames.size(); ++k) if (frames[k] == (const void*)fr) return (int)k;
     Context& c = default_context();
     typedef typename std::remove_reference<decltype(*fr->cam_)>::type Cam;
+    if (!camera_traits<Cam>::supported(*fr->cam_)) ok = false;
     const plsvo_pinhole cm = camera_traits<Cam>::get(*fr->cam_);
     const int n_levels = (int)fr->img_pyr_.size();
     if (frames.empty()) cam = cm;
     if (!c.ensure(cm.width, cm.height, n_levels)) ok = false;
+    if (frames.empty()) generation = c.generation;
+    else if (generation != c.generation) {
+      // a frame with a different size or a deeper pyramid re-allocated the slab: the slots of the frames registered
+      // earlier in this batch now point at zeroed memory
+      if (ok) std::fprintf(stderr, "[plsvo_hip] frames of one batch differ in image size or pyramid depth (the slab was re-allocated): batch refused\n");
+      ok = false;
+    }
     int slot = 0;
     if (ok) {
-      if (batch_start == 0) batch_start = c.clock + 1;
-      int victim = -1;
-      slot = c.lookup((const void*)fr, (long)fr->id_, batch_start, &victim);
-      if (slot < 0) {
-        if (victim < 0) {
-          std::fprintf(stderr, "[plsvo_hip] more than %d distinct frames in one batch (raise PLSVO_KF_SLOTS)\n", (int)c.cache.size());
-          ok = false; slot = 0;
-        } else {
-          slot = 2 + victim;
-          if (!upload_frame_pyramid(c, slot, *fr, n_levels)) { ok = false; c.cache[(size_t)victim] = Context::CachedFrame{nullptr, 0, 0ul}; }
-          else c.cache[(size_t)victim] = Context::CachedFrame{(const void*)fr, (long)fr->id_, ++c.clock};
-        }
-      }
+      slot = c.slot_for(fr, n_levels < c.levels ? n_levels : c.levels, &batch_start);
+      if (slot < 0) { ok = false; slot = 0; }
     }
     frames.push_back((const void*)fr);
     double T[7];
@@ -511,7 +572,7 @@ class DirectMatcher {
     const size_t n = ref_level_.size();
     out_px_.assign(px_cur_.begin(), px_cur_.end()); out_found_.assign(n ? n : 1, 0); out_level_.assign(n ? n : 1, -1);
     if (n == 0) return true;
-    if (!reg_.ok) return false;
+    if (!reg_.valid()) return false;
     plsvo_match_in in;
     in.cam = reg_.cam; in.n_pyr_levels = n_pyr_levels_; in.align_max_iter = align_max_iter_;
     in.n_frames = (int32_t)reg_.frames.size(); in.n = (int32_t)n;
@@ -626,7 +687,7 @@ bool updateSeeds(const FrameT& frame, PointSeedList& pt_seeds, LineSeedList& seg
   }
   const size_t np = pa.size(), ns = sa.size();
   if (np + ns == 0) return true;
-  if (!reg.ok) return false;
+  if (!reg.valid()) return false;
   plsvo_seeds_in in;
   in.cam = reg.cam; in.n_pyr_levels = opt.n_pyr_levels; in.align_max_iter = opt.align_max_iter; in.max_epi_search_steps = opt.max_epi_search_steps;
   in.edgelet_filtering = opt.epi_search_edgelet_filtering ? 1 : 0; in.edgelet_max_angle = opt.epi_search_edgelet_max_angle; in.px_noise = 1.0;

@@ -82,3 +82,60 @@ def test_sharding_helpers():
     assert D.stream_seed(5) == 1239
     t = torch.arange(14, dtype=torch.float64).reshape(2, 7)
     assert torch.equal(D.gather_poses(t), t)       # un-initialised process group: identity
+
+
+def _bench_flow_worker(rank, world, port, n_local, q):
+    """bench.py's timed region (pl-svo_amd/dist.py::timed_sharded_steps) with a recorded per-stream result table in place of
+    the kernels: rank r's "hot path" looks the poses of ITS seeds up and publishes them step by step."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    import time
+    D = importlib.import_module("pl-svo_amd.dist")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seeds = D.rank_seeds(rank, world, n_local)                  # bench.py: seed0 = 1234 + rank * B
+        state = {"step": 0, "result": None}
+
+        def table(seed, step):                                      # the "recorded result" of a stream at a given step
+            return np.array([seed, step, 0.5 * seed, -seed, seed * 1e-3, step * 1e-2, 1.0], np.float64)
+
+        def step_local():
+            state["step"] += 1
+            if rank == 1:
+                time.sleep(0.02)                                    # an uneven rank: the MAX over ranks must report it
+            state["result"] = torch.tensor(np.array([table(s, state["step"]) for s in seeds]))
+
+        def copy_local_poses(t):
+            t.copy_(state["result"])                                # must happen BEFORE the all-gather of the same step
+
+        local = torch.zeros((n_local, 7), dtype=torch.float64)
+        steps, warmup = 4, 2
+        elapsed, gathered = D.timed_sharded_steps(step_local, copy_local_poses, local, steps, warmup)
+        q.put((rank, seeds, elapsed, gathered.numpy().copy(), state["step"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_bench_control_flow():
+    world, n_local = 2, 5
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_flow_worker, args=(r, world, port, n_local, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r: rest for r, *rest in (q.get(timeout=180) for _ in range(world))}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    seeds0, el0, g0, n0 = got[0]
+    seeds1, el1, g1, n1 = got[1]
+    assert seeds0 == [1234 + i for i in range(n_local)] and seeds1 == [1234 + n_local + i for i in range(n_local)]
+    assert n0 == n1 == 6                                            # 2 warm-up + 4 timed steps, nothing skipped
+    assert el0 == el1 and el0 >= 4 * 0.02                           # MAX over ranks: both report the slow rank's time
+    # the gathered table of the LAST step: rank-major, every row = (seed, step 6, ...)
+    assert np.array_equal(g0, g1) and g0.shape == (world * n_local, 7)
+    assert list(g0[:, 0]) == [1234 + i for i in range(world * n_local)]
+    assert (g0[:, 1] == 6).all()

@@ -20,20 +20,8 @@ def test_adapter_reproduces_reference_mutations(P, ob, tmp_path):
     W, H, nlev, maxl, minl, npts, nseg, ndead = 320, 240, 4, 3, 1, 60, 24, 3
     st, ref, cur, _ = Hh.make_case(ob, 777, W, H, npts, nseg, nlev, maxl, minl)
     fr = P.synth.make_poseopt_frame(778, 90, 30, W, H)
-    blob = [np.array([W, H, nlev, maxl, minl, npts, nseg, 90, 30, ndead, 0, 0], float), np.array(st.cam[:4], float),
-            st.T_ref_w, st.T_cur_w_init]
     path = tmp_path / "in.bin"
-    with open(path, "wb") as f:
-        for a in blob:
-            np.asarray(a, np.float64).tofile(f)
-        for pyr in (ref, cur):
-            for l in pyr:
-                np.ascontiguousarray(l, np.uint8).tofile(f)
-        np.hstack([st.pt_px, st.pt_f, st.pt_pos_w]).astype(np.float64).tofile(f)
-        np.hstack([st.seg_spx, st.seg_epx, st.seg_sf, st.seg_ef, st.seg_spos_w, st.seg_epos_w, st.seg_len[:, None]]).astype(np.float64).tofile(f)
-        np.asarray(fr.T_init, np.float64).tofile(f)
-        np.hstack([fr.pt_f, fr.pt_pos, fr.pt_level[:, None].astype(float)]).astype(np.float64).tofile(f)
-        np.hstack([fr.seg_line, fr.seg_spos, fr.seg_epos, fr.seg_level[:, None].astype(float)]).astype(np.float64).tofile(f)
+    P.adapter_io.write_adapter_input(path, st, ref, cur, fr, nlev, maxl, minl, n_dead_seg=ndead)
     # landmarks with observation lists for the structure-optimisation step (src/frame_handler_mono.cpp:340)
     sb = P.synth.make_structure_batch(779, 12, 9, 5)
     spath = tmp_path / "struct.bin"

@@ -1,6 +1,17 @@
-"""Turn the two PMC summaries (tools/rocpd_summary.py --counters on a FETCH_SIZE pass and a WRITE_SIZE pass) into
-profiles/hbm_traffic.json, the per-stream HBM traffic bench.py reports as roofline.traffic.
-usage: python tools/hbm_traffic.py <fetch.csv> <write.csv> <batch> <out.json> "<profiled command>" """
+"""Turn the PMC summaries (tools/rocpd_summary.py --counters on a FETCH_SIZE pass and a WRITE_SIZE pass of bench.py, plus the same
+two passes of tools/pmc_calib) into profiles/hbm_traffic.json, the per-stream memory-side traffic bench.py reports as
+roofline.traffic (labelled offline, with this file's commit tag).
+
+usage: python tools/hbm_traffic.py <fetch.csv> <write.csv> <batch> <out.json> "<profiled command>" <commit> [<calib_fetch.csv> <calib_write.csv> <calib.json>]
+
+Counters are in KiB.  MI355X_MICROARCH.md (HBM section) says FETCH_SIZE reads exactly half the bytes of a WIDE (16 B per lane)
+coalesced stream on gfx950 and calls other access widths and WRITE_SIZE uncalibrated.  The calibration kernels measure the
+three factors in this repository's own access patterns:
+  c_wide   = known bytes / FETCH_SIZE for a 16-B-per-lane streaming read   (the ref/dx/dy cache reads of align_fused_kernel)
+  c_gather = distinct 64-B blocks touched x 64 / FETCH_SIZE for the 3-rows x 2-dwords image gather of align_fused_kernel
+  c_write  = known bytes / WRITE_SIZE for a 16-B-per-lane streaming write
+and the kernel's fetches are corrected with the blend of c_wide and c_gather given by its own request mix (192 + 24 B of
+wide/dense loads against 48 B of gathered dwords per patch-iteration)."""
 import csv, json, sys
 
 
@@ -13,18 +24,41 @@ def per_launch(path, counter, kernel_substr):
     return sum(vals) / max(len(vals), 1), len(vals)
 
 
-fetch_csv, write_csv, batch, out, cmd = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
-res = {"note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) on `{cmd}`, MI355X. Counters are in KiB. "
-               "gfx950 correction from MI355X_MICROARCH.md (HBM section): FETCH_SIZE reads half the bytes of wide coalesced reads -> doubled; "
-               "WRITE_SIZE uncalibrated, taken as is.", "batch": batch}
+fetch_csv, write_csv, batch, out, cmd, commit = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
+res = {"note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) on `{cmd}`, MI355X. Counters are in KiB.",
+       "batch": batch, "measured_at": commit}
+c_wide, c_gather, c_write, calib = 2.0, 2.0, 1.0, None
+if len(sys.argv) > 9:
+    cf, cw, cj = sys.argv[7], sys.argv[8], json.load(open(sys.argv[9]))
+    f_stream, _ = per_launch(cf, "FETCH_SIZE", "calib_stream_read")
+    f_gather, _ = per_launch(cf, "FETCH_SIZE", "calib_gather_dword")
+    w_stream, _ = per_launch(cw, "WRITE_SIZE", "calib_stream_write")
+    calib = {"known": cj, "FETCH_SIZE_KiB_stream_read": f_stream, "FETCH_SIZE_KiB_gather": f_gather, "WRITE_SIZE_KiB_stream_write": w_stream}
+    if f_stream > 0:
+        c_wide = cj["stream_read_bytes"] / (f_stream * 1024.0)
+    if f_gather > 0:
+        c_gather = cj["gather_distinct_64B_blocks_bytes"] / (f_gather * 1024.0)
+        calib["gather_factor_vs_32B_blocks"] = cj["gather_distinct_32B_blocks_bytes"] / (f_gather * 1024.0)
+        calib["gather_factor_vs_128B_blocks"] = cj["gather_distinct_128B_blocks_bytes"] / (f_gather * 1024.0)
+    if w_stream > 0:
+        c_write = cj["stream_write_bytes"] / (w_stream * 1024.0)
+    calib.update({"c_wide": c_wide, "c_gather_64B": c_gather, "c_write": c_write})
+    res["calibration"] = calib
+else:
+    res["note"] += " No calibration pass given: FETCH_SIZE doubled (the guide's wide-read figure) for every fetch, WRITE_SIZE as is."
+w_wide = (192.0 + 24.0) / (192.0 + 24.0 + 48.0)     # request mix of align_fused_kernel per patch-iteration (bench.py OWN_BYTES_PER_PATCH_ITER)
+c_fetch = w_wide * c_wide + (1.0 - w_wide) * c_gather
+res["fetch_correction_used"] = c_fetch
+res["write_correction_used"] = c_write
 for kern, key in (("align_fused", "align_fused_kernel"), ("pose_opt", "pose_opt_kernel")):
     f, n = per_launch(fetch_csv, "FETCH_SIZE", kern)
     w, _ = per_launch(write_csv, "WRITE_SIZE", kern)
     res[f"{key}_launches_measured"] = n
     res[f"{key}_FETCH_SIZE_KiB_per_launch"] = f
     res[f"{key}_WRITE_SIZE_KiB_per_launch"] = w
-    res[f"{key}_bytes_per_launch"] = (2.0 * f + w) * 1024.0
-    res[f"{key}_bytes_per_stream"] = (2.0 * f + w) * 1024.0 / batch
+    res[f"{key}_bytes_per_launch"] = (c_fetch * f + c_write * w) * 1024.0
+    res[f"{key}_bytes_per_stream"] = (c_fetch * f + c_write * w) * 1024.0 / batch
+    res[f"{key}_bytes_per_stream_uncorrected"] = (f + w) * 1024.0 / batch
 res["launches_measured"] = res["align_fused_kernel_launches_measured"]
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))

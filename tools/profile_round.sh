@@ -1,8 +1,10 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): GPU test suite, smoke, the default bench line, a rocprofv3 kernel trace of the
-# bench command and the two PMC passes (FETCH_SIZE, WRITE_SIZE; --kernel-trace only, as the pool requires).
-# usage: tools/profile_round.sh <tag>      -> everything lands in gpurun_out/<tag>/
-TAG=${1:-r01}
+# Runs on the GPU box (through gpurun): GPU test suite, smoke, the default bench line (+ configs 3 and 5), a rocprofv3 kernel trace of
+# the default bench command (same run as the JSON line it is stored with), the FETCH_SIZE / WRITE_SIZE PMC passes (--kernel-trace
+# only, as the pool requires) on the bench command AND on the calibration kernels (tools/pmc_calib), reduced to hbm_traffic.json.
+# usage: tools/profile_round.sh <tag> <commit>      -> everything lands in gpurun_out/<tag>/
+TAG=${1:-r02}
+COMMIT=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -10,19 +12,27 @@ export TMPDIR=/tmp
 cd $R
 timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
-timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; cat $O/bench_default.json
-timeout 300 python tools/bench_match.py > $O/match_microbench.json 2> $O/match_microbench.err; cat $O/match_microbench.json
-timeout 300 python tools/bench_structopt.py > $O/structopt_microbench.json 2> /dev/null
-timeout 300 python tools/bench_seeds.py > $O/seeds_microbench.json 2> $O/seeds_microbench.err; cat $O/seeds_microbench.json
-CMD="python $R/bench.py --batch 32768 --steps 3 --warmup 1 --no-cpu-baseline"
+timeout 900 python bench.py --config 3 > $O/bench_config3.json 2> $O/bench_config3.err; cut -c1-300 $O/bench_config3.json
+timeout 600 python bench.py --config 5 > $O/bench_config5.json 2> $O/bench_config5.err; cut -c1-300 $O/bench_config5.json
+# default bench line + kernel trace of that same run
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -- $CMD > $O/kt.log 2>&1
+rm -rf /tmp/kt
+timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt -- python $R/bench.py > $O/bench_stdout.txt 2> $O/bench_default.err
+grep '^{"metric"' $O/bench_stdout.txt | tail -1 > $O/bench_default.json
+cut -c1-400 $O/bench_default.json
 DB=$(find /tmp/kt -name "*results.db" | head -1)
-python $R/tools/rocpd_summary.py "$DB" $O/kernel_trace_stats.csv "python bench.py --batch 32768 --steps 3 --warmup 1 --no-cpu-baseline (MI355X)"
+python $R/tools/rocpd_summary.py "$DB" $O/kernel_trace_stats.csv "python bench.py (default: 32768 streams, 20 steps + 3 warm-up; MI355X); same run as bench_default.json"
+CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency"
 for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$C /tmp/cal_$C
   timeout 600 rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_$C -- $CMD > $O/pmc_$C.log 2>&1
   DB=$(find /tmp/pmc_$C -name "*results.db" | head -1)
-  python $R/tools/rocpd_summary.py --counters "$DB" $O/pmc_$C.csv "python bench.py --batch 32768 --steps 3 --warmup 1 --no-cpu-baseline (MI355X)"
+  python $R/tools/rocpd_summary.py --counters "$DB" $O/pmc_$C.csv "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency (MI355X)"
+  timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/cal_$C -- $R/tools/pmc_calib > $O/calib_$C.log 2>&1
+  DB=$(find /tmp/cal_$C -name "*results.db" | head -1)
+  python $R/tools/rocpd_summary.py --counters "$DB" $O/calib_$C.csv "tools/pmc_calib (MI355X)" "%calib_%"
 done
-python $R/tools/hbm_traffic.py $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv 32768 $O/hbm_traffic.json "python bench.py --batch 32768 --steps 3 --warmup 1 --no-cpu-baseline"
+grep "^{" $O/calib_FETCH_SIZE.log | tail -1 > $O/calib_known_bytes.json
+python $R/tools/hbm_traffic.py $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv 32768 $O/hbm_traffic.json "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency" $COMMIT \
+       $O/calib_FETCH_SIZE.csv $O/calib_WRITE_SIZE.csv $O/calib_known_bytes.json > $O/hbm_traffic.log 2>&1; tail -c 600 $O/hbm_traffic.log
 head -8 $O/kernel_trace_stats.csv

@@ -25,13 +25,15 @@ def main(db, out, cmd):
 
 
 
-def counters(db, out, cmd):
-    """per-kernel PMC counter totals (rocprofv3 --pmc ... pass) for the plsvo kernels"""
+def counters(db, out, cmd, like=None):
+    """per-kernel PMC counter totals (rocprofv3 --pmc ... pass) for the plsvo kernels (or kernels matching `like`)"""
     c = sqlite3.connect(db)
     lines = [f"# rocprofv3 --kernel-trace --pmc <counter> -- {cmd}", "# view counters_collection; one row per dispatch",
              "kernel,counter,dispatch_index,grid,workgroup,value"]
+    where = ("kernel_name like '%plsvo%align_fused%' or kernel_name like '%plsvo%pose_opt%'" if not like
+             else " or ".join(f"kernel_name like '{l}'" for l in like.split(",")))
     q = ("select kernel_name, counter_name, dispatch_id, grid_size, workgroup_size, value from counters_collection "
-         "where kernel_name like '%plsvo%align_fused%' or kernel_name like '%plsvo%pose_opt%' order by dispatch_id")
+         f"where {where} order by dispatch_id")
     for r in c.execute(q):
         lines.append(f"\"{r[0]}\",{r[1]},{r[2]},{r[3]},{r[4]},{r[5]}")
     open(out, "w").write("\n".join(lines) + "\n")
@@ -39,6 +41,6 @@ def counters(db, out, cmd):
 
 if __name__ == "__main__":
     if sys.argv[1] == "--counters":
-        counters(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
+        counters(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "", sys.argv[5] if len(sys.argv) > 5 else None)
     else:
         main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")
