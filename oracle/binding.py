@@ -17,7 +17,7 @@ if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 abi = importlib.import_module("pl-svo_amd.abi")
 
-_LIB_PATH = os.path.join(_HERE, "libplsvo_oracle.so")
+_LIB_PATH = os.environ.get("PLSVO_ORACLE_LIB") or os.path.join(_HERE, "libplsvo_oracle.so")   # override: the sanitizer build (make -C oracle sanitize)
 
 
 class OraclePyr(C.Structure):

@@ -126,7 +126,7 @@ def _on_plane(n, d, rays):
 
 
 def make_align_stream(seed, W=640, H=480, n_pts=200, n_seg=80, max_level=3, motion_scale=0.5,
-                      tex_lam=(16.0, 320.0)):
+                      tex_lam=(16.0, 320.0), seg_len_range=None):
     rng = np.random.default_rng(seed)
     fx = fy = 0.65 * W
     cam = (fx, fy, W / 2.0, H / 2.0, W, H)
@@ -159,7 +159,7 @@ def make_align_stream(seed, W=640, H=480, n_pts=200, n_seg=80, max_level=3, moti
 
     margin = 4.0 * (1 << max_level)
     pt_px = np.stack([rng.uniform(margin, W - margin, n_pts), rng.uniform(margin, H - margin, n_pts)], axis=1)
-    lmin, lmax = 0.15 * W * H / (W + H), 0.35 * W
+    lmin, lmax = (0.15 * W * H / (W + H), 0.35 * W) if seg_len_range is None else seg_len_range   # SURVEY.md 8(d) unless overridden
     spx = np.zeros((n_seg, 2))
     epx = np.zeros((n_seg, 2))
     k = 0

@@ -24,14 +24,50 @@ def frame_pose(T_cur_from_ref, st):
     return synth.se3_mul(np.asarray(T_cur_from_ref, float), st.T_ref_w)
 
 
-def make_case(ob, seed, W, H, n_pts, n_seg, n_levels, max_level, min_level, n_iter=30, motion_scale=0.5):
+def make_case(ob, seed, W, H, n_pts, n_seg, n_levels, max_level, min_level, n_iter=30, motion_scale=0.5, seg_len_range=None):
     """One synthetic alignment case: stream, pyramids (built by the oracle's half-sampler), job."""
-    st = synth.make_align_stream(seed, W, H, n_pts, n_seg, max_level=max_level, motion_scale=motion_scale)
+    st = synth.make_align_stream(seed, W, H, n_pts, n_seg, max_level=max_level, motion_scale=motion_scale, seg_len_range=seg_len_range)
     imgs = synth.render_streams([st]).numpy()
     ref = ob.build_pyramid(imgs[0, 0], n_levels)
     cur = ob.build_pyramid(imgs[0, 1], n_levels)
     job = P.align_job_from_stream(st, max_level, min_level, n_iter=n_iter)
     return st, ref, cur, job
+
+
+def common_prefix(log_ref, log_dev):
+    """number of leading trace records in which both paths evaluate the same (level, iteration) and take the same decision"""
+    n = 0
+    for a, b in zip(log_ref, log_dev):
+        if (a["level"], a["iter"]) != (b["level"], b["iter"]):
+            break
+        n += 1
+        if a["accepted"] != b["accepted"]:
+            break
+    return n
+
+
+def same_path(log_ref, log_dev):
+    """True when the two Gauss-Newton paths visit the same iterations with the same accept / roll-back decisions"""
+    return len(log_ref) == len(log_dev) and all((a["level"], a["iter"], a["accepted"]) == (b["level"], b["iter"], b["accepted"])
+                                                for a, b in zip(log_ref, log_dev))
+
+
+def se3_matrix4(T):
+    """4x4 homogeneous matrix of a (qx, qy, qz, qw, tx, ty, tz) pose"""
+    M = np.eye(4)
+    M[:3, :3] = synth.quat_to_R(np.asarray(T, float)[:4])
+    M[:3, 3] = np.asarray(T, float)[4:]
+    return M
+
+
+def hat6(u):
+    """4x4 twist matrix of a tangent vector (upsilon, omega), Sophus ordering"""
+    u = np.asarray(u, float)
+    w = u[3:]
+    M = np.zeros((4, 4))
+    M[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]
+    M[:3, 3] = u[:3]
+    return M
 
 
 def rel(a, b):

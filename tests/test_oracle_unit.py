@@ -148,3 +148,72 @@ def test_cpu_baseline_harness_runs_the_two_hot_functions_on_threads(P, ob):
     d1, t1 = ob.bench([c[3] for c in cases], [c[1] for c in cases], [c[2] for c in cases], pj, 1, 0.3)
     d2, t2 = ob.bench([c[3] for c in cases], [c[1] for c in cases], [c[2] for c in cases], pj, 2, 0.3)
     assert d1 > 0 and d2 > 0 and 0.25 < t1 < 30.0 and 0.25 < t2 < 30.0
+
+
+# ---- independent pins of the restated third-party pieces (nothing below comes from this repository's own code) ----
+
+def _hat6(u):
+    """4x4 twist matrix of a tangent vector (upsilon, omega), Sophus ordering"""
+    w = u[3:]
+    M = np.zeros((4, 4))
+    M[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]
+    M[:3, 3] = u[:3]
+    return M
+
+
+def test_se3_exp_against_scipy_expm(ob):
+    """Sophus::SE3::exp == matrix exponential of the 4x4 twist (scipy.linalg.expm), from GN-update-sized to large angles"""
+    from scipy.linalg import expm
+    rng = np.random.default_rng(11)
+    for scale in (1e-9, 1e-6, 1e-3, 0.05, 0.5, 2.5):
+        for _ in range(10):
+            u = rng.normal(0, scale, 6)
+            R, t = ob.se3_matrix(ob.se3_exp(u))
+            E = expm(_hat6(u))
+            tol = 5e-15 if scale <= 0.5 else 5e-13      # expm's own Pade error grows with the norm of the twist
+            assert np.allclose(R, E[:3, :3], atol=tol, rtol=0), scale
+            assert np.allclose(t, E[:3, 3], atol=tol, rtol=0), scale
+
+
+def test_se3_mul_inv_against_4x4_matrices(ob):
+    rng = np.random.default_rng(12)
+    for _ in range(20):
+        A, B = ob.se3_exp(rng.normal(0, 0.7, 6)), ob.se3_exp(rng.normal(0, 0.7, 6))
+        def M(T):
+            R, t = ob.se3_matrix(T)
+            X = np.eye(4); X[:3, :3] = R; X[:3, 3] = t
+            return X
+        assert np.allclose(M(ob.se3_mul(A, B)), M(A) @ M(B), atol=1e-14)
+        assert np.allclose(M(ob.se3_inv(A)), np.linalg.inv(M(A)), atol=1e-14)
+
+
+def test_ldlt_against_scipy_ldl_pivot_order_and_solution(ob):
+    """Eigen's LDLT pivots on the largest remaining |diagonal|; scipy.linalg.ldl (LAPACK sytrf, Bunch-Kaufman) is a different
+    pivoting of the same factorisation: both must reproduce H and solve H x = b to the conditioning of H."""
+    from scipy.linalg import ldl, solve
+    rng = np.random.default_rng(13)
+    for cond_pow in (0, 3, 6, 9):
+        A = rng.normal(0, 1, (40, 6)) * np.logspace(0, -cond_pow / 2.0, 6)
+        H = A.T @ A
+        b = H @ rng.normal(0, 1, 6)
+        L, Dm, perm = ldl(H)
+        assert np.allclose(L @ Dm @ L.T, H, rtol=1e-12, atol=1e-14 * np.abs(H).max())
+        x_ref = solve(H, b, assume_a="sym")
+        x = ob.ldlt_solve6(H, b)
+        c = np.linalg.cond(H)
+        assert np.linalg.norm(x - x_ref) <= 50 * c * 2.2e-16 * np.linalg.norm(x_ref) + 1e-300, cond_pow
+        assert np.linalg.norm(H @ x - b) <= 1e-12 * np.linalg.norm(b)
+
+
+def test_tukey_and_mad_closed_forms(ob):
+    """vk::robust_cost: Tukey weight (1 - x^2/b^2)^2 inside b = 4.6851, 0 outside (float arithmetic); MAD scale = 1.48 * upper median"""
+    b = np.float32(4.6851)
+    for x in (0.0, 0.1, 1.0, 2.5, 4.0, 4.68, 4.69, 10.0):
+        xf = np.float32(x)
+        expect = float((np.float32(1.0) - xf * xf / (b * b)) ** 2) if xf * xf <= b * b else 0.0
+        assert ob.tukey(x) == pytest.approx(expect, rel=2e-7, abs=1e-12)
+    rng = np.random.default_rng(14)
+    for n in (1, 2, 5, 8, 101):
+        v = np.abs(rng.normal(0, 1, n)).astype(np.float32)
+        assert ob.mad_scale(v) == pytest.approx(1.48 * float(np.sort(v)[n // 2]), rel=1e-6)
+        assert ob.median_f64(v.astype(np.float64)) == float(np.sort(v.astype(np.float64))[n // 2])
