@@ -300,25 +300,44 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       for (int pass = long_lines ? 0 : 1; pass < 2; ++pass) {
         const bool write_abs = !long_lines || pass == 0;
         const bool accumulate = pass == 1;
+        // what a lane pair needs of a slot before the pose comes in: table entry, 3-D point, cached reference patch rows 2h, 2h+1.
+        // The loads of round r+1 are issued right after the pixel arithmetic of round r (software pipelining: their latency
+        // overlaps the line weights, the 6x6 expansion and the next projection; the registers are free at that point)
+        struct SlotFetch { int2 meta; bool cand; double X, Y, Z; float4 vr0, vx0, vy0, vr1, vx1, vy1; };
+        auto fetch_slot = [&](int pb_) -> SlotFetch {
+          SlotFetch f;
+          const int p_ = pb_ + pair;
+          f.meta = make_int2(SLOT_HOLE, 0);
+          if (p_ < n_slots) f.meta = s_meta[p_];
+          f.cand = f.meta.x != SLOT_HOLE;
+          if (f.cand && f.meta.x < 0 && s_dead[-1 - f.meta.x]) f.cand = false;   // line culled at an earlier iteration of this level
+          f.X = 0.0; f.Y = 0.0; f.Z = 1.0;
+          f.vr0 = make_float4(0.f, 0.f, 0.f, 0.f); f.vx0 = f.vr0; f.vy0 = f.vr0; f.vr1 = f.vr0; f.vx1 = f.vr0; f.vy1 = f.vr0;
+          if (f.cand) {
+            f.X = pxyz[3 * p_]; f.Y = pxyz[3 * p_ + 1]; f.Z = pxyz[3 * p_ + 2];
+            const size_t q = (pbase + p_) * 4 + 2 * half;
+            f.vr0 = reinterpret_cast<const float4*>(b.cache_ref)[q]; f.vr1 = reinterpret_cast<const float4*>(b.cache_ref)[q + 1];
+            f.vx0 = reinterpret_cast<const float4*>(b.cache_dx)[q];  f.vx1 = reinterpret_cast<const float4*>(b.cache_dx)[q + 1];
+            f.vy0 = reinterpret_cast<const float4*>(b.cache_dy)[q];  f.vy1 = reinterpret_cast<const float4*>(b.cache_dy)[q + 1];
+          }
+          return f;
+        };
+#ifdef PLSVO_PIPELINE
+        SlotFetch nxt = fetch_slot(0);
+#endif
         for (int pb = 0; pb < n_slots; pb += T / 2) {
           const int p = pb + pair;
-          int2 meta = make_int2(SLOT_HOLE, 0);
-          if (p < n_slots) meta = s_meta[p];
+#ifdef PLSVO_PIPELINE
+          const SlotFetch cur = nxt;
+#else
+          const SlotFetch cur = fetch_slot(pb);
+#endif
+          const int2 meta = cur.meta;
           const bool hole = meta.x == SLOT_HOLE;
           const bool is_line = !hole && meta.x < 0;
-          bool cand = !hole;
-          if (is_line && s_dead[-1 - meta.x]) cand = false;   // line culled at an earlier iteration of this level
-
-          // -- loads that do not depend on the pose: 3-D point, cached reference patch rows 2h, 2h+1
-          double X = 0.0, Y = 0.0, Z = 1.0;
-          float4 vr0 = make_float4(0.f, 0.f, 0.f, 0.f), vx0 = vr0, vy0 = vr0, vr1 = vr0, vx1 = vr0, vy1 = vr0;
-          if (cand) {
-            X = pxyz[3 * p]; Y = pxyz[3 * p + 1]; Z = pxyz[3 * p + 2];
-            const size_t q = (pbase + p) * 4 + 2 * half;
-            vr0 = reinterpret_cast<const float4*>(b.cache_ref)[q]; vr1 = reinterpret_cast<const float4*>(b.cache_ref)[q + 1];
-            vx0 = reinterpret_cast<const float4*>(b.cache_dx)[q];  vx1 = reinterpret_cast<const float4*>(b.cache_dx)[q + 1];
-            vy0 = reinterpret_cast<const float4*>(b.cache_dy)[q];  vy1 = reinterpret_cast<const float4*>(b.cache_dy)[q + 1];
-          }
+          const bool cand = cur.cand;
+          const double X = cur.X, Y = cur.Y, Z = cur.Z;
+          const float4 vr0 = cur.vr0, vx0 = cur.vx0, vy0 = cur.vy0, vr1 = cur.vr1, vx1 = cur.vx1, vy1 = cur.vy1;
           // -- warp the 3-D point, project (:422-431, :583-594): lane 0 of the pair computes u, lane 1 computes v
           const double c_cam = Ra * X + Rb * Y + Rc * Z + ta;
           const double z_cam = Rz0 * X + Rz1 * Y + Rz2 * Z + tz;
@@ -390,6 +409,9 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           sA += dpp_mov_f64<DPP_QUAD_XOR1>(sA); sB += dpp_mov_f64<DPP_QUAD_XOR1>(sB); sC += dpp_mov_f64<DPP_QUAD_XOR1>(sC);
           sD += dpp_mov_f64<DPP_QUAD_XOR1>(sD); sE += dpp_mov_f64<DPP_QUAD_XOR1>(sE); sChi += dpp_mov_f64<DPP_QUAD_XOR1>(sChi);
           sAbs += dpp_mov_f32<DPP_QUAD_XOR1>(sAbs);
+#ifdef PLSVO_PIPELINE
+          nxt = fetch_slot(pb + T / 2);     // (slots beyond the table come back as holes: no loads)
+#endif
 
           // -- weights: points 1; a line's samples share w / mean|res| (H) and w (Jres), :640-688
           double wh = 0.0, wj = 0.0;

@@ -5,13 +5,17 @@ roofline.traffic (labelled offline, with this file's commit tag).
 usage: python tools/hbm_traffic.py <fetch.csv> <write.csv> <batch> <out.json> "<profiled command>" <commit> [<calib_fetch.csv> <calib_write.csv> <calib.json>]
 
 Counters are in KiB.  MI355X_MICROARCH.md (HBM section) says FETCH_SIZE reads exactly half the bytes of a WIDE (16 B per lane)
-coalesced stream on gfx950 and calls other access widths and WRITE_SIZE uncalibrated.  The calibration kernels measure the
-three factors in this repository's own access patterns:
+coalesced stream on gfx950 and calls other access widths and WRITE_SIZE uncalibrated.  The calibration kernels
+(tools/pmc_calib.hip) measure the factors in this repository's own access patterns:
   c_wide   = known bytes / FETCH_SIZE for a 16-B-per-lane streaming read   (the ref/dx/dy cache reads of align_fused_kernel)
-  c_gather = distinct 64-B blocks touched x 64 / FETCH_SIZE for the 3-rows x 2-dwords image gather of align_fused_kernel
   c_write  = known bytes / WRITE_SIZE for a 16-B-per-lane streaming write
-and the kernel's fetches are corrected with the blend of c_wide and c_gather given by its own request mix (192 + 24 B of
-wide/dense loads against 48 B of gathered dwords per patch-iteration)."""
+  gather   : FETCH_SIZE against the DISTINCT 32 / 64 / 128-byte blocks the 3-rows x 2-dwords image gather touches (one
+             workgroup per image, as in align_fused_kernel).  Measured: the counter is NOT below the distinct-block bytes for
+             this pattern (it reads ~1.6x the distinct 128-B lines), so the gathered share of the fetches gets no upward
+             correction (factor 1); only the wide share is doubled.
+Three figures are written per kernel: uncorrected (FETCH + WRITE), upper bound (2 x FETCH + WRITE: every fetch wide) and the
+estimate bench.py reports, c_fetch x FETCH + c_write x WRITE with c_fetch = w_wide x c_wide + (1 - w_wide) x 1, where w_wide is the
+wide share of the kernel's own requests (192 + 24 B of dense 16-B loads against 48 B of gathered dwords per patch-iteration)."""
 import csv, json, sys
 
 
@@ -27,7 +31,7 @@ def per_launch(path, counter, kernel_substr):
 fetch_csv, write_csv, batch, out, cmd, commit = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
 res = {"note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) on `{cmd}`, MI355X. Counters are in KiB.",
        "batch": batch, "measured_at": commit}
-c_wide, c_gather, c_write, calib = 2.0, 2.0, 1.0, None
+c_wide, c_gather, c_write, calib = 2.0, 1.0, 1.0, None
 if len(sys.argv) > 9:
     cf, cw, cj = sys.argv[7], sys.argv[8], json.load(open(sys.argv[9]))
     f_stream, _ = per_launch(cf, "FETCH_SIZE", "calib_stream_read")
@@ -36,13 +40,13 @@ if len(sys.argv) > 9:
     calib = {"known": cj, "FETCH_SIZE_KiB_stream_read": f_stream, "FETCH_SIZE_KiB_gather": f_gather, "WRITE_SIZE_KiB_stream_write": w_stream}
     if f_stream > 0:
         c_wide = cj["stream_read_bytes"] / (f_stream * 1024.0)
+    c_gather = 1.0
     if f_gather > 0:
-        c_gather = cj["gather_distinct_64B_blocks_bytes"] / (f_gather * 1024.0)
-        calib["gather_factor_vs_32B_blocks"] = cj["gather_distinct_32B_blocks_bytes"] / (f_gather * 1024.0)
-        calib["gather_factor_vs_128B_blocks"] = cj["gather_distinct_128B_blocks_bytes"] / (f_gather * 1024.0)
+        for g in (32, 64, 128):
+            calib[f"gather_distinct_{g}B_block_bytes_over_FETCH_SIZE"] = cj[f"gather_distinct_{g}B_blocks_bytes"] / (f_gather * 1024.0)
     if w_stream > 0:
         c_write = cj["stream_write_bytes"] / (w_stream * 1024.0)
-    calib.update({"c_wide": c_wide, "c_gather_64B": c_gather, "c_write": c_write})
+    calib.update({"c_wide": c_wide, "c_gather_used": c_gather, "c_write": c_write})
     res["calibration"] = calib
 else:
     res["note"] += " No calibration pass given: FETCH_SIZE doubled (the guide's wide-read figure) for every fetch, WRITE_SIZE as is."
@@ -59,6 +63,7 @@ for kern, key in (("align_fused", "align_fused_kernel"), ("pose_opt", "pose_opt_
     res[f"{key}_bytes_per_launch"] = (c_fetch * f + c_write * w) * 1024.0
     res[f"{key}_bytes_per_stream"] = (c_fetch * f + c_write * w) * 1024.0 / batch
     res[f"{key}_bytes_per_stream_uncorrected"] = (f + w) * 1024.0 / batch
+    res[f"{key}_bytes_per_stream_upper_bound"] = (2.0 * f + c_write * w) * 1024.0 / batch
 res["launches_measured"] = res["align_fused_kernel_launches_measured"]
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))

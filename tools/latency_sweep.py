@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--pyr", type=int, default=4)
     ap.add_argument("--max-level", type=int, default=3)
     ap.add_argument("--min-level", type=int, default=1)
+    ap.add_argument("--same-images", action="store_true", help="experiment: every job reads pyramid slots 0/1 (image gathers always cache-hot)")
     args = ap.parse_args()
     import torch
     P = importlib.import_module("pl-svo_amd")
@@ -44,7 +45,8 @@ def main():
             imgs = P.synth.render_streams(sub, device=dev)
             ctx.build_pyramids_dev(2 * c0, 2 * len(sub), imgs.data_ptr(), W, W * H, 0)
             ctx.synchronize()
-        jobs = [P.align_job_from_stream(s, args.max_level, args.min_level, ref_slot=2 * i, cur_slot=2 * i + 1) for i, s in enumerate(streams)]
+        jobs = [P.align_job_from_stream(s, args.max_level, args.min_level, ref_slot=0 if args.same_images else 2 * i,
+                                        cur_slot=1 if args.same_images else 2 * i + 1) for i, s in enumerate(streams)]
         pjobs = [P.poseopt_job_from_frame(P.synth.make_poseopt_frame(1234 + i, args.pts, args.segs, W, H)) for i in range(B)]
         ctx.align_stage(jobs)
         ctx.poseopt_stage(pjobs)

@@ -2,8 +2,10 @@
 // (MI355X_MICROARCH.md, HBM section: "calibrate on a known byte count in your own access pattern").
 //   calib_stream_read   wide coalesced streaming read, 16 B per lane (what the ref/dx/dy cache reads of align_fused_kernel look like)
 //   calib_gather_dword  the current-image gather of align_fused_kernel: per lane 3 image rows x 2 aligned dwords at a pseudo-random
-//                       position of a pseudo-random 320x240 level image; the host replays the positions and counts the DISTINCT
-//                       32 / 64 / 128-byte blocks touched, so the counter can be compared with each granularity
+//                       position of a 320x240 level image.  As in the real kernel every WORKGROUP owns its images (one frame =
+//                       one workgroup = one XCD's L2: no line is fetched by two L2s), 1024 lanes per image, 8 images per workgroup
+//                       one after the other; the host replays the positions and counts the DISTINCT 32 / 64 / 128-byte blocks
+//                       touched per image, so the counter can be compared with each granularity
 //   calib_stream_write  wide coalesced streaming write, 16 B per lane
 // All three sweep buffers far larger than the 256 MB Infinity Cache, so memory-side counters see the traffic.
 // Build: hipcc -O3 --offload-arch=gfx950 tools/pmc_calib.hip -o tools/pmc_calib      Run under: rocprofv3 --kernel-trace --pmc FETCH_SIZE -- tools/pmc_calib
@@ -21,10 +23,9 @@ __host__ __device__ inline uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7fe
 constexpr int IMG_W = 320, IMG_H = 240;                 // pyramid level 1 of a 640x480 frame
 constexpr size_t IMG_BYTES = (size_t)IMG_W * IMG_H;     // rows tight, as in the pyramid slab
 
-__host__ __device__ inline size_t gather_offset(uint32_t lane_id, uint32_t n_images) {
-  const uint32_t h = mix32(lane_id * 2654435761u + 12345u);
-  const uint32_t img = h % n_images;
-  const uint32_t h2 = mix32(h + 0x9e3779b9u);
+constexpr uint32_t LANES_PER_IMAGE = 1024, IMAGES_PER_BLOCK = 8;   // ~500 patches x 2 lanes of one frame at level 1
+__host__ __device__ inline size_t gather_offset(uint32_t img, uint32_t lane_in_image) {
+  const uint32_t h2 = mix32(mix32(img * 2654435761u + 12345u) + lane_in_image * 0x9e3779b9u);
   const uint32_t x = 2 + h2 % (IMG_W - 12), y = 2 + (h2 >> 12) % (IMG_H - 8);
   return (size_t)img * IMG_BYTES + (size_t)y * IMG_W + x;
 }
@@ -38,15 +39,19 @@ __global__ void calib_stream_read(const float4* src, size_t n4, float* sink) {
   if (acc == 1234.5678f) *sink = acc;   // never true for the fill pattern: keeps the loads alive
 }
 
-__global__ void calib_gather_dword(const uint8_t* img, uint32_t n_lanes, uint32_t n_images, uint32_t* sink) {
-  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= n_lanes) return;
-  const size_t off = gather_offset(id, n_images);
+__global__ void calib_gather_dword(const uint8_t* img, uint32_t n_images, uint32_t* sink) {
   uint32_t acc = 0;
+  for (uint32_t k = 0; k < IMAGES_PER_BLOCK; ++k) {
+    const uint32_t image = blockIdx.x * IMAGES_PER_BLOCK + k;
+    if (image >= n_images) break;
+    for (uint32_t l = threadIdx.x; l < LANES_PER_IMAGE; l += blockDim.x) {
+      const size_t off = gather_offset(image, l);
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const size_t a = (off + (size_t)r * IMG_W) & ~(size_t)3;
-    acc += *reinterpret_cast<const uint32_t*>(img + a) + *reinterpret_cast<const uint32_t*>(img + a + 4);
+      for (int r = 0; r < 3; ++r) {
+        const size_t a = (off + (size_t)r * IMG_W) & ~(size_t)3;
+        acc += *reinterpret_cast<const uint32_t*>(img + a) + *reinterpret_cast<const uint32_t*>(img + a + 4);
+      }
+    }
   }
   if (acc == 0xdeadbeefu) *sink = acc;
 }
@@ -70,7 +75,7 @@ static size_t distinct_blocks(const std::vector<size_t>& addrs, size_t total_byt
 int main() {
   const size_t stream_bytes = (size_t)2 << 30;             // 2 GiB streamed
   const uint32_t n_images = 16384;                        // 16384 x 75 KB = 1.2 GB of level images
-  const uint32_t n_lanes = 16u << 20;                     // 16 M gather lanes
+  const uint32_t n_lanes = n_images * LANES_PER_IMAGE;    // 16 M gather lanes
   const size_t img_bytes = (size_t)n_images * IMG_BYTES + 256;
   float4* buf; uint8_t* img; float* sink; uint32_t* sink2;
   CHECK(hipMalloc(&buf, stream_bytes));
@@ -82,17 +87,18 @@ int main() {
   const size_t n4 = stream_bytes / 16;
   for (int rep = 0; rep < 3; ++rep) {
     hipLaunchKernelGGL(calib_stream_read, dim3(256 * 16), dim3(256), 0, 0, buf, n4, sink);
-    hipLaunchKernelGGL(calib_gather_dword, dim3((n_lanes + 255) / 256), dim3(256), 0, 0, img, n_lanes, n_images, sink2);
+    hipLaunchKernelGGL(calib_gather_dword, dim3((n_images + IMAGES_PER_BLOCK - 1) / IMAGES_PER_BLOCK), dim3(128), 0, 0, img, n_images, sink2);
     hipLaunchKernelGGL(calib_stream_write, dim3(256 * 16), dim3(256), 0, 0, buf, n4);
     CHECK(hipDeviceSynchronize());
   }
   // host replay of the gather: the bytes a perfect memory system would fetch at each block size
   std::vector<size_t> addrs;
   addrs.reserve((size_t)n_lanes * 3);
-  for (uint32_t id = 0; id < n_lanes; ++id) {
-    const size_t off = gather_offset(id, n_images);
-    for (int r = 0; r < 3; ++r) addrs.push_back((off + (size_t)r * IMG_W) & ~(size_t)3);
-  }
+  for (uint32_t image = 0; image < n_images; ++image)
+    for (uint32_t l = 0; l < LANES_PER_IMAGE; ++l) {
+      const size_t off = gather_offset(image, l);
+      for (int r = 0; r < 3; ++r) addrs.push_back((off + (size_t)r * IMG_W) & ~(size_t)3);
+    }
   const size_t d32 = distinct_blocks(addrs, img_bytes, 5), d64 = distinct_blocks(addrs, img_bytes, 6), d128 = distinct_blocks(addrs, img_bytes, 7);
   printf("{\"stream_read_bytes\": %zu, \"stream_write_bytes\": %zu, \"gather_lanes\": %u, \"gather_requested_bytes\": %zu, "
          "\"gather_distinct_32B_blocks_bytes\": %zu, \"gather_distinct_64B_blocks_bytes\": %zu, \"gather_distinct_128B_blocks_bytes\": %zu}\n",
