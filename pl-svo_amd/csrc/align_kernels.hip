@@ -300,52 +300,94 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       for (int pass = long_lines ? 0 : 1; pass < 2; ++pass) {
         const bool write_abs = !long_lines || pass == 0;
         const bool accumulate = pass == 1;
-        // what a lane pair needs of a slot before the pose comes in: table entry, 3-D point, cached reference patch rows 2h, 2h+1.
-        // The loads of round r+1 are issued right after the pixel arithmetic of round r (software pipelining: their latency
-        // overlaps the line weights, the 6x6 expansion and the next projection; the registers are free at that point)
-        struct SlotFetch { int2 meta; bool cand; double X, Y, Z; float4 vr0, vx0, vy0, vr1, vx1, vy1; };
-        auto fetch_slot = [&](int pb_) -> SlotFetch {
-          SlotFetch f;
+        // Three stages per slot, software-pipelined over the rounds of the pass (PLSVO_PIPELINE = depth; 0 = none):
+        //   stage A  table entry + 3-D point                      (does not depend on the pose)
+        //   stage B  warp + project the point, gather the 5x5 window of the current image (needs A)
+        //   stage C  cached reference patch rows 2h, 2h+1 -> residuals, patch sums, line weights, expansion (needs B)
+        // depth 2: while round r is in stage C, round r+1 is in stage B (its image loads fly during r's arithmetic) and round
+        // r+2 in stage A; the cache rows of r+1 are requested right after r's pixel arithmetic, when r's rows are dead.
+        struct SlotA { int2 meta; bool cand; double X, Y, Z; };
+        struct SlotB { bool live; float u, v; int off; uint32_t r0a, r0b, r1a, r1b, r2a, r2b; };
+        struct SlotC { float4 vr0, vx0, vy0, vr1, vx1, vy1; };
+        auto stage_a = [&](int pb_) -> SlotA {
+          SlotA f;
           const int p_ = pb_ + pair;
           f.meta = make_int2(SLOT_HOLE, 0);
           if (p_ < n_slots) f.meta = s_meta[p_];
           f.cand = f.meta.x != SLOT_HOLE;
           if (f.cand && f.meta.x < 0 && s_dead[-1 - f.meta.x]) f.cand = false;   // line culled at an earlier iteration of this level
           f.X = 0.0; f.Y = 0.0; f.Z = 1.0;
-          f.vr0 = make_float4(0.f, 0.f, 0.f, 0.f); f.vx0 = f.vr0; f.vy0 = f.vr0; f.vr1 = f.vr0; f.vx1 = f.vr0; f.vy1 = f.vr0;
-          if (f.cand) {
-            f.X = pxyz[3 * p_]; f.Y = pxyz[3 * p_ + 1]; f.Z = pxyz[3 * p_ + 2];
-            const size_t q = (pbase + p_) * 4 + 2 * half;
-            f.vr0 = reinterpret_cast<const float4*>(b.cache_ref)[q]; f.vr1 = reinterpret_cast<const float4*>(b.cache_ref)[q + 1];
-            f.vx0 = reinterpret_cast<const float4*>(b.cache_dx)[q];  f.vx1 = reinterpret_cast<const float4*>(b.cache_dx)[q + 1];
-            f.vy0 = reinterpret_cast<const float4*>(b.cache_dy)[q];  f.vy1 = reinterpret_cast<const float4*>(b.cache_dy)[q + 1];
-          }
+          if (f.cand) { f.X = pxyz[3 * p_]; f.Y = pxyz[3 * p_ + 1]; f.Z = pxyz[3 * p_ + 2]; }
           return f;
         };
-#ifdef PLSVO_PIPELINE
-        SlotFetch nxt = fetch_slot(0);
+        auto stage_b = [&](const SlotA& sa) -> SlotB {
+          SlotB g;
+          // warp the 3-D point, project (:422-431, :583-594): lane 0 of the pair computes u, lane 1 computes v
+          const double c_cam = Ra * sa.X + Rb * sa.Y + Rc * sa.Z + ta;
+          const double z_cam = Rz0 * sa.X + Rz1 * sa.Y + Rz2 * sa.Z + tz;
+          const float w_mine = (float)((f_sel * (c_cam / z_cam) + c_sel) * scale);
+          const float w_other = dpp_mov_f32<DPP_QUAD_XOR1>(w_mine);
+          g.u = half ? w_other : w_mine; g.v = half ? w_mine : w_other;
+          // Patch::isInFrame(halfsize=2) on floorf(u), floorf(v); NaN -> out of frame
+          g.live = sa.cand && (g.u >= 2.0f) && (g.v >= 2.0f) && (g.u < colmax) && (g.v < rowmax);
+          g.off = 0; g.r0a = g.r0b = g.r1a = g.r1b = g.r2a = g.r2b = 0u;
+          if (g.live) {
+            const int ui = (int)floorf(g.u), vi = (int)floorf(g.v);
+            g.off = (vi - 2 + 2 * half) * W + (ui - 2);
+            const int a0 = g.off & ~3, a1 = (g.off + W) & ~3, a2 = (g.off + 2 * W) & ~3;
+            g.r0a = *reinterpret_cast<const uint32_t*>(cur_img + a0); g.r0b = *reinterpret_cast<const uint32_t*>(cur_img + a0 + 4);
+            g.r1a = *reinterpret_cast<const uint32_t*>(cur_img + a1); g.r1b = *reinterpret_cast<const uint32_t*>(cur_img + a1 + 4);
+            g.r2a = *reinterpret_cast<const uint32_t*>(cur_img + a2); g.r2b = *reinterpret_cast<const uint32_t*>(cur_img + a2 + 4);
+          }
+          return g;
+        };
+        auto stage_c_loads = [&](int pb_, bool cand_) -> SlotC {
+          SlotC c;
+          c.vr0 = make_float4(0.f, 0.f, 0.f, 0.f); c.vx0 = c.vr0; c.vy0 = c.vr0; c.vr1 = c.vr0; c.vx1 = c.vr0; c.vy1 = c.vr0;
+          if (cand_) {
+            const size_t q = (pbase + pb_ + pair) * 4 + 2 * half;
+            c.vr0 = reinterpret_cast<const float4*>(b.cache_ref)[q]; c.vr1 = reinterpret_cast<const float4*>(b.cache_ref)[q + 1];
+            c.vx0 = reinterpret_cast<const float4*>(b.cache_dx)[q];  c.vx1 = reinterpret_cast<const float4*>(b.cache_dx)[q + 1];
+            c.vy0 = reinterpret_cast<const float4*>(b.cache_dy)[q];  c.vy1 = reinterpret_cast<const float4*>(b.cache_dy)[q + 1];
+          }
+          return c;
+        };
+#ifndef PLSVO_PIPELINE
+#define PLSVO_PIPELINE 0
+#endif
+#if PLSVO_PIPELINE >= 2
+        SlotA a_cur = stage_a(0);
+        SlotC c_cur = stage_c_loads(0, a_cur.cand);
+        SlotB b_cur = stage_b(a_cur);
+        SlotA a_nxt = stage_a(T / 2);
+#elif PLSVO_PIPELINE == 1
+        SlotA a_nxt = stage_a(0);
+        SlotC c_nxt = stage_c_loads(0, a_nxt.cand);
 #endif
         for (int pb = 0; pb < n_slots; pb += T / 2) {
           const int p = pb + pair;
-#ifdef PLSVO_PIPELINE
-          const SlotFetch cur = nxt;
+#if PLSVO_PIPELINE >= 2
+          const SlotA sa = a_cur;
+          const SlotB sb = b_cur;
+          const SlotC sc = c_cur;
+          b_cur = stage_b(a_nxt);                       // round r+1: project, request its image window
+#elif PLSVO_PIPELINE == 1
+          const SlotA sa = a_nxt;
+          const SlotC sc = c_nxt;
+          const SlotB sb = stage_b(sa);
 #else
-          const SlotFetch cur = fetch_slot(pb);
+          const SlotA sa = stage_a(pb);
+          const SlotC sc = stage_c_loads(pb, sa.cand);
+          const SlotB sb = stage_b(sa);
 #endif
-          const int2 meta = cur.meta;
+          const int2 meta = sa.meta;
           const bool hole = meta.x == SLOT_HOLE;
           const bool is_line = !hole && meta.x < 0;
-          const bool cand = cur.cand;
-          const double X = cur.X, Y = cur.Y, Z = cur.Z;
-          const float4 vr0 = cur.vr0, vx0 = cur.vx0, vy0 = cur.vy0, vr1 = cur.vr1, vx1 = cur.vx1, vy1 = cur.vy1;
-          // -- warp the 3-D point, project (:422-431, :583-594): lane 0 of the pair computes u, lane 1 computes v
-          const double c_cam = Ra * X + Rb * Y + Rc * Z + ta;
-          const double z_cam = Rz0 * X + Rz1 * Y + Rz2 * Z + tz;
-          const float w_mine = (float)((f_sel * (c_cam / z_cam) + c_sel) * scale);
-          const float w_other = dpp_mov_f32<DPP_QUAD_XOR1>(w_mine);
-          const float u = half ? w_other : w_mine, v = half ? w_mine : w_other;
-          // Patch::isInFrame(halfsize=2) on floorf(u), floorf(v); NaN -> out of frame
-          const bool live = cand && (u >= 2.0f) && (v >= 2.0f) && (u < colmax) && (v < rowmax);
+          const bool cand = sa.cand;
+          const double X = sa.X, Y = sa.Y, Z = sa.Z;
+          const float4 vr0 = sc.vr0, vx0 = sc.vx0, vy0 = sc.vy0, vr1 = sc.vr1, vx1 = sc.vx1, vy1 = sc.vy1;
+          const float u = sb.u, v = sb.v;
+          const bool live = sb.live;
 
           // -- residuals and the five patch sums over this lane's two patch rows (8 pixels)
           double sA = 0, sB = 0, sC = 0, sD = 0, sE = 0, sChi = 0;
@@ -353,11 +395,8 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           const bool any_point = __any(live && !is_line) != 0;   // wave-uniform
           if (live) {
             const PatchW pw = patch_weights(u, v);
-            const int off = (pw.vi - 2 + 2 * half) * W + (pw.ui - 2);
-            const int a0 = off & ~3, a1 = (off + W) & ~3, a2 = (off + 2 * W) & ~3;
-            const uint32_t r0a = *reinterpret_cast<const uint32_t*>(cur_img + a0), r0b = *reinterpret_cast<const uint32_t*>(cur_img + a0 + 4);
-            const uint32_t r1a = *reinterpret_cast<const uint32_t*>(cur_img + a1), r1b = *reinterpret_cast<const uint32_t*>(cur_img + a1 + 4);
-            const uint32_t r2a = *reinterpret_cast<const uint32_t*>(cur_img + a2), r2b = *reinterpret_cast<const uint32_t*>(cur_img + a2 + 4);
+            const int off = sb.off;
+            const uint32_t r0a = sb.r0a, r0b = sb.r0b, r1a = sb.r1a, r1b = sb.r1b, r2a = sb.r2a, r2b = sb.r2b;
             auto unpack5 = [](uint32_t lo, uint32_t hi, int sh, float* o) {
               const uint32_t w0 = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh);
               o[0] = (float)(w0 & 0xffu); o[1] = (float)((w0 >> 8) & 0xffu); o[2] = (float)((w0 >> 16) & 0xffu); o[3] = (float)(w0 >> 24);
@@ -409,8 +448,13 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           sA += dpp_mov_f64<DPP_QUAD_XOR1>(sA); sB += dpp_mov_f64<DPP_QUAD_XOR1>(sB); sC += dpp_mov_f64<DPP_QUAD_XOR1>(sC);
           sD += dpp_mov_f64<DPP_QUAD_XOR1>(sD); sE += dpp_mov_f64<DPP_QUAD_XOR1>(sE); sChi += dpp_mov_f64<DPP_QUAD_XOR1>(sChi);
           sAbs += dpp_mov_f32<DPP_QUAD_XOR1>(sAbs);
-#ifdef PLSVO_PIPELINE
-          nxt = fetch_slot(pb + T / 2);     // (slots beyond the table come back as holes: no loads)
+#if PLSVO_PIPELINE >= 2
+          a_cur = a_nxt;                                   // (slots beyond the table come back as holes: no loads)
+          c_cur = stage_c_loads(pb + T / 2, a_cur.cand);   // round r+1's cache rows: r's are dead now
+          a_nxt = stage_a(pb + T);                         // round r+2's table entry + 3-D point
+#elif PLSVO_PIPELINE == 1
+          a_nxt = stage_a(pb + T / 2);
+          c_nxt = stage_c_loads(pb + T / 2, a_nxt.cand);
 #endif
 
           // -- weights: points 1; a line's samples share w / mean|res| (H) and w (Jres), :640-688
