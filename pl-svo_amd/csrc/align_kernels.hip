@@ -300,12 +300,15 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       for (int pass = long_lines ? 0 : 1; pass < 2; ++pass) {
         const bool write_abs = !long_lines || pass == 0;
         const bool accumulate = pass == 1;
-        // Three stages per slot, software-pipelined over the rounds of the pass (PLSVO_PIPELINE = depth; 0 = none):
+        // Three stages per slot, software-pipelined over the rounds of the pass (PLSVO_PIPELINE = depth):
         //   stage A  table entry + 3-D point                      (does not depend on the pose)
         //   stage B  warp + project the point, gather the 5x5 window of the current image (needs A)
         //   stage C  cached reference patch rows 2h, 2h+1 -> residuals, patch sums, line weights, expansion (needs B)
-        // depth 2: while round r is in stage C, round r+1 is in stage B (its image loads fly during r's arithmetic) and round
-        // r+2 in stage A; the cache rows of r+1 are requested right after r's pixel arithmetic, when r's rows are dead.
+        // depth 1 (default): the loads of stages A and C of round r+1 are issued right after the pixel arithmetic of round r --
+        //   the registers of r's cache rows are dead there, the latency overlaps r's line weights and expansion
+        //   (measured: -2.7 % launch time at 32768 frames, nothing at small batches);
+        // depth 2: round r+1 is also projected and its image window requested before r's arithmetic (measured: 11 spilled
+        //   VGPRs, no gain over depth 1); depth 0: no pipelining.
         struct SlotA { int2 meta; bool cand; double X, Y, Z; };
         struct SlotB { bool live; float u, v; int off; uint32_t r0a, r0b, r1a, r1b, r2a, r2b; };
         struct SlotC { float4 vr0, vx0, vy0, vr1, vx1, vy1; };
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           return c;
         };
 #ifndef PLSVO_PIPELINE
-#define PLSVO_PIPELINE 0
+#define PLSVO_PIPELINE 1
 #endif
 #if PLSVO_PIPELINE >= 2
         SlotA a_cur = stage_a(0);
