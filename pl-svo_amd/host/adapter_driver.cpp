@@ -117,8 +117,9 @@ int main(int argc, char** argv) {
     return 0;
   }
   FILE* o = fopen(argv[2], "w");
+  const bool verbose = getenv("PLSVO_DRIVER_VERBOSE") != nullptr;   // the reference's verbose flags (its call sites pass false)
   // ---- step 2 of processFrame: sparse image alignment ----
-  SparseImgAlign img_align(max_level, min_level, 30, SparseImgAlign::GaussNewton, false, false);
+  SparseImgAlign img_align(max_level, min_level, 30, SparseImgAlign::GaussNewton, false, verbose);
   const size_t n_tracked = img_align.run(ref, cur);
   fprintf(o, "n_tracked %zu\n", n_tracked);
   fprintf(o, "T_cur %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", cur->T_f_w_.q.x(), cur->T_f_w_.q.y(), cur->T_f_w_.q.z(), cur->T_f_w_.q.w(),
@@ -155,7 +156,7 @@ int main(int argc, char** argv) {
   fclose(f);
   size_t sfba_n_edges_final_pt = 0, sfba_n_edges_final_ls = 0;
   double sfba_thresh = 0, sfba_error_init = 0, sfba_error_final = 0;
-  plsvo::pose_optimizer::optimizeGaussNewton(2.0, (size_t)10, false, fr, sfba_thresh, sfba_error_init, sfba_error_final,
+  plsvo::pose_optimizer::optimizeGaussNewton(2.0, (size_t)10, verbose, fr, sfba_thresh, sfba_error_init, sfba_error_final,
                                              sfba_n_edges_final_pt, sfba_n_edges_final_ls);
   fprintf(o, "T_opt %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", fr->T_f_w_.q.x(), fr->T_f_w_.q.y(), fr->T_f_w_.q.z(), fr->T_f_w_.q.w(),
           fr->T_f_w_.t[0], fr->T_f_w_.t[1], fr->T_f_w_.t[2]);

@@ -277,7 +277,12 @@ class SparseImgAlignT {
     plsvo_align_out out;
     std::vector<uint8_t> alive_out(alive.size() ? alive.size() : 1, 1);
     out.seg_alive_out = alive_out.data();
-    if (plsvo_sparse_align(c.ctx, &in, &out) != PLSVO_OK) {
+    const int n_trace = verbose_ ? (max_level_ - min_level_ + 1) * (n_iter_ + 1) : 0;   // verbose: per-iteration records come back
+    if (verbose_) plsvo_align_set_trace(c.ctx, n_trace);
+    const int rc = plsvo_sparse_align(c.ctx, &in, &out);
+    if (rc == PLSVO_OK && verbose_) print_trace(c.ctx, n_trace);
+    if (verbose_) plsvo_align_set_trace(c.ctx, 0);
+    if (rc != PLSVO_OK) {
       std::fprintf(stderr, "[plsvo_hip] sparse_align failed: %s\n", plsvo_hip_last_error(c.ctx));
       return 0;
     }
@@ -291,8 +296,6 @@ class SparseImgAlignT {
     for (int k = 0; k < 36; ++k) H_[k] = out.H[k];
     n_meas_ = out.n_meas; chi2_ = out.chi2; stop_ = (out.status & 1) != 0;
     for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) iters_per_level_[l] = out.iters_per_level[l];
-    if (verbose_)
-      for (int l = max_level_; l >= min_level_; --l) std::printf("PYRAMID LEVEL %i: %d iterations\n", l, iters_per_level_[l]);
     return (size_t)out.n_tracked;                                                  // :94
   }
 
@@ -314,6 +317,26 @@ class SparseImgAlignT {
     plsvo_hip_adapter::mat66_traits<Mat66>::set(I, tmp);
   }
 
+  /// verbose_: what the reference prints while it optimises -- the level banner of run() (src/sparse_img_align.cpp:88-89) and
+  /// the per-iteration lines of [ext] vk::NLLSSolver::optimizeGaussNewton ("It. k  Success/Failure  new_chi2 = ..  n_meas = ..
+  /// x_norm = ..", restated from vikit's nlls_solver_impl.hpp) -- reconstructed after the launch from the device's trace
+  static void print_trace(plsvo_ctx* ctx, int cap) {
+    std::vector<plsvo_align_iterlog> log((size_t)(cap > 0 ? cap : 1));
+    int n = 0;
+    if (plsvo_align_fetch_trace(ctx, 0, log.data(), cap, &n) != PLSVO_OK) return;
+    int level = -1;
+    for (int k = 0; k < n; ++k) {
+      const plsvo_align_iterlog& r = log[(size_t)k];
+      if (r.level != level) { level = r.level; std::printf("\nPYRAMID LEVEL %i\n---------------\n", level); }
+      double xn = 0;
+      for (int j = 0; j < 6; ++j) xn = std::fabs(r.x[j]) > xn ? std::fabs(r.x[j]) : xn;
+      if (r.accepted)
+        std::printf("It. %d\t Success\t new_chi2 = %g\t n_meas = %llu\t x_norm = %g\n", r.iter, r.new_chi2, (unsigned long long)r.n_meas, xn);
+      else
+        std::printf("It. %d\t Failure\t new_chi2 = %g\t Error increased. Stop optimizing.\n", r.iter, r.new_chi2);
+    }
+  }
+
   // solver state the reference exposes through vk::NLLSSolver
   size_t n_meas_ = 0;
   double chi2_ = 1e10;
@@ -323,7 +346,7 @@ class SparseImgAlignT {
  private:
   int max_level_, min_level_, n_iter_;
   Method method_;
-  bool display_, verbose_;
+  bool display_, verbose_;   // display_ (the reference's cv::Mat residual image for a debug window, :121-122, :493-497) is accepted and ignored
   double eps_;
   double H_[36];
 };
@@ -366,7 +389,22 @@ void optimizeGaussNewtonImpl(const double reproj_thresh, const size_t n_iter, co
   plsvo_poseopt_out out;
   std::vector<uint8_t> pk(pt_ptr.size() ? pt_ptr.size() : 1, 1), sk(seg_ptr.size() ? seg_ptr.size() : 1, 1);
   out.pt_keep = pk.data(); out.seg_keep = sk.data();
-  if (plsvo_pose_optimize(c.ctx, &in, &out) != PLSVO_OK) {
+  const int n_trace = verbose ? (int)n_iter + (n_iter_ref > 0 ? (int)n_iter_ref : 0) + 2 : 0;
+  if (verbose) plsvo_poseopt_set_trace(c.ctx, n_trace);
+  const int rc = plsvo_pose_optimize(c.ctx, &in, &out);
+  if (rc == PLSVO_OK && verbose) {   // the per-iteration lines of src/pose_optimizer.cpp:175-190, from the device's trace
+    std::vector<plsvo_poseopt_iterlog> log((size_t)n_trace);
+    int n = 0;
+    if (plsvo_poseopt_fetch_trace(c.ctx, 0, log.data(), n_trace, &n) == PLSVO_OK)
+      for (int k = 0; k < n; ++k) {
+        double dn = 0;
+        for (int j = 0; j < 6; ++j) dn = std::fabs(log[(size_t)k].dT[j]) > dn ? std::fabs(log[(size_t)k].dT[j]) : dn;
+        if (log[(size_t)k].accepted) std::printf("it %d\t Success \t new_chi2 = %g\t norm(dT) = %g\n", log[(size_t)k].iter, log[(size_t)k].new_chi2, dn);
+        else std::printf("it %d\t FAILURE \t new_chi2 = %g\n", log[(size_t)k].iter, log[(size_t)k].new_chi2);
+      }
+  }
+  if (verbose) plsvo_poseopt_set_trace(c.ctx, 0);
+  if (rc != PLSVO_OK) {
     std::fprintf(stderr, "[plsvo_hip] pose_optimize failed: %s\n", plsvo_hip_last_error(c.ctx));
     return;
   }

@@ -229,3 +229,25 @@ def test_adapter_under_sanitizers(P, ob, tmp_path):
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
     r = subprocess.run([drv, "--bench", "5", str(path)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "run_us_mean" in r.stdout, r.stderr[-2000:]
+
+
+def test_adapter_verbose_prints_the_reference_lines(P, ob, tmp_path):
+    """verbose = true: the level banner of SparseImgAlign::run (src/sparse_img_align.cpp:88-89), vikit's per-iteration solver
+    lines and the pose optimiser's (src/pose_optimizer.cpp:175-190, :252-256), reconstructed from the device trace"""
+    W, H, nlev, maxl, minl = 320, 240, 4, 3, 1
+    st, ref, cur, job = Hh.make_case(ob, 883, W, H, 50, 20, nlev, maxl, minl)
+    fr = P.synth.make_poseopt_frame(884, 80, 25, W, H)
+    path = tmp_path / "in.bin"
+    P.adapter_io.write_adapter_input(path, st, ref, cur, fr, nlev, maxl, minl)
+    env = dict(os.environ, PLSVO_DRIVER_VERBOSE="1")
+    r = subprocess.run([DRIVER, str(path), str(tmp_path / "out.txt")], env=env, capture_output=True, text=True, timeout=120, check=True)
+    out = r.stdout
+    for level in (3, 2, 1):
+        assert f"PYRAMID LEVEL {level}\n---------------" in out
+    assert "It. 0\t Success\t new_chi2 = " in out and "n_meas = " in out and "x_norm = " in out
+    assert "it 0\t Success \t new_chi2 = " in out and "norm(dT) = " in out
+    assert "n deleted obs = " in out and "error init = " in out
+    # one solver line per Gauss-Newton iteration the device ran
+    ro, lo = ob.sparse_align(job, ref, cur, max_log=200)
+    n_lines = sum(1 for l in out.splitlines() if l.startswith("It. "))
+    assert abs(n_lines - len(lo)) <= 3          # the oracle's path may differ by an iteration per level (float chi2 decisions)
