@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -540,9 +541,20 @@ extern "C" int plsvo_align_fetch(plsvo_ctx* c, int n, plsvo_align_out* out) {
 }
 
 extern "C" int plsvo_sparse_align_batch(plsvo_ctx* c, int n, const plsvo_align_in* in, plsvo_align_out* out) {
+  static const bool host_timing = getenv("PLSVO_HOST_TIMING") != nullptr;   // debug: wall time of the three steps on stderr
+  const auto t0 = std::chrono::steady_clock::now();
   int rc = plsvo_align_stage(c, n, in); if (rc) return rc;
+  const auto t1 = std::chrono::steady_clock::now();
   rc = plsvo_align_run(c); if (rc) return rc;
-  return plsvo_align_fetch(c, n, out);
+  const auto t2 = std::chrono::steady_clock::now();
+  rc = plsvo_align_fetch(c, n, out);
+  if (host_timing) {
+    const auto t3 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[plsvo_hip] sparse_align_batch n=%d: stage %.1f us, run (enqueue) %.1f us, fetch (incl. wait) %.1f us\n", n,
+            std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count(),
+            std::chrono::duration<double, std::micro>(t3 - t2).count());
+  }
+  return rc;
 }
 extern "C" int plsvo_sparse_align(plsvo_ctx* c, const plsvo_align_in* in, plsvo_align_out* out) {
   return plsvo_sparse_align_batch(c, 1, in, out);
