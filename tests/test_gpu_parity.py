@@ -255,6 +255,48 @@ def test_sparse_align_edge_cases(P, ob, gpu_ctx):
     assert np.array_equal(rd.seg_alive, ro.seg_alive)
 
 
+def test_sparse_align_border_features_leave_holes_in_the_slot_table(P, ob, gpu_ctx):
+    """points / segment end points inside the 3-pixel border of a COARSE level but not of a fine one (`:216-219`, `:299-301`): their
+    slots are holes at the coarse levels and live at the fine ones; points that project outside the current image; segments
+    without a landmark on entry.  Per-iteration n_meas, culls and the pose must follow the oracle through all of it."""
+    W, H = 640, 480
+    st = P.synth.make_align_stream(61, W, H, 120, 40, max_level=3)
+    imgs = P.synth.render_streams([st]).numpy()
+    ref, cur = ob.build_pyramid(imgs[0, 0], 4), ob.build_pyramid(imgs[0, 1], 4)
+    px = st.pt_px.copy()
+    rng = np.random.default_rng(5)
+    # 3 px at level 3 = 24 px at level 0, 12 px at level 2, 6 px at level 1: spread 40 points over those bands, all four sides
+    for i in range(40):
+        band = (4.0, 7.0, 13.0, 25.0)[i % 4] + rng.uniform(0.0, 2.0)
+        side = (i // 4) % 4
+        if side == 0: px[i] = [band, rng.uniform(40, H - 40)]
+        elif side == 1: px[i] = [W - 1 - band, rng.uniform(40, H - 40)]
+        elif side == 2: px[i] = [rng.uniform(40, W - 40), band]
+        else: px[i] = [rng.uniform(40, W - 40), H - 1 - band]
+    spx, epx = st.seg_spx.copy(), st.seg_epx.copy()
+    for s in range(8):                                  # segment end points in the same bands
+        spx[s] = [(5.0, 9.0, 15.0, 27.0)[s % 4], 100.0 + 20 * s]
+    alive_in = np.ones(40, np.uint8)
+    alive_in[[3, 17, 39]] = 0
+    job = P.abi.AlignJob(st.cam, 3, 1, 30, 1e-6, st.T_init, px, st.pt_xyz_ref, spx, epx, np.linalg.norm(epx - spx, axis=1),
+                         st.seg_p_ref, st.seg_q_ref, seg_alive_in=alive_in)
+    ro, lo = ob.sparse_align(job, ref, cur, max_log=200)
+    gpu_ctx.config_pyramids(2, W, H, 4)
+    gpu_ctx.upload_pyramid(0, ref)
+    gpu_ctx.upload_pyramid(1, cur)
+    gpu_ctx.align_set_trace(200)
+    rd = gpu_ctx.sparse_align(job)
+    ld = gpu_ctx.align_fetch_trace(0)
+    n, worst = Hh.compare_align_logs(lo, ld)            # asserts n_meas equality per shared iteration
+    assert n >= 3 and worst["H"] < 2e-5 and worst["chi2"] < 1e-4, worst
+    per_level = {r["level"]: r["n_meas"] for r in lo}
+    assert per_level[3] < per_level[2] < per_level[1], "the case must gain measurements from level to level (border bands)"
+    assert np.array_equal(rd.seg_alive, ro.seg_alive) and not rd.seg_alive[[3, 17, 39]].any()
+    assert Hh.pose_close(Hh.frame_pose(rd.T, st), Hh.frame_pose(ro.T, st))[2]
+    if Hh.same_path(lo, ld):
+        assert rd.n_meas == ro.n_meas
+
+
 def test_sparse_align_batch_equals_single(P, ob, gpu_ctx):
     """streams are independent: a batch must reproduce the single-job results bit for bit"""
     B, W, H = 6, 320, 240
