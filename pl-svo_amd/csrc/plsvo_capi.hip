@@ -58,6 +58,18 @@ struct DevBuf {
 
 struct EventPair { hipEvent_t a, b; };
 
+// All input arrays of a staged batch travel as ONE host-to-device copy: sections of a single blob, each 256-byte aligned.
+// (A single-frame call used to pay a dozen small pageable copies; small blobs go through a pinned staging buffer.)
+struct Blob {
+  std::vector<uint8_t> host;
+  template <typename T> size_t add(const std::vector<T>& v) {
+    const size_t off = (host.size() + 255) & ~(size_t)255;
+    host.resize(off + std::max(v.size() * sizeof(T), (size_t)16));
+    if (!v.empty()) memcpy(host.data() + off, v.data(), v.size() * sizeof(T));
+    return off;
+  }
+};
+
 }  // namespace
 
 struct plsvo_ctx {
@@ -83,8 +95,8 @@ struct plsvo_ctx {
   int a_cap[PLSVO_MAX_LEVELS]{};
   int a_scap = 4;   // max segments of one job
   int a_trace_cap = 0;
-  DevBuf a_d_jobs, a_d_state, a_d_T0, a_d_ptpx, a_d_ptxyz, a_d_spx, a_d_epx, a_d_len, a_d_p, a_d_q, a_d_alive_in, a_d_alive;
-  DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_cdx, a_d_cdy, a_d_segslot, a_d_log, a_d_poses, a_d_order;
+  DevBuf a_d_state, a_d_alive;   // (inputs: a_d_blob)
+  DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_cdx, a_d_cdy, a_d_log, a_d_poses;
   AlignBatchDev a_b{};
 
   // pose-opt batch
@@ -93,12 +105,17 @@ struct plsvo_ctx {
   std::vector<PoseJobDev> p_jobs;
   int p_total_pt = 0, p_total_seg = 0;
   int p_trace_cap = 0;
-  DevBuf p_d_jobs, p_d_state, p_d_f, p_d_pos, p_d_plevel, p_d_line, p_d_spos, p_d_epos, p_d_slevel, p_d_ptkeep, p_d_segkeep;
+  DevBuf p_d_state, p_d_ptkeep, p_d_segkeep;   // (inputs: p_d_blob)
   DevBuf p_d_s32, p_d_s64, p_d_log, p_d_poses;
   PoseBatchDev p_b{};
 
   // structure optimisation (one-shot batches)
   DevBuf s_d_in, s_d_out;
+
+  // staging: one blob per batch type (Blob), pinned bounce buffer for small ones
+  DevBuf a_d_blob, p_d_blob;
+  void* pinned = nullptr;
+  size_t pinned_cap = 0;
 
   // profiling
   bool profiling = false;
@@ -192,12 +209,11 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-  DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_upload, &c->a_d_jobs, &c->a_d_state, &c->a_d_T0, &c->a_d_ptpx, &c->a_d_ptxyz, &c->a_d_spx,
-                     &c->a_d_epx, &c->a_d_len, &c->a_d_p, &c->a_d_q, &c->a_d_alive_in, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv,
-                     &c->a_d_cref, &c->a_d_cdx, &c->a_d_cdy, &c->a_d_segslot, &c->a_d_log, &c->a_d_poses, &c->a_d_order, &c->p_d_jobs, &c->p_d_state,
-                     &c->p_d_f, &c->p_d_pos, &c->p_d_plevel, &c->p_d_line, &c->p_d_spos, &c->p_d_epos, &c->p_d_slevel,
-                     &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64, &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out };
+  DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_upload, &c->a_d_blob, &c->a_d_state, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv, &c->a_d_cref, &c->a_d_cdx,
+                     &c->a_d_cdy, &c->a_d_log, &c->a_d_poses, &c->p_d_blob, &c->p_d_state, &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64,
+                     &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out };
   for (DevBuf* b : bufs) b->release();
+  if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -318,6 +334,25 @@ static int upload(plsvo_ctx* c, DevBuf& buf, const std::vector<T>& v) {
   return PLSVO_OK;
 }
 
+static const size_t kPinnedMax = (size_t)8 << 20;   // blobs up to 8 MB (hundreds of frames) bounce through pinned memory
+static int upload_blob(plsvo_ctx* c, DevBuf& buf, const Blob& blob) {
+  const size_t bytes = std::max(blob.host.size(), (size_t)256);
+  HIP_TRY(c, buf.ensure(bytes));
+  if (blob.host.empty()) return PLSVO_OK;
+  const void* src = blob.host.data();
+  if (blob.host.size() <= kPinnedMax) {
+    if (c->pinned_cap < blob.host.size()) {
+      if (c->pinned) (void)hipHostFree(c->pinned);
+      c->pinned = nullptr; c->pinned_cap = 0;
+      const size_t want = std::max(blob.host.size() * 2, (size_t)1 << 20);
+      if (hipHostMalloc(&c->pinned, want, hipHostMallocDefault) == hipSuccess) c->pinned_cap = want; else c->pinned = nullptr;
+    }
+    if (c->pinned) { memcpy(c->pinned, blob.host.data(), blob.host.size()); src = c->pinned; }
+  }
+  HIP_TRY(c, hipMemcpyAsync(buf.p, src, blob.host.size(), hipMemcpyHostToDevice, c->stream));
+  return PLSVO_OK;
+}
+
 extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) {
   CTX_CHECK(c);
   if (n <= 0 || !in) return fail(c, PLSVO_E_INVALID, "align_stage: bad arguments");
@@ -412,18 +447,11 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   std::vector<int> slot_table;
   for (int l = slot_level0; l <= std::max(gmax, slot_level0); ++l) slot_table.insert(slot_table.end(), seg_slot[(size_t)l].begin(), seg_slot[(size_t)l].end());
   if (slot_table.empty()) slot_table.push_back(-1);
-  if ((rc = upload(c, c->a_d_segslot, slot_table))) return rc;
-  if ((rc = upload(c, c->a_d_order, order))) return rc;
-  if ((rc = upload(c, c->a_d_jobs, jobs))) return rc;
-  if ((rc = upload(c, c->a_d_T0, T0))) return rc;
-  if ((rc = upload(c, c->a_d_ptpx, ptpx))) return rc;
-  if ((rc = upload(c, c->a_d_ptxyz, ptxyz))) return rc;
-  if ((rc = upload(c, c->a_d_spx, spx))) return rc;
-  if ((rc = upload(c, c->a_d_epx, epx))) return rc;
-  if ((rc = upload(c, c->a_d_len, len))) return rc;
-  if ((rc = upload(c, c->a_d_p, sp))) return rc;
-  if ((rc = upload(c, c->a_d_q, sq))) return rc;
-  if ((rc = upload(c, c->a_d_alive_in, alive))) return rc;
+  Blob blob;
+  const size_t o_slot = blob.add(slot_table), o_order = blob.add(order), o_jobs = blob.add(jobs), o_T0 = blob.add(T0), o_ptpx = blob.add(ptpx),
+               o_ptxyz = blob.add(ptxyz), o_spx = blob.add(spx), o_epx = blob.add(epx), o_len = blob.add(len), o_sp = blob.add(sp),
+               o_sq = blob.add(sq), o_alive = blob.add(alive);
+  if ((rc = upload_blob(c, c->a_d_blob, blob))) return rc;
   HIP_TRY(c, c->a_d_alive.ensure(std::max(alive.size(), (size_t)1)));
   HIP_TRY(c, c->a_d_state.ensure((size_t)n * sizeof(AlignStateDev)));
   HIP_TRY(c, c->a_d_poses.ensure((size_t)n * 7 * sizeof(double)));
@@ -437,20 +465,23 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
 
   AlignBatchDev& b = c->a_b;
-  b.jobs = c->a_d_jobs.as<AlignJobDev>(); b.state = c->a_d_state.as<AlignStateDev>(); b.T0 = c->a_d_T0.as<double>();
-  b.pt_px = c->a_d_ptpx.as<double>(); b.pt_xyz = c->a_d_ptxyz.as<double>();
-  b.seg_spx = c->a_d_spx.as<double>(); b.seg_epx = c->a_d_epx.as<double>(); b.seg_len = c->a_d_len.as<double>();
-  b.seg_p = c->a_d_p.as<double>(); b.seg_q = c->a_d_q.as<double>();
-  b.seg_alive_in = c->a_d_alive_in.as<uint8_t>(); b.seg_alive = c->a_d_alive.as<uint8_t>();
+  uint8_t* const base = c->a_d_blob.as<uint8_t>();
+  b.jobs = reinterpret_cast<const AlignJobDev*>(base + o_jobs); b.state = c->a_d_state.as<AlignStateDev>();
+  b.T0 = reinterpret_cast<const double*>(base + o_T0);
+  b.pt_px = reinterpret_cast<const double*>(base + o_ptpx); b.pt_xyz = reinterpret_cast<const double*>(base + o_ptxyz);
+  b.seg_spx = reinterpret_cast<const double*>(base + o_spx); b.seg_epx = reinterpret_cast<const double*>(base + o_epx);
+  b.seg_len = reinterpret_cast<const double*>(base + o_len);
+  b.seg_p = reinterpret_cast<const double*>(base + o_sp); b.seg_q = reinterpret_cast<const double*>(base + o_sq);
+  b.seg_alive_in = base + o_alive; b.seg_alive = c->a_d_alive.as<uint8_t>();
   b.patch_xyz = c->a_d_pxyz.as<double>(); b.patch_uvref = c->a_d_puv.as<float>();
   b.cache_ref = c->a_d_cref.as<float>(); b.cache_dx = c->a_d_cdx.as<float>(); b.cache_dy = c->a_d_cdy.as<float>();
-  b.seg_slot = c->a_d_segslot.as<int>(); b.slot_level0 = slot_level0; b.slot_stride = (int)total_seg;
+  b.seg_slot = reinterpret_cast<const int*>(base + o_slot); b.slot_level0 = slot_level0; b.slot_stride = (int)total_seg;
   b.poses = c->a_d_poses.as<double>();
   b.pyr = c->pyr;
   b.log = c->a_trace_cap > 0 ? c->a_d_log.as<plsvo_align_iterlog>() : nullptr;
   b.log_cap = c->a_trace_cap;
   b.n_jobs = n;
-  b.order = c->a_d_order.as<int>();
+  b.order = reinterpret_cast<const int*>(base + o_order);
   c->a_jobs.swap(jobs);
   c->a_n = n; c->a_total_seg = (int)alive.size(); c->a_gmax = gmax; c->a_gmin = gmin;
   for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) c->a_cap[l] = caps[l];
@@ -661,14 +692,10 @@ extern "C" int plsvo_poseopt_stage(plsvo_ctx* c, int n, const plsvo_poseopt_in* 
     for (int i = 0; i < a.n_seg; ++i) if (a.seg_level[i] < 0 || a.seg_level[i] > 30) return fail(c, PLSVO_E_INVALID, "poseopt_stage: feature level out of range");
   }
   int rc;
-  if ((rc = upload(c, c->p_d_jobs, jobs))) return rc;
-  if ((rc = upload(c, c->p_d_f, f))) return rc;
-  if ((rc = upload(c, c->p_d_pos, pos))) return rc;
-  if ((rc = upload(c, c->p_d_plevel, plev))) return rc;
-  if ((rc = upload(c, c->p_d_line, line))) return rc;
-  if ((rc = upload(c, c->p_d_spos, spos))) return rc;
-  if ((rc = upload(c, c->p_d_epos, epos))) return rc;
-  if ((rc = upload(c, c->p_d_slevel, slev))) return rc;
+  Blob blob;
+  const size_t o_jobs = blob.add(jobs), o_f = blob.add(f), o_pos = blob.add(pos), o_plev = blob.add(plev), o_line = blob.add(line),
+               o_spos = blob.add(spos), o_epos = blob.add(epos), o_slev = blob.add(slev);
+  if ((rc = upload_blob(c, c->p_d_blob, blob))) return rc;
   const size_t npt = plev.size(), nsg = slev.size(), nft = std::max(npt + nsg, (size_t)1);
   HIP_TRY(c, c->p_d_ptkeep.ensure(std::max(npt, (size_t)1)));
   HIP_TRY(c, c->p_d_segkeep.ensure(std::max(nsg, (size_t)1)));
@@ -679,10 +706,12 @@ extern "C" int plsvo_poseopt_stage(plsvo_ctx* c, int n, const plsvo_poseopt_in* 
   if (c->p_trace_cap > 0) HIP_TRY(c, c->p_d_log.ensure((size_t)n * c->p_trace_cap * sizeof(plsvo_poseopt_iterlog)));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   PoseBatchDev& b = c->p_b;
-  b.jobs = c->p_d_jobs.as<PoseJobDev>(); b.state = c->p_d_state.as<PoseStateDev>();
-  b.pt_f = c->p_d_f.as<double>(); b.pt_pos = c->p_d_pos.as<double>(); b.pt_level = c->p_d_plevel.as<int>();
-  b.seg_line = c->p_d_line.as<double>(); b.seg_spos = c->p_d_spos.as<double>(); b.seg_epos = c->p_d_epos.as<double>();
-  b.seg_level = c->p_d_slevel.as<int>();
+  uint8_t* const base = c->p_d_blob.as<uint8_t>();
+  b.jobs = reinterpret_cast<const PoseJobDev*>(base + o_jobs); b.state = c->p_d_state.as<PoseStateDev>();
+  b.pt_f = reinterpret_cast<const double*>(base + o_f); b.pt_pos = reinterpret_cast<const double*>(base + o_pos);
+  b.pt_level = reinterpret_cast<const int*>(base + o_plev);
+  b.seg_line = reinterpret_cast<const double*>(base + o_line); b.seg_spos = reinterpret_cast<const double*>(base + o_spos);
+  b.seg_epos = reinterpret_cast<const double*>(base + o_epos); b.seg_level = reinterpret_cast<const int*>(base + o_slev);
   b.pt_keep = c->p_d_ptkeep.as<uint8_t>(); b.seg_keep = c->p_d_segkeep.as<uint8_t>();
   b.scratch_f32 = c->p_d_s32.as<float>(); b.scratch_f64 = c->p_d_s64.as<double>();
   b.log = c->p_trace_cap > 0 ? c->p_d_log.as<plsvo_poseopt_iterlog>() : nullptr;
