@@ -103,11 +103,10 @@ __device__ __forceinline__ PatchW patch_weights(float u, float v) {
 
 #define SLOT_HOLE ((int)0x80000000)   // s_meta[p].x of a slot no live feature owns at this level
 
-__device__ __forceinline__ void wave_lds_sync() { wave_lds_fence(); }
 // workgroup barrier; a one-wave workgroup needs only the wave-level form
 template <int T>
 __device__ __forceinline__ void block_sync() {
-  if constexpr (T == 64) wave_lds_sync(); else __syncthreads();
+  if constexpr (T == 64) wave_lds_fence(); else __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -465,7 +464,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           if (__any(is_line && cand)) {   // wave-uniform
             if (write_abs) {
               if (is_line && cand && half == 0) s_abs[p] = live ? sAbs : -1.0f;
-              wave_lds_sync();   // all samples of a line sit in this wave's round (host layout); two-pass levels: see the barrier below
+              wave_lds_fence();   // all samples of a line sit in this wave's round (host layout); two-pass levels: see the barrier below
             }
             if (accumulate && is_line && cand) {
               const int first = meta.y & 0xfffff, N = meta.y >> 20;

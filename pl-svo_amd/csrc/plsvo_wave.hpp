@@ -38,11 +38,6 @@ __device__ __forceinline__ double quad_sum(double v) {
   v += dpp_mov_f64<DPP_QUAD_XOR2>(v);
   return v;
 }
-__device__ __forceinline__ float quad_sum(float v) {
-  v += dpp_mov_f32<DPP_QUAD_XOR1>(v);
-  v += dpp_mov_f32<DPP_QUAD_XOR2>(v);
-  return v;
-}
 // sum over the 64 lanes of a wave; the total is valid in lane 63
 __device__ __forceinline__ double wave_sum_to_lane63(double v) {
   v = quad_sum(v);
@@ -51,26 +46,6 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
   v += dpp_bcast_f64<DPP_ROW_BCAST15, 0xA>(v);
   v += dpp_bcast_f64<DPP_ROW_BCAST31, 0xC>(v);
   return v;
-}
-
-// wave-sum of N values at once (N multiple of 6): six independent DPP chains at a time; totals valid in lane 63
-template <int N>
-__device__ __forceinline__ void wave_sum_array(double* v) {
-#pragma unroll
-  for (int c0 = 0; c0 < N; c0 += 6) {
-#pragma unroll
-    for (int k = c0; k < c0 + 6; ++k) v[k] += dpp_mov_f64<DPP_QUAD_XOR1>(v[k]);
-#pragma unroll
-    for (int k = c0; k < c0 + 6; ++k) v[k] += dpp_mov_f64<DPP_QUAD_XOR2>(v[k]);
-#pragma unroll
-    for (int k = c0; k < c0 + 6; ++k) v[k] += dpp_mov_f64<DPP_ROW_HALF_MIRROR>(v[k]);
-#pragma unroll
-    for (int k = c0; k < c0 + 6; ++k) v[k] += dpp_mov_f64<DPP_ROW_MIRROR>(v[k]);
-#pragma unroll
-    for (int k = c0; k < c0 + 6; ++k) v[k] += dpp_bcast_f64<DPP_ROW_BCAST15, 0xA>(v[k]);
-#pragma unroll
-    for (int k = c0; k < c0 + 6; ++k) v[k] += dpp_bcast_f64<DPP_ROW_BCAST31, 0xC>(v[k]);
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -256,33 +231,6 @@ __device__ __forceinline__ void wave_solve6_core(double m, double* x) {
   const double xi = (((zero_piv >> i) & 1u) || !(fabs(dgi) > tolerance)) ? ((dgi != dgi || m != m) ? (m + dgi) : 0.0) : m / dgi;   // lanes 8i+6: m = rhs
 #pragma unroll
   for (int r = 0; r < 6; ++r) x[r] = readlane_f64(xi, 8 * r + 6);
-}
-
-// sin and cos of a small angle (|x| <= pi/4: Taylor/Horner to x^17 / x^16, < 1 ulp); larger angles use ocml.
-// Gauss-Newton updates are tiny rotations, so the fast path is the one that runs.
-__device__ __forceinline__ void sincos_small(double x, double* s, double* c) {
-  if (fabs(x) <= 0.7853981633974483) {
-    const double z = x * x;
-    double ps = -1.0 / 355687428096000.0;                      // -1/17!
-    ps = ps * z + 1.0 / 1307674368000.0;                       //  1/15!
-    ps = ps * z - 1.0 / 6227020800.0;                          // -1/13!
-    ps = ps * z + 1.0 / 39916800.0;                            //  1/11!
-    ps = ps * z - 1.0 / 362880.0;                              // -1/9!
-    ps = ps * z + 1.0 / 5040.0;                                //  1/7!
-    ps = ps * z - 1.0 / 120.0;                                 // -1/5!
-    ps = ps * z + 1.0 / 6.0;                                   //  1/3!  (sign folded below)
-    *s = x - x * z * ps;
-    double pc = 1.0 / 20922789888000.0;                        //  1/16!
-    pc = pc * z - 1.0 / 87178291200.0;                         // -1/14!
-    pc = pc * z + 1.0 / 479001600.0;                           //  1/12!
-    pc = pc * z - 1.0 / 3628800.0;                             // -1/10!
-    pc = pc * z + 1.0 / 40320.0;                               //  1/8!
-    pc = pc * z - 1.0 / 720.0;                                 // -1/6!
-    pc = pc * z + 1.0 / 24.0;                                  //  1/4!
-    *c = 1.0 - 0.5 * z + z * z * pc;
-  } else {
-    *s = sin(x); *c = cos(x);
-  }
 }
 
 __device__ __forceinline__ Quat quat_normalized_fast(const Quat& a) {
