@@ -10,6 +10,6 @@ CMD="python $R/bench.py --batch ${PMC_BATCH:-4096} --steps 3 --warmup 1 --no-cpu
 for C in "$@"; do
   rm -rf /tmp/pmc_$C
   timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_$C -- $CMD > $O/pmc_$C.log 2>&1
-  DB=$(find /tmp/pmc_$C -name "*results.db" | head -1)
+  DB=$(find /tmp/pmc_$C -name "*results.db" | paste -sd, -)
   if [ -n "$DB" ]; then python $R/tools/rocpd_summary.py --counters "$DB" $O/pmc_$C.csv "bench.py --batch ${PMC_BATCH:-4096} --steps 3 --warmup 1 --no-cpu-baseline --no-latency"; grep align_fused $O/pmc_$C.csv | tail -2; else tail -3 $O/pmc_$C.log; fi
 done

@@ -20,16 +20,16 @@ rm -rf /tmp/kt
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/kt -- python $R/bench.py > $O/bench_stdout.txt 2> $O/bench_default.err
 grep '^{"metric"' $O/bench_stdout.txt | tail -1 > $O/bench_default.json
 cut -c1-400 $O/bench_default.json
-DB=$(find /tmp/kt -name "*results.db" | head -1)
+DB=$(find /tmp/kt -name "*results.db" | paste -sd, -)
 python $R/tools/rocpd_summary.py "$DB" $O/kernel_trace_stats.csv "python bench.py (default: 32768 streams, 20 steps + 3 warm-up; MI355X); same run as bench_default.json"
 CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency"
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C /tmp/cal_$C
   timeout 600 rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_$C -- $CMD > $O/pmc_$C.log 2>&1
-  DB=$(find /tmp/pmc_$C -name "*results.db" | head -1)
+  DB=$(find /tmp/pmc_$C -name "*results.db" | paste -sd, -)
   python $R/tools/rocpd_summary.py --counters "$DB" $O/pmc_$C.csv "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency (MI355X)"
   timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/cal_$C -- $R/tools/pmc_calib > $O/calib_$C.log 2>&1
-  DB=$(find /tmp/cal_$C -name "*results.db" | head -1)
+  DB=$(find /tmp/cal_$C -name "*results.db" | paste -sd, -)
   python $R/tools/rocpd_summary.py --counters "$DB" $O/calib_$C.csv "tools/pmc_calib (MI355X)" "%calib_%"
 done
 grep "^{" $O/calib_FETCH_SIZE.log | tail -1 > $O/calib_known_bytes.json
