@@ -171,6 +171,15 @@ int plsvo_align_run(plsvo_ctx* ctx);
 int plsvo_align_fetch(plsvo_ctx* ctx, int n, plsvo_align_out* out);
 
 /* per-iteration trace: enable before plsvo_align_run; max_records_per_job bounds the trace */
+/* Host-only helper (no device needed): the static patch-slot layout plsvo_align_stage gives one job at one pyramid level.
+ * Points own slots [0, n_pts); segments follow from the next multiple of 32 in feature order; a segment with N <= 32 samples
+ * (N = 1 + (N0-1)/2^level, LineFeat::setupSampling src/feature.cpp:160-173, src/sparse_img_align.cpp:320) never straddles a
+ * multiple of 32.  seg_code[s] = first slot | N << 20, or -1 for a segment without landmark on entry or with an end point inside
+ * the 3-pixel border of the level (src/sparse_img_align.cpp:299-301).  n_slots: slots in use; long_lines: some N > 32;
+ * n_patches: points + samples (holes not counted).  Returns PLSVO_E_CAPACITY for N > 2047 or more than 2^20 slots. */
+int plsvo_align_slot_layout(const plsvo_align_in* in, int level, int32_t* seg_code, int32_t* n_slots, int32_t* long_lines,
+                            long long* n_patches);
+
 int plsvo_align_set_trace(plsvo_ctx* ctx, int max_records_per_job);
 int plsvo_align_fetch_trace(plsvo_ctx* ctx, int job, plsvo_align_iterlog* out, int max_records,
                             int* n_records);

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("PLSVO_HIP_LIB", os.path.join(_HERE, "libplsvo_hip.so"
 
 # every symbol include/plsvo_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "plsvo_hip_create", "plsvo_hip_create_on_stream", "plsvo_hip_destroy", "plsvo_hip_last_error", "plsvo_hip_stream", "plsvo_hip_synchronize",
+    "plsvo_hip_create", "plsvo_hip_create_on_stream", "plsvo_align_slot_layout", "plsvo_hip_destroy", "plsvo_hip_last_error", "plsvo_hip_stream", "plsvo_hip_synchronize",
     "plsvo_hip_config_pyramids", "plsvo_hip_upload_pyramid", "plsvo_hip_build_pyramid", "plsvo_hip_build_pyramids_dev",
     "plsvo_hip_download_level",
     "plsvo_sparse_align", "plsvo_sparse_align_batch", "plsvo_align_stage", "plsvo_align_run", "plsvo_align_fetch",
@@ -86,6 +86,8 @@ def lib():
         "plsvo_reproject": (C.c_int, [ctxp, C.POINTER(abi.ReprojectIn), C.POINTER(abi.ReprojectOut)]),
         "plsvo_update_seeds": (C.c_int, [ctxp, C.POINTER(abi.SeedsIn), C.POINTER(abi.SeedsOut)]),
         "plsvo_trajectory_record": (C.c_int, [abi.c_double_p, abi.c_double_p, abi.c_double_p]),
+        "plsvo_align_slot_layout": (C.c_int, [C.POINTER(abi.AlignIn), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                              C.POINTER(C.c_longlong)]),
         "plsvo_gather_poses": (C.c_int, [ctxp, vp, vp, C.c_int, vp]),
         "plsvo_hip_set_profiling": (C.c_int, [ctxp, C.c_int]),
         "plsvo_hip_kernel_time": (C.c_int, [ctxp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -326,3 +328,19 @@ def trajectory_record(T_f_w, cov):
     out = np.empty(7)
     ok = lib().plsvo_trajectory_record(T.ctypes.data_as(abi.c_double_p), Cv.ctypes.data_as(abi.c_double_p), out.ctypes.data_as(abi.c_double_p))
     return bool(ok), out
+
+
+def align_slot_layout(job, level):
+    """plsvo_align_slot_layout: the static patch-slot layout of one alignment job at one level -- host-only, no ctx needed.
+    Returns (first slot per segment or -1, samples per segment, slots in use, long_lines flag, patches)."""
+    import numpy as np
+    n_seg = int(job.c.n_seg)
+    codes = (C.c_int32 * max(n_seg, 1))()
+    n_slots, long_lines, n_patches = C.c_int32(0), C.c_int32(0), C.c_longlong(0)
+    rc = lib().plsvo_align_slot_layout(C.byref(job.c), int(level), codes, C.byref(n_slots), C.byref(long_lines), C.byref(n_patches))
+    if rc != 0:
+        raise PlsvoError(rc, "plsvo_align_slot_layout failed")
+    code = np.array(codes[:n_seg], dtype=np.int64)
+    first = np.where(code >= 0, code & 0xfffff, -1)
+    n = np.where(code >= 0, code >> 20, 0)
+    return first, n, int(n_slots.value), bool(long_lines.value), int(n_patches.value)

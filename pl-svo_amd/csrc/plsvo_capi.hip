@@ -334,6 +334,42 @@ static int upload(plsvo_ctx* c, DevBuf& buf, const std::vector<T>& v) {
   return PLSVO_OK;
 }
 
+// Static patch-slot layout of one job at one level (align_kernels.hip header): points own slots [0, n_pts); segments follow
+// from the next multiple of 32 in feature order, and a segment with N <= 32 samples never straddles a multiple of 32, so that
+// all its samples sit in one wave-round of the kernel.  Segments without a landmark on entry, or whose end points fail the
+// 3-pixel border test of the level (src/sparse_img_align.cpp:299-301), get no slots (code -1).  Host-only arithmetic.
+extern "C" int plsvo_align_slot_layout(const plsvo_align_in* in, int level, int32_t* seg_code, int32_t* n_slots, int32_t* long_lines,
+                                       long long* n_patches) {
+  if (!in || level < 0 || level >= PLSVO_MAX_LEVELS || in->n_pts < 0 || in->n_seg < 0 || (in->n_seg > 0 && !seg_code)) return PLSVO_E_INVALID;
+  const plsvo_align_in& a = *in;
+  long long cur = a.n_seg > 0 ? (((long long)a.n_pts + 31) & ~31LL) : (long long)a.n_pts;
+  long long used = a.n_pts, n_real = a.n_pts;
+  int any_long = 0;
+  const double scale = 1.0 / (double)(1 << level);
+  const int cw = a.cam.width / (1 << level), ch = a.cam.height / (1 << level);
+  for (int s = 0; s < a.n_seg; ++s) {
+    int code = -1;
+    const bool alive_on_entry = a.seg_alive_in ? (a.seg_alive_in[s] != 0) : true;
+    const double sx = a.seg_spx[2 * s], sy = a.seg_spx[2 * s + 1], ex = a.seg_epx[2 * s], ey = a.seg_epx[2 * s + 1];
+    const int isx = (int)(sx * scale), isy = (int)(sy * scale), iex = (int)(ex * scale), iey = (int)(ey * scale);
+    const bool vis = isx >= 3 && isx < cw - 3 && isy >= 3 && isy < ch - 3 && iex >= 3 && iex < cw - 3 && iey >= 3 && iey < ch - 3;
+    if (alive_on_entry && vis) {
+      const int N = seg_num_samples(sx, sy, ex, ey, a.seg_len[s], level);
+      if (N > 2047) return PLSVO_E_CAPACITY;
+      if (N <= 32) { if ((cur & 31) + N > 32) cur = (cur + 31) & ~31LL; }
+      else any_long = 1;
+      if (cur + N > (1 << 20) - 8) return PLSVO_E_CAPACITY;
+      code = (int)cur | (N << 20);
+      cur += N; used = cur; n_real += N;
+    }
+    seg_code[s] = code;
+  }
+  if (n_slots) *n_slots = (int32_t)used;
+  if (long_lines) *long_lines = any_long;
+  if (n_patches) *n_patches = n_real;
+  return PLSVO_OK;
+}
+
 static const size_t kPinnedMax = (size_t)8 << 20;   // blobs up to 8 MB (hundreds of frames) bounce through pinned memory
 static int upload_blob(plsvo_ctx* c, DevBuf& buf, const Blob& blob) {
   const size_t bytes = std::max(blob.host.size(), (size_t)256);
@@ -400,30 +436,16 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
     long long ub_sum = 0;
     J.long_mask = 0; J.reserved0 = 0;
     for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) J.n_slots[l] = 0;
+    std::vector<int> codes((size_t)std::max(a.n_seg, 1));
     for (int l = a.max_level; l >= a.min_level; --l) {
-      long long cur = a.n_seg > 0 ? (((long long)a.n_pts + 31) & ~31LL) : (long long)a.n_pts;
-      long long used = a.n_pts, n_real = a.n_pts;
-      const double scale = 1.0 / (double)(1 << l);
-      const int cw = a.cam.width / (1 << l), ch = a.cam.height / (1 << l);
-      for (int s = 0; s < a.n_seg; ++s) {
-        int code = -1;
-        const bool alive_on_entry = a.seg_alive_in ? (a.seg_alive_in[s] != 0) : true;
-        const double sx = a.seg_spx[2 * s], sy = a.seg_spx[2 * s + 1], ex = a.seg_epx[2 * s], ey = a.seg_epx[2 * s + 1];
-        const int isx = (int)(sx * scale), isy = (int)(sy * scale), iex = (int)(ex * scale), iey = (int)(ey * scale);
-        const bool vis = isx >= 3 && isx < cw - 3 && isy >= 3 && isy < ch - 3 && iex >= 3 && iex < cw - 3 && iey >= 3 && iey < ch - 3;
-        if (alive_on_entry && vis) {
-          const int N = seg_num_samples(sx, sy, ex, ey, a.seg_len[s], l);
-          if (N > 2047) return fail(c, PLSVO_E_CAPACITY, "align_stage: a segment with more than 2047 samples");
-          if (N <= 32) { if ((cur & 31) + N > 32) cur = (cur + 31) & ~31LL; }
-          else J.long_mask |= 1 << l;
-          if (cur + N > (1 << 20) - 8) return fail(c, PLSVO_E_CAPACITY, "align_stage: more than 2^20 patch slots in one job");
-          code = (int)cur | (N << 20);
-          cur += N; used = cur; n_real += N;
-        }
-        seg_slot[(size_t)l].push_back(code);
-      }
-      const int slots4 = (int)((used + 3) & ~3LL);
-      J.n_slots[l] = (int)used;
+      int n_slots = 0, long_lines = 0; long long n_real = 0;
+      const int lrc = plsvo_align_slot_layout(&a, l, codes.data(), &n_slots, &long_lines, &n_real);
+      if (lrc == PLSVO_E_CAPACITY) return fail(c, PLSVO_E_CAPACITY, "align_stage: a segment with more than 2047 samples or more than 2^20 patch slots in one job");
+      if (lrc != PLSVO_OK) return fail(c, lrc, "align_stage: slot layout failed");
+      seg_slot[(size_t)l].insert(seg_slot[(size_t)l].end(), codes.begin(), codes.begin() + a.n_seg);
+      if (long_lines) J.long_mask |= 1 << l;
+      const int slots4 = (n_slots + 3) & ~3;
+      J.n_slots[l] = n_slots;
       ub_sum += n_real;
       if (!J.skip) caps[l] = std::max(caps[l], slots4);
       ub_max = std::max(ub_max, slots4);
