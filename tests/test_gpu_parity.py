@@ -320,6 +320,52 @@ def test_sparse_align_batch_equals_single(P, ob, gpu_ctx):
         assert Hh.pose_close(batch[i].T, ro.T)[2]
 
 
+@pytest.mark.parametrize("threads", [64, 128, 256, 512])
+def test_sparse_align_every_launch_shape(P, ob, gpu_ctx, threads, monkeypatch):
+    """the library picks 64 / 128 / 256 / 512 threads per frame from the batch size (64: one wave per frame, no workgroup barrier
+    at all -- the shape of the 32768-frame benchmark); every shape must meet the bar on its own, follow the oracle's per-iteration
+    trace, and give the same result wherever a job sits in the batch"""
+    monkeypatch.setenv("PLSVO_ALIGN_THREADS", str(threads))
+    B, W, H = 5, 640, 480
+    streams = [P.synth.make_align_stream(700 + i, W, H, 200 - 30 * i, 80 - 10 * i, max_level=3) for i in range(B)]
+    imgs = P.synth.render_streams(streams).numpy()
+    gpu_ctx.config_pyramids(2 * B, W, H, 4)
+    pyr = []
+    for i in range(B):
+        gpu_ctx.build_pyramid(2 * i, imgs[i, 0], 0)
+        gpu_ctx.build_pyramid(2 * i + 1, imgs[i, 1], 0)
+        pyr.append((gpu_ctx.download_pyramid(2 * i), gpu_ctx.download_pyramid(2 * i + 1)))
+    jobs = [P.align_job_from_stream(s, 3, 1, ref_slot=2 * i, cur_slot=2 * i + 1) for i, s in enumerate(streams)]
+    gpu_ctx.align_set_trace(200)
+    batch = gpu_ctx.sparse_align_batch(jobs)
+    logs = [gpu_ctx.align_fetch_trace(i) for i in range(B)]
+    for i, (st, j) in enumerate(zip(streams, jobs)):
+        ro, lo = ob.sparse_align(j, pyr[i][0], pyr[i][1], max_log=200)
+        n, worst = Hh.compare_align_logs(lo, logs[i])
+        assert n >= 1 and worst["H"] < 2e-5 and worst["chi2"] < 1e-4, (threads, i, worst)
+        ang, tr, ok = Hh.pose_close(Hh.frame_pose(batch[i].T, st), Hh.frame_pose(ro.T, st))
+        assert ok, (threads, i, ang, tr)
+        assert np.array_equal(batch[i].seg_alive, ro.seg_alive)
+    gpu_ctx.align_set_trace(0)
+    single = gpu_ctx.sparse_align(jobs[3])
+    assert np.array_equal(single.T, batch[3].T) and single.n_meas == batch[3].n_meas
+
+
+@pytest.mark.parametrize("threads", [64, 256, 512])
+def test_pose_optimizer_every_launch_shape(P, ob, gpu_ctx, threads, monkeypatch):
+    monkeypatch.setenv("PLSVO_POSEOPT_THREADS", str(threads))
+    for seed, npts, nseg, nref in ((77, 500, 200, -1), (79, 300, 100, 5), (82, 7, 3, -1)):
+        job = P.poseopt_job_from_frame(P.synth.make_poseopt_frame(seed, npts, nseg), n_iter_ref=nref)
+        ro, _ = ob.pose_optimize(job)
+        gpu_ctx.poseopt_set_trace(0)
+        rd = gpu_ctx.pose_optimize(job)
+        assert Hh.pose_close(rd.T, ro.T)[2]
+        assert np.array_equal(rd.pt_keep, ro.pt_keep) and np.array_equal(rd.seg_keep, ro.seg_keep)
+        assert (rd.num_obs_pt, rd.num_obs_ls) == (ro.num_obs_pt, ro.num_obs_ls)
+        assert rd.error_init == pytest.approx(ro.error_init, rel=1e-9) and rd.error_final == pytest.approx(ro.error_final, rel=1e-6)
+        assert Hh.rel(rd.cov, ro.cov) < 1e-6
+
+
 POSE_CASES = [("config5", 77, 500, 200, -1), ("frame-200-80", 78, 200, 80, -1), ("ten-arg", 79, 300, 100, 5),
               ("points-only", 80, 120, 0, -1), ("lines-only", 81, 0, 60, -1), ("tiny", 82, 7, 3, -1)]
 
