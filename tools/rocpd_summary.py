@@ -39,6 +39,20 @@ def main(dbs, out, cmd):
 
 
 
+def per_kernel(dbs, out, cmd):
+    """one row per (kernel, launch shape) of the plsvo kernels, all traced processes together: call count, time, resources"""
+    lines = [f"# rocprofv3 --kernel-trace --stats -- {cmd}", "# extracted from the rocpd databases (view `kernels`); durations in microseconds",
+             "name,grid_x,workgroup_x,calls,total_us,avg_us,min_us,max_us,lds_bytes,arch_vgpr,sgpr,scratch"]
+    for db in dbs.split(","):
+        c = sqlite3.connect(db)
+        q = ("select name, grid_x, workgroup_x, count(*), sum(duration), avg(duration), min(duration), max(duration), max(lds_size), "
+             "max(vgpr_count), max(sgpr_count), max(scratch_size) from kernels where name like '%plsvo%' "
+             "group by name, grid_x, workgroup_x order by sum(duration) desc")
+        for r in c.execute(q):
+            lines.append(f"\"{r[0]}\",{r[1]},{r[2]},{r[3]},{r[4] / 1e3:.1f},{r[5] / 1e3:.1f},{r[6] / 1e3:.1f},{r[7] / 1e3:.1f},{r[8]},{r[9]},{r[10]},{r[11]}")
+    open(out, "w").write("\n".join(lines) + "\n")
+
+
 def counters(dbs, out, cmd, like=None):
     """per-kernel PMC counter totals (rocprofv3 --pmc ... pass) for the plsvo kernels (or kernels matching `like`); dbs comma separated"""
     lines = [f"# rocprofv3 --kernel-trace --pmc <counter> -- {cmd}", "# view counters_collection; one row per dispatch",
@@ -64,5 +78,7 @@ def _counters_one(db, lines, like):
 if __name__ == "__main__":
     if sys.argv[1] == "--counters":
         counters(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "", sys.argv[5] if len(sys.argv) > 5 else None)
+    elif sys.argv[1] == "--per-kernel":
+        per_kernel(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
     else:
         main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")
