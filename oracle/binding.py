@@ -70,6 +70,7 @@ def lib():
             ("plsvo_oracle_se3_exp", [d, d], None), ("plsvo_oracle_se3_mul", [d, d, d], None),
             ("plsvo_oracle_se3_inv", [d, d], None), ("plsvo_oracle_se3_act", [d, d, d], None),
             ("plsvo_oracle_se3_matrix", [d, d, d], None), ("plsvo_oracle_ldlt_solve6", [d, d, d], C.c_int),
+            ("plsvo_oracle_set_ldlt_flavour", [C.c_int], None), ("plsvo_oracle_get_ldlt_flavour", [], C.c_int),
             ("plsvo_oracle_inv6", [d, d], None), ("plsvo_oracle_jacobian_xyz2uv", [d, d], None),
             ("plsvo_oracle_setup_sampling", [d, d, C.c_double, C.c_uint64, d], C.c_uint64),
             ("plsvo_oracle_line_normal", [d, d, d], None), ("plsvo_oracle_scaled_bearing", [d, d, d, d], None),
@@ -276,6 +277,13 @@ def se3_matrix(T):
     t = np.empty(3)
     lib().plsvo_oracle_se3_matrix(_dp(T), _dp(R), _dp(t))
     return R.reshape(3, 3), t
+
+
+def set_ldlt_flavour(flavour):
+    """320 (default; Eigen 3.1...3.2.1) or 330 (Eigen 3.3) zero-pivot rule of ldlt().solve(); returns the previous one"""
+    prev = lib().plsvo_oracle_get_ldlt_flavour()
+    lib().plsvo_oracle_set_ldlt_flavour(int(flavour))
+    return prev
 
 
 def ldlt_solve6(H, b):

@@ -12,6 +12,7 @@
  */
 #include "plsvo_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -142,17 +143,39 @@ void plsvo_oracle_se3_matrix(const double T[7], double R[9], double t[3]) {
 /* [ext] Eigen 3 dense pieces: LDLT with diagonal pivoting (ldlt().solve) and PartialPivLU inverse */
 /* ============================================================================================ */
 
-/* Eigen::LDLT<Matrix6d>::compute (unblocked, lower) followed by solve():
- *   dst = P b;  L^-1;  D^-1 (entries with |d| <= 1/highest() give 0);  L^-T;  P^T.
- * returns 0 always (Eigen reports nothing here); NaN/Inf propagate into x. */
-int plsvo_oracle_ldlt_solve6(const double H[36], const double b[6], double x[6]) {
-  enum { N = 6 };
-  double m[N][N]; int tr[N];
-  for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) m[i][j] = H[i * N + j];
+/* Eigen::LDLT<MatrixNd>::compute (unblocked, lower, N <= 6) followed by solve():
+ *   dst = P b;  L^-1;  D^+ (pseudo-inverse of D);  L^-T;  P^T.
+ * The pivot of step k is the largest |diagonal| of the tail -- of the matrix AS STORED: the algorithm is left-looking, only
+ * column k is updated in step k, so the tail diagonal still holds the (permuted) ORIGINAL entries.  First maximum wins.
+ *
+ * What counts as a zero pivot depends on the Eigen release, and PL-SVO names three platforms (README.md:27: Ubuntu 12.04,
+ * 14.04, 16.04 = libeigen3-dev 3.0.5, 3.2.0, 3.2.92) without pinning one (CMakeLists.txt:40).  Two flavours are restated:
+ *   320 (default; Eigen 3.1 ... 3.2.1, Ubuntu 14.04): cutoff = |eps * largest diagonal| fixed at step 0; the factorisation
+ *       stops when the largest remaining (stored) diagonal is below it; column k is divided by its pivot only if
+ *       |pivot| > cutoff; solve() zeroes the components whose |D| <= max(max|D| * eps, 1/highest()).
+ *   330 (Eigen 3.3): a pivot is invalid only if it is exactly 0; solve() zeroes components with |D| <= 1/highest().
+ * They are the same arithmetic, bit for bit, whenever every pivot exceeds eps * the largest diagonal -- every full-rank system
+ * this path produces (tests/test_oracle_unit.py checks that, and the committed fixtures do not depend on the flavour).  They
+ * differ on rank-deficient normal equations (fewer than three point observations), where 330 divides rounding residue by
+ * rounding residue and 320 returns zero components for the unobservable directions.
+ * NaN/Inf propagate into x. */
+static int g_ldlt_flavour = 320;
+void plsvo_oracle_set_ldlt_flavour(int flavour) { g_ldlt_flavour = (flavour == 330) ? 330 : 320; }
+int plsvo_oracle_get_ldlt_flavour(void) { return g_ldlt_flavour; }
+
+static void ldlt_solve_n(const int N, const double* A, const double* b, double* x) {
+  double m[6][6]; int tr[6];
+  const int flavour = g_ldlt_flavour;
+  double cutoff = 0.0;
+  for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) m[i][j] = A[i * N + j];
   for (int k = 0; k < N; ++k) {
     /* largest |diagonal| in the remaining corner (first maximum wins) */
     int big = k; double bigv = fabs(m[k][k]);
     for (int i = k + 1; i < N; ++i) { const double v = fabs(m[i][i]); if (v > bigv) { bigv = v; big = i; } }
+    if (flavour == 320) {
+      if (k == 0) cutoff = fabs(DBL_EPSILON * bigv);
+      if (bigv < cutoff) { for (int i = k; i < N; ++i) tr[i] = i; break; }   /* "finish early if the matrix is not full rank" */
+    }
     tr[k] = big;
     if (k != big) {
       const int s = N - big - 1;
@@ -163,7 +186,7 @@ int plsvo_oracle_ldlt_solve6(const double H[36], const double b[6], double x[6])
     }
     const int rs = N - k - 1;
     if (k > 0) {
-      double temp[N];
+      double temp[6];
       for (int j = 0; j < k; ++j) temp[j] = m[j][j] * m[k][j];
       double acc = 0.0;
       for (int j = 0; j < k; ++j) acc += m[k][j] * temp[j];
@@ -175,22 +198,37 @@ int plsvo_oracle_ldlt_solve6(const double H[36], const double b[6], double x[6])
       }
     }
     const double akk = m[k][k];
-    const int pivot_is_valid = fabs(akk) > 0.0;
-    if (k == 0 && !pivot_is_valid) { /* the whole diagonal is zero: nothing more to do */
-      for (int j = 0; j < N; ++j) tr[j] = j;
-      break;
+    if (flavour == 320) {
+      if (rs > 0 && fabs(akk) > cutoff) for (int i = k + 1; i < N; ++i) m[i][k] /= akk;
+    } else {
+      const int pivot_is_valid = fabs(akk) > 0.0;
+      if (k == 0 && !pivot_is_valid) { /* the whole diagonal is zero: nothing more to do */
+        for (int j = 0; j < N; ++j) tr[j] = j;
+        break;
+      }
+      if (rs > 0 && pivot_is_valid) for (int i = k + 1; i < N; ++i) m[i][k] /= akk;
     }
-    if (rs > 0 && pivot_is_valid) for (int i = k + 1; i < N; ++i) m[i][k] /= akk;
   }
-  double d[N];
+  double d[6];
   for (int i = 0; i < N; ++i) d[i] = b[i];
   for (int k = 0; k < N; ++k) { const double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
   for (int i = 0; i < N; ++i) for (int j = 0; j < i; ++j) d[i] -= m[i][j] * d[j];
-  const double tolerance = 1.0 / 1.7976931348623157e308;
+  double tolerance = 1.0 / 1.7976931348623157e308;
+  if (flavour == 320) {
+    double maxd = fabs(m[0][0]);
+    for (int i = 1; i < N; ++i) { const double v = fabs(m[i][i]); if (v > maxd) maxd = v; }
+    const double rel = maxd * DBL_EPSILON;
+    if (rel > tolerance) tolerance = rel;   /* (max)(maxAbsD * eps, 1/highest) */
+  }
   for (int i = 0; i < N; ++i) { if (fabs(m[i][i]) > tolerance) d[i] /= m[i][i]; else d[i] = 0.0; }
   for (int i = N - 1; i >= 0; --i) for (int j = i + 1; j < N; ++j) d[i] -= m[j][i] * d[j];
   for (int k = N - 1; k >= 0; --k) { const double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
   for (int i = 0; i < N; ++i) x[i] = d[i];
+}
+
+/* returns 0 always (Eigen reports nothing here) */
+int plsvo_oracle_ldlt_solve6(const double H[36], const double b[6], double x[6]) {
+  ldlt_solve_n(6, H, b, x);
   return 0;
 }
 
@@ -869,47 +907,7 @@ done:
 /* ============================================================================================ */
 
 /* [ext] Eigen::LDLT<Matrix3d>::compute + solve, the 3x3 instance of the algorithm restated above */
-static void ldlt_solve3(const double A[9], const double b[3], double x[3]) {
-  enum { N = 3 };
-  double m[N][N]; int tr[N];
-  for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) m[i][j] = A[i * N + j];
-  for (int k = 0; k < N; ++k) {
-    int big = k; double bigv = fabs(m[k][k]);
-    for (int i = k + 1; i < N; ++i) { const double v = fabs(m[i][i]); if (v > bigv) { bigv = v; big = i; } }
-    tr[k] = big;
-    if (k != big) {
-      for (int j = 0; j < k; ++j) { const double t = m[k][j]; m[k][j] = m[big][j]; m[big][j] = t; }
-      for (int i = big + 1; i < N; ++i) { const double t = m[i][k]; m[i][k] = m[i][big]; m[i][big] = t; }
-      { const double t = m[k][k]; m[k][k] = m[big][big]; m[big][big] = t; }
-      for (int i = k + 1; i < big; ++i) { const double t = m[i][k]; m[i][k] = m[big][i]; m[big][i] = t; }
-    }
-    if (k > 0) {
-      double temp[N];
-      for (int j = 0; j < k; ++j) temp[j] = m[j][j] * m[k][j];
-      double acc = 0.0;
-      for (int j = 0; j < k; ++j) acc += m[k][j] * temp[j];
-      m[k][k] -= acc;
-      for (int i = k + 1; i < N; ++i) {
-        double a2 = 0.0;
-        for (int j = 0; j < k; ++j) a2 += m[i][j] * temp[j];
-        m[i][k] -= a2;
-      }
-    }
-    const double akk = m[k][k];
-    const int pivot_is_valid = fabs(akk) > 0.0;
-    if (k == 0 && !pivot_is_valid) { for (int j = 0; j < N; ++j) tr[j] = j; break; }
-    if (k < N - 1 && pivot_is_valid) for (int i = k + 1; i < N; ++i) m[i][k] /= akk;
-  }
-  double d[N];
-  for (int i = 0; i < N; ++i) d[i] = b[i];
-  for (int k = 0; k < N; ++k) { const double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
-  for (int i = 0; i < N; ++i) for (int j = 0; j < i; ++j) d[i] -= m[i][j] * d[j];
-  const double tolerance = 1.0 / 1.7976931348623157e308;
-  for (int i = 0; i < N; ++i) { if (fabs(m[i][i]) > tolerance) d[i] /= m[i][i]; else d[i] = 0.0; }
-  for (int i = N - 1; i >= 0; --i) for (int j = i + 1; j < N; ++j) d[i] -= m[j][i] * d[j];
-  for (int k = N - 1; k >= 0; --k) { const double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
-  for (int i = 0; i < N; ++i) x[i] = d[i];
-}
+static void ldlt_solve3(const double A[9], const double b[3], double x[3]) { ldlt_solve_n(3, A, b, x); }
 
 /* one observation's contribution: Point::jacobian_xyz2uv (include/plsvo/feature3D.h:126-140),
  * e = project2d(f) - project2d(p_in_f), A += J^T J, b -= J^T e, chi2 += |e|^2  (feature3D_impl.cpp:49-58) */

@@ -6,8 +6,8 @@
 //   pose        = unit quaternion (x,y,z,w) + translation          (Sophus::SE3 storage)
 //   tangent     = (upsilon[0:3], omega[3:6])                       (Sophus::SE3::exp)
 //   compose     = t_A + R_A t_B, normalize(q_A q_B)                (Sophus::SE3::operator*)
-//   6x6 solve   = LDL^T with diagonal pivoting                     (Eigen::LDLT, used by
-//                 src/sparse_img_align.cpp:699 and src/pose_optimizer.cpp:170)
+//   6x6 solve   = LDL^T with diagonal pivoting                     (Eigen::LDLT, src/sparse_img_align.cpp:699 and
+//                 src/pose_optimizer.cpp:170): on the device, plsvo_wave.hpp::wave_solve6_core
 //   6x6 inverse = LU with partial pivoting                         (Eigen inverse(), src/pose_optimizer.cpp:199)
 #pragma once
 
@@ -123,49 +123,6 @@ PLSVO_HD void jacobian_xyz2uv(const double* xyz, double* J) {
   const double z_inv_2 = z_inv * z_inv;
   J[0] = -z_inv; J[1] = 0.0; J[2] = x * z_inv_2; J[3] = y * J[2]; J[4] = -(1.0 + x * J[2]); J[5] = y * z_inv;
   J[6] = 0.0; J[7] = -z_inv; J[8] = y * z_inv_2; J[9] = 1.0 + y * J[8]; J[10] = -J[3]; J[11] = -x * z_inv;
-}
-
-// Solve H x = b for symmetric H (full 6x6 row-major given, lower triangle used), Eigen::LDLT style:
-// diagonal pivoting, unit-lower L, D entries below 1/DBL_MAX treated as zero.  NaN/Inf propagate.
-PLSVO_HD void ldlt_solve6(const double* H, const double* b, double* x) {
-  double m[6][6]; int tr[6];
-  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) m[i][j] = H[i * 6 + j];
-  for (int k = 0; k < 6; ++k) {
-    int big = k; double bigv = fabs(m[k][k]);
-    for (int i = k + 1; i < 6; ++i) { const double v = fabs(m[i][i]); if (v > bigv) { bigv = v; big = i; } }
-    tr[k] = big;
-    if (k != big) {
-      for (int j = 0; j < k; ++j) { const double t = m[k][j]; m[k][j] = m[big][j]; m[big][j] = t; }
-      for (int i = big + 1; i < 6; ++i) { const double t = m[i][k]; m[i][k] = m[i][big]; m[i][big] = t; }
-      { const double t = m[k][k]; m[k][k] = m[big][big]; m[big][big] = t; }
-      for (int i = k + 1; i < big; ++i) { const double t = m[i][k]; m[i][k] = m[big][i]; m[big][i] = t; }
-    }
-    if (k > 0) {
-      double temp[6];
-      for (int j = 0; j < k; ++j) temp[j] = m[j][j] * m[k][j];
-      double acc = 0.0;
-      for (int j = 0; j < k; ++j) acc += m[k][j] * temp[j];
-      m[k][k] -= acc;
-      for (int i = k + 1; i < 6; ++i) {
-        double a2 = 0.0;
-        for (int j = 0; j < k; ++j) a2 += m[i][j] * temp[j];
-        m[i][k] -= a2;
-      }
-    }
-    const double akk = m[k][k];
-    const bool pivot_is_valid = fabs(akk) > 0.0;
-    if (k == 0 && !pivot_is_valid) { for (int j = 0; j < 6; ++j) tr[j] = j; break; }
-    if (k < 5 && pivot_is_valid) for (int i = k + 1; i < 6; ++i) m[i][k] /= akk;
-  }
-  double d[6];
-  for (int i = 0; i < 6; ++i) d[i] = b[i];
-  for (int k = 0; k < 6; ++k) { const double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
-  for (int i = 0; i < 6; ++i) for (int j = 0; j < i; ++j) d[i] -= m[i][j] * d[j];
-  const double tolerance = 1.0 / 1.7976931348623157e308;
-  for (int i = 0; i < 6; ++i) { if (fabs(m[i][i]) > tolerance) d[i] /= m[i][i]; else d[i] = 0.0; }
-  for (int i = 5; i >= 0; --i) for (int j = i + 1; j < 6; ++j) d[i] -= m[j][i] * d[j];
-  for (int k = 5; k >= 0; --k) { const double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
-  for (int i = 0; i < 6; ++i) x[i] = d[i];
 }
 
 // 6x6 inverse through LU with partial pivoting (Eigen PartialPivLU::inverse)

@@ -152,15 +152,20 @@ __device__ __forceinline__ double fast_sqrt(double x) {   // x >= 0, finite; sqr
 // Solve H x = rhs for a symmetric 6x6 H, cooperatively by ONE FULL WAVE (all 64 lanes must be active).
 //   tot[0..20]  upper triangle of H (row-major), tot[21..26] rhs
 //   x[0..5]     result, returned in registers of every lane (wave-uniform)
-// Method: Gauss-Jordan elimination of the augmented 6x7 system with the pivot order of Eigen's LDLT (largest remaining
-// |diagonal| of the Schur complement, lowest index on ties; src/sparse_img_align.cpp:699 and src/pose_optimizer.cpp:170
-// call H.ldlt().solve()).  Lane 8*i+j holds entry (i,j); column 6 is the rhs.
+// Method: Gauss-Jordan elimination of the augmented 6x7 system in the pivot order of Eigen's LDLT (src/sparse_img_align.cpp:699
+// and src/pose_optimizer.cpp:170 call H.ldlt().solve()).  Eigen's unblocked LDLT is left-looking -- step k updates column k
+// only -- so "the largest remaining |diagonal|" it pivots on is the largest remaining ORIGINAL diagonal entry: the order is
+// fixed by the input (descending |H_ii|; on exact ties the first in Eigen's permuted order) and the D entries are the Schur pivots met in that order.
+// Zero pivots follow Eigen 3.1...3.2.1 (libeigen3-dev 3.2.0 of Ubuntu 14.04, one of the three platforms PL-SVO names; the rule
+// under which rank-deficient systems have a reproducible answer at all): with cutoff = eps * largest |H_ii|, the factorisation
+// ends when the next original diagonal is below the cutoff, and a Schur pivot with |d| <= cutoff gives a zero component
+// (solve()'s pseudo-inverse of D: |d| <= max|D| * eps; max|D| is the first pivot for the positive semi-definite H of this
+// path).  Full-rank systems never meet either rule.  NaN/Inf propagate into x; an all-zero system returns x = 0.
+// Lane 8*i+j holds entry (i,j); column 6 is the rhs.
 // The serial part of a Gauss-Newton iteration is one wave issuing dependent instructions at ~4-5 cycles each, so a step
 // is written for instruction count: the pivot is a DPP max over the lanes' own |diagonal| keys + one ballot (no per-row
 // readlanes, no compare chain), its reciprocal comes from fast_rcp while the two ds_bpermute round trips (row p, column p)
 // are in flight, and the update is one multiply + one fma per lane.
-// The pivots are LDLT's D entries; like Eigen's solve, a pivot that is zero (or below 1/DBL_MAX) yields a zero component,
-// so an all-zero system returns x = 0.  NaN/Inf propagate into x.
 __device__ __forceinline__ void wave_solve6_core(double m, double* x);
 
 __device__ __forceinline__ void wave_solve6(const double* tot, double* x) {
@@ -205,18 +210,36 @@ __device__ __forceinline__ void wave_solve6_core(double m, double* x) {
   const int addr_row = 4 * j, addr_col = 4 * 8 * i;      // byte addresses of lanes (p,j) / (i,p) once 32p / 4p is added
   bool diag_active = (i == j) && (i < 6);                // this lane holds a diagonal entry not yet used as pivot
   const bool in_system = (i < 6) && (j <= 6);
+  const double key0 = fabs(m);                           // |original diagonal|: Eigen's pivot order is fixed by the input
+  int pos = diag_active ? i : 64;                        // current position of this diagonal entry under Eigen's transpositions
   unsigned zero_piv = 0u;
+  double cutoff = 0.0;
 #pragma unroll
   for (int step = 0; step < 6; ++step) {
-    // pivot: largest |diagonal| among the rows not yet eliminated, lowest index on ties
-    const double key = diag_active ? fabs(m) : -1.0;
+    // pivot: largest original |diagonal| among the rows not yet eliminated
+    const double key = diag_active ? key0 : -1.0;
     const double kmax = readlane_f64(wave_max_to_lane63(key), 63);
     unsigned long long cand = __ballot(diag_active && key == kmax);
     if (cand == 0ull) cand = __ballot(diag_active);      // every remaining diagonal is NaN: take the first (as a compare chain would)
-    const int plane = __builtin_ctzll(cand);             // lane 9p
+    int plane = __builtin_ctzll(cand);                   // lane 9p
+    if (cand & (cand - 1ull)) {
+      // exactly equal diagonals (points-only pose optimisation: A00 == A11): Eigen's maxCoeff takes the first one in its PERMUTED
+      // order, i.e. the smallest current position -- rare, wave-uniform, so a scalar loop over the tied lanes
+      int best = 64;
+      for (unsigned long long c = cand; c; c &= c - 1ull) {
+        const int l = __builtin_ctzll(c);
+        const int ps = __builtin_amdgcn_readlane(pos, l);
+        if (ps < best) { best = ps; plane = l; }
+      }
+    }
     const int p = (plane * 57) >> 9;                     // plane / 9 for plane in {0, 9, .., 45}
     const double piv = readlane_f64(m, plane);
-    if (fabs(piv) > 0.0) {
+    // Eigen swaps positions `step` and pos[p]: the entry that sat at position `step` moves to where the pivot was
+    const int pos_p = __builtin_amdgcn_readlane(pos, plane);
+    if (pos == step) pos = pos_p;
+    if (step == 0) cutoff = fabs(2.220446049250313e-16 * kmax);
+    // Eigen 3.2: stop at "biggest_in_corner < cutoff"; no scaling unless |pivot| > cutoff; D^+ drops |d| <= max|D| eps
+    if (!(kmax < cutoff) && fabs(piv) > cutoff) {
       const double mp_j = bpermute_f64(addr_row + 32 * p, m);   // M[p][j]
       const double mi_p = bpermute_f64(addr_col + 4 * p, m);    // M[i][p]
       const double rinv = fast_rcp(piv);

@@ -19,46 +19,63 @@
 
 namespace plsvo_hip {
 
-// Eigen::LDLT<Matrix3d> compute + solve (diagonal pivoting), the 3x3 instance of plsvo_math.hpp::ldlt_solve6
+// A.ldlt().solve(b) for a symmetric 3x3 (src/feature3D_impl.cpp:83,146-147; [ext] Eigen::LDLT, release 3.2's zero-pivot rule
+// as in plsvo_wave.hpp::wave_solve6_core), written out on scalars: no arrays, no run-time indexing, nothing in scratch.
+// Eigen's unblocked LDLT pivots on the stored diagonal of the tail, which a left-looking factorisation has not updated yet: the
+// order is a sort of |A00|, |A11|, |A22| (first maximum wins, in the order its own swaps leave behind), applied as two
+// conditional symmetric swaps; the factorisation and the two triangular solves then follow Eigen's operation order term by term
+// (this translation unit is compiled without fma contraction), so the result is the CPU oracle's bit for bit.
 __device__ __forceinline__ void ldlt_solve3(const double* A, const double* b, double* x) {
-  double m[3][3]; int tr[3];
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m[i][j] = A[i * 3 + j];
-  for (int k = 0; k < 3; ++k) {
-    int big = k; double bigv = fabs(m[k][k]);
-    for (int i = k + 1; i < 3; ++i) { const double v = fabs(m[i][i]); if (v > bigv) { bigv = v; big = i; } }
-    tr[k] = big;
-    if (k != big) {
-      for (int j = 0; j < k; ++j) { const double t = m[k][j]; m[k][j] = m[big][j]; m[big][j] = t; }
-      for (int i = big + 1; i < 3; ++i) { const double t = m[i][k]; m[i][k] = m[i][big]; m[i][big] = t; }
-      { const double t = m[k][k]; m[k][k] = m[big][big]; m[big][big] = t; }
-      for (int i = k + 1; i < big; ++i) { const double t = m[i][k]; m[i][k] = m[big][i]; m[big][i] = t; }
+  double a00 = A[0], a10 = A[3], a11 = A[4], a20 = A[6], a21 = A[7], a22 = A[8];   // lower triangle
+  double y0 = b[0], y1 = b[1], y2 = b[2];
+  auto swp = [](double& p, double& q, bool c) { const double t = p; p = c ? q : p; q = c ? t : q; };
+  // step 0: largest of the three diagonals to the front
+  int big0 = 0; double bigv = fabs(a00);
+  if (fabs(a11) > bigv) { bigv = fabs(a11); big0 = 1; }
+  if (fabs(a22) > bigv) { bigv = fabs(a22); big0 = 2; }
+  const double cutoff = fabs(2.220446049250313e-16 * bigv);
+  swp(a00, a11, big0 == 1); swp(a20, a21, big0 == 1);       // rows/columns 0 <-> 1 of the lower triangle: a10 stays
+  swp(a00, a22, big0 == 2); swp(a10, a21, big0 == 2);       // rows/columns 0 <-> 2: a20 stays
+  swp(y0, y1, big0 == 1); swp(y0, y2, big0 == 2);
+  double d0 = a00, l10 = a10, l20 = a20;
+  if (fabs(d0) > cutoff) { l10 = a10 / d0; l20 = a20 / d0; }
+  // step 1 (skipped, like everything after it, once the largest remaining diagonal is below the cutoff)
+  double d1 = a11, l21 = a21, d2 = a22;
+  bool big1 = false;
+  const bool go1 = !(fmax(fabs(a11), fabs(a22)) < cutoff) || fabs(a11) != fabs(a11);
+  if (go1) {
+    big1 = fabs(a22) > fabs(a11);
+    swp(a11, a22, big1); swp(l10, l20, big1);               // rows/columns 1 <-> 2: a21 stays
+    const double t0 = d0 * l10;
+    d1 = a11 - l10 * t0;
+    l21 = a21 - l20 * t0;
+    if (fabs(d1) > cutoff) l21 = l21 / d1;
+    // step 2
+    d2 = a22;
+    if (!(fabs(a22) < cutoff)) {
+      const double u0 = d0 * l20, u1 = d1 * l21;
+      d2 = a22 - (l20 * u0 + l21 * u1);
     }
-    if (k > 0) {
-      double temp[3];
-      for (int j = 0; j < k; ++j) temp[j] = m[j][j] * m[k][j];
-      double acc = 0.0;
-      for (int j = 0; j < k; ++j) acc += m[k][j] * temp[j];
-      m[k][k] -= acc;
-      for (int i = k + 1; i < 3; ++i) {
-        double a2 = 0.0;
-        for (int j = 0; j < k; ++j) a2 += m[i][j] * temp[j];
-        m[i][k] -= a2;
-      }
-    }
-    const double akk = m[k][k];
-    const bool pivot_is_valid = fabs(akk) > 0.0;
-    if (k == 0 && !pivot_is_valid) { for (int j = 0; j < 3; ++j) tr[j] = j; break; }
-    if (k < 2 && pivot_is_valid) for (int i = k + 1; i < 3; ++i) m[i][k] /= akk;
   }
-  double d[3];
-  for (int i = 0; i < 3; ++i) d[i] = b[i];
-  for (int k = 0; k < 3; ++k) { const double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < i; ++j) d[i] -= m[i][j] * d[j];
-  const double tolerance = 1.0 / 1.7976931348623157e308;
-  for (int i = 0; i < 3; ++i) { if (fabs(m[i][i]) > tolerance) d[i] /= m[i][i]; else d[i] = 0.0; }
-  for (int i = 2; i >= 0; --i) for (int j = i + 1; j < 3; ++j) d[i] -= m[j][i] * d[j];
-  for (int k = 2; k >= 0; --k) { const double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
-  for (int i = 0; i < 3; ++i) x[i] = d[i];
+  swp(y1, y2, big1);
+  // P b -> L^-1 -> D^+ -> L^-T -> P^T
+  y1 -= l10 * y0;
+  y2 -= l20 * y0;
+  y2 -= l21 * y1;
+  double maxd = fabs(d0);
+  if (fabs(d1) > maxd) maxd = fabs(d1);
+  if (fabs(d2) > maxd) maxd = fabs(d2);
+  double tolerance = 1.0 / 1.7976931348623157e308;
+  if (maxd * 2.220446049250313e-16 > tolerance) tolerance = maxd * 2.220446049250313e-16;
+  y0 = (fabs(d0) > tolerance) ? y0 / d0 : 0.0;
+  y1 = (fabs(d1) > tolerance) ? y1 / d1 : 0.0;
+  y2 = (fabs(d2) > tolerance) ? y2 / d2 : 0.0;
+  y1 -= l21 * y2;
+  y0 -= l10 * y1;
+  y0 -= l20 * y2;
+  swp(y1, y2, big1);
+  swp(y0, y2, big0 == 2); swp(y0, y1, big0 == 1);
+  x[0] = y0; x[1] = y1; x[2] = y2;
 }
 
 // one observation: Point::jacobian_xyz2uv, e = project2d(f) - project2d(p_in_f), A += J^T J, b -= J^T e, chi2 += |e|^2

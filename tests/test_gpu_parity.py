@@ -274,6 +274,43 @@ def test_sparse_align_edge_cases(P, ob, gpu_ctx):
     assert np.array_equal(rd.seg_alive, ro.seg_alive)
 
 
+@pytest.mark.parametrize("npts", [1, 2, 3])
+def test_sparse_align_fewer_patches_than_unknowns(P, ob, gpu_ctx, npts):
+    """a 4x4 patch constrains two directions of the pose (its 16 Jacobian rows span r0, r1 of the 2x6 projection Jacobian): one or
+    two point patches give rank-2 / rank-4 normal equations.
+      * one patch: Eigen's LDLT (3.2 rule, fixed pivot order -- plsvo_wave.hpp) returns zero components for the four directions it
+        cannot see; the device must return the same components and walk the same path;
+      * two patches: H is a double sum of 32 rank-1 terms, its rounding residue outside the rank-4 span is ~eps * max -- right AT
+        Eigen's cutoff -- so the reference's own step is rounding noise divided by rounding noise under either release's rule
+        (the oracle shows 5 or 6 non-zero components from iteration to iteration).  Checked: same linearisation, finite result;
+      * three patches: full rank, ordinary parity."""
+    st, ref, cur, job = Hh.make_case(ob, 35, 320, 240, npts, 0, 3, 2, 0)
+    ro, lo = ob.sparse_align(job, ref, cur, max_log=120)
+    gpu_ctx.config_pyramids(2, 320, 240, 3)
+    gpu_ctx.upload_pyramid(0, ref)
+    gpu_ctx.upload_pyramid(1, cur)
+    gpu_ctx.align_set_trace(120)
+    rd = gpu_ctx.sparse_align(job)
+    ld = gpu_ctx.align_fetch_trace(0)
+    assert np.all(np.isfinite(rd.T)) and len(ld) >= 1
+    a, b = lo[0], ld[0]
+    assert a["n_meas"] == b["n_meas"] == 16 * npts
+    assert Hh.rel(b["H"], a["H"]) < 2e-5 and Hh.rel(b["Jres"], a["Jres"]) < 2e-5   # (the reference rounds each pixel's Jacobian to float)
+    if npts == 2:
+        return
+    n = Hh.common_prefix(lo, ld)
+    assert n >= 2
+    for a, b in list(zip(lo, ld))[:n]:
+        assert a["n_meas"] == b["n_meas"]
+        if npts == 1:
+            assert np.count_nonzero(a["x"]) <= 2, a["x"]
+        assert np.array_equal(a["x"] == 0.0, b["x"] == 0.0), (a["x"], b["x"])
+        assert np.allclose(b["x"], a["x"], rtol=1e-3, atol=1e-4 * float(np.max(np.abs(lo[0]["x"])))), (a["x"], b["x"])
+    if Hh.same_path(lo, ld):
+        assert Hh.pose_close(rd.T, ro.T)[2], Hh.pose_close(rd.T, ro.T)
+        assert rd.n_meas == ro.n_meas
+
+
 def test_sparse_align_border_features_leave_holes_in_the_slot_table(P, ob, gpu_ctx):
     """points / segment end points inside the 3-pixel border of a COARSE level but not of a fine one (`:216-219`, `:299-301`): their
     slots are holes at the coarse levels and live at the fine ones; points that project outside the current image; segments
@@ -408,6 +445,58 @@ def test_pose_optimizer_matches_oracle(P, ob, gpu_ctx, case):
     a, b = lo[0], ld[0]
     assert Hh.rel(b["A"], a["A"]) < 1e-9 and Hh.rel(b["b"], a["b"]) < 1e-7
     assert abs(a["new_chi2"] - b["new_chi2"]) <= 1e-9 * abs(a["new_chi2"])
+
+
+POSE_DEGENERATE = [("empty", 0, 0), ("one-point", 1, 0), ("two-points", 2, 0), ("one-line", 0, 1), ("three-points", 3, 0), ("two-and-two", 2, 2),
+                   ("large-2000-600", 2000, 600)]
+
+
+@pytest.mark.parametrize("case", POSE_DEGENERATE, ids=[c[0] for c in POSE_DEGENERATE])
+def test_pose_optimizer_degenerate_and_large_sizes(P, ob, gpu_ctx, case):
+    """no observations at all, fewer observations than unknowns (rank-deficient normal equations: the pivoted LDLT's zero pivots
+    give zero components, as Eigen's solve does), and a frame several times the benchmark's size"""
+    tag, npts, nseg = case
+    fr = P.synth.make_poseopt_frame(83, npts, nseg)
+    job = P.poseopt_job_from_frame(fr)
+    ro, lo = ob.pose_optimize(job, max_log=40)
+    gpu_ctx.poseopt_set_trace(40)
+    rd = gpu_ctx.pose_optimize(job)
+    ld = gpu_ctx.poseopt_fetch_trace(0)
+    assert np.all(np.isfinite(rd.T))
+    assert np.array_equal(rd.pt_keep, ro.pt_keep) and np.array_equal(rd.seg_keep, ro.seg_keep)
+    assert (rd.num_obs_pt, rd.num_obs_ls) == (ro.num_obs_pt, ro.num_obs_ls)
+    assert len(ld) == len(lo) and rd.iters == ro.iters
+    assert Hh.pose_close(rd.T, ro.T)[2], (Hh.pose_close(rd.T, ro.T), rd.T, ro.T)
+    assert rd.error_init == pytest.approx(ro.error_init, rel=1e-9, abs=1e-300)
+    for a, b in zip(lo, ld):     # rank-deficient steps stay inside the observable directions: the same zero components, the rest to rounding
+        assert np.array_equal(a["dT"] == 0.0, b["dT"] == 0.0), (tag, a["dT"], b["dT"])
+        assert np.allclose(b["dT"], a["dT"], rtol=1e-6, atol=1e-9 * max(1e-300, float(np.max(np.abs(lo[0]["dT"]))))), (tag, a["dT"], b["dT"])
+    if npts + nseg == 0:
+        assert np.array_equal(rd.T, np.asarray(job.c.T_f_w[:], dtype=np.float64))   # nothing to optimise: the pose comes back untouched
+
+
+def test_pose_optimizer_seed_sweep(P, ob, gpu_ctx):
+    """40 seeds of a 200-point + 80-segment frame: keep masks, counts and iteration counts bit-equal on every seed, poses to 1e-9"""
+    import json, os
+    worst = {"rot_rad": 0.0, "trans_rel": 0.0}
+    gpu_ctx.poseopt_set_trace(0)
+    for seed in range(5000, 5040):
+        fr = P.synth.make_poseopt_frame(seed, 200, 80)
+        job = P.poseopt_job_from_frame(fr)
+        ro, _ = ob.pose_optimize(job, max_log=0)
+        rd = gpu_ctx.pose_optimize(job)
+        assert np.array_equal(rd.pt_keep, ro.pt_keep) and np.array_equal(rd.seg_keep, ro.seg_keep), seed
+        assert (rd.num_obs_pt, rd.num_obs_ls, rd.iters) == (ro.num_obs_pt, ro.num_obs_ls, ro.iters), seed
+        ang, tr, ok = Hh.pose_close(rd.T, ro.T)
+        assert ok and ang < 1e-9 and tr < 1e-9, (seed, ang, tr)
+        assert rd.estimated_scale == pytest.approx(ro.estimated_scale, rel=1e-6)
+        worst["rot_rad"] = max(worst["rot_rad"], ang); worst["trans_rel"] = max(worst["trans_rel"], tr)
+    out = {"what": "40 seeds (5000..5039), 200 points + 80 segments, pose_optimizer::optimizeGaussNewton: HIP path vs CPU oracle; keep masks, "
+                   "observation counts and iteration counts equal on every seed", "worst": worst}
+    root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(root, "gpurun_out", "poseopt_seed_sweep.json"), "w"), indent=1)
+    print(json.dumps(out))
 
 
 def test_pose_optimizer_known_answer(P, gpu_ctx):

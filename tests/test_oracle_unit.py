@@ -217,3 +217,49 @@ def test_tukey_and_mad_closed_forms(ob):
         v = np.abs(rng.normal(0, 1, n)).astype(np.float32)
         assert ob.mad_scale(v) == pytest.approx(1.48 * float(np.sort(v)[n // 2]), rel=1e-6)
         assert ob.median_f64(v.astype(np.float64)) == float(np.sort(v.astype(np.float64))[n // 2])
+
+
+def test_ldlt_zero_pivot_rules_of_the_two_eigen_releases(ob, P):
+    """PL-SVO does not pin an Eigen release (README.md:27 names Ubuntu 12.04 / 14.04 / 16.04), and ldlt().solve() treats zero pivots
+    differently in 3.2 (relative cutoff, eps * largest diagonal) and 3.3 (exact zero only).  The oracle restates both (default 320):
+      * on full-rank systems -- everything this path produces with three or more point observations -- the two are the same
+        arithmetic bit for bit, so neither the fixtures nor the parity tests depend on the choice;
+      * on rank-deficient normal equations the 3.2 rule returns a basic solution: exact zeros for the directions whose pivots are
+        rounding residue, and the remaining components solve the reduced system."""
+    rng = np.random.default_rng(21)
+    assert ob.set_ldlt_flavour(320) in (320, 330)
+    try:
+        for cond_pow in (0, 0, 3, 6, 9, 12):
+            A = rng.normal(0, 1, (30, 6)) * np.logspace(0, -cond_pow / 2.0, 6)
+            H = A.T @ A
+            b = rng.normal(0, 1, 6)
+            ob.set_ldlt_flavour(320); x320 = ob.ldlt_solve6(H, b)
+            ob.set_ldlt_flavour(330); x330 = ob.ldlt_solve6(H, b)
+            assert np.array_equal(x320, x330), cond_pow
+        # rank 2 (one point observation) and rank 4 with an exact diagonal tie (two point observations: H00 == H11 = sum 1/z^2)
+        for n_obs, rank in ((1, 2), (2, 4)):
+            pts = rng.uniform([-1, -1, 2], [1, 1, 6], (n_obs, 3))
+            Js = [ob.jacobian_xyz2uv(p) for p in pts]
+            H = sum(J.T @ J for J in Js)
+            b = sum(J.T @ rng.normal(0, 1e-2, 2) for J in Js)
+            if n_obs == 2:
+                assert H[0, 0] == H[1, 1]
+            ob.set_ldlt_flavour(320)
+            x = ob.ldlt_solve6(H, b)
+            v = np.flatnonzero(x != 0.0)
+            assert len(v) == rank, (n_obs, x)
+            assert np.allclose(H[np.ix_(v, v)] @ x[v], b[v], rtol=1e-9, atol=1e-14)
+            assert np.linalg.norm(H @ x - b) <= 1e-9 * np.linalg.norm(b)      # b is in the range of H: a basic solution is exact
+        # a whole frame: identical under both rules when it is full rank
+        fr = P.synth.make_poseopt_frame(78, 60, 20)
+        job = P.poseopt_job_from_frame(fr)
+        ob.set_ldlt_flavour(320); r320, _ = ob.pose_optimize(job)
+        ob.set_ldlt_flavour(330); r330, _ = ob.pose_optimize(job)
+        assert np.array_equal(r320.T, r330.T) and np.array_equal(r320.pt_keep, r330.pt_keep) and r320.iters == r330.iters
+        # one point observation: the 3.2 rule keeps the step inside the two observable directions
+        ob.set_ldlt_flavour(320)
+        job = P.poseopt_job_from_frame(P.synth.make_poseopt_frame(83, 1, 0))
+        r, log = ob.pose_optimize(job, max_log=10)
+        assert all(np.count_nonzero(rec["dT"]) <= 2 for rec in log[:3]) and r.error_final < 1e-9
+    finally:
+        ob.set_ldlt_flavour(320)

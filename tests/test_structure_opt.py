@@ -109,6 +109,14 @@ def test_hip_structure_optimize_edge_cases(P, ob, gpu_ctx):
     job = P.structopt_job_from_batch(d)
     ro, rd = ob.structure_optimize(job), gpu_ctx.structure_optimize(job)
     assert np.array_equal(rd["pt_pos"], ro["pt_pos"]) and np.array_equal(rd["seg_spos"], ro["seg_spos"])
+    # landmarks with ONE observation: rank-2 3x3 normal equations -- A.ldlt().solve(b) returns a zero component for the depth
+    # direction (Eigen 3.2's zero-pivot rule, oracle flavour 320) and the device must return the same bits
+    d = P.synth.make_structure_batch(23, n_pts=6, n_seg=0)
+    d["pt_obs_off"] = np.arange(7, dtype=np.int32)
+    job1 = P.structopt_job_from_batch(d)
+    ro, rd = ob.structure_optimize(job1), gpu_ctx.structure_optimize(job1)
+    assert np.all(np.isfinite(ro["pt_pos"]))
+    assert np.array_equal(rd["pt_pos"], ro["pt_pos"]) and np.array_equal(rd["pt_iters"], ro["pt_iters"])
     job0 = P.structopt_job_from_batch(P.synth.make_structure_batch(22, 4, 4), 0, 0)
     rd = gpu_ctx.structure_optimize(job0)
     assert np.array_equal(rd["pt_pos"], job0.pt_pos)
