@@ -58,10 +58,14 @@ __device__ __forceinline__ void load_row7(const uint8_t* img, int off, float* o7
   o7[6] = (float)((w1 >> 16) & 0xffu);
 }
 
-// wTL*a + wTR*b + wBL*c + wBR*d, evaluated left to right in float without contraction
-// (src/sparse_img_align.cpp:251, 458, 620)
+// wTL*a + wTR*b + wBL*c + wBR*d, evaluated left to right in float, every product and every sum rounded on its own
+// (src/sparse_img_align.cpp:251, 458, 620).  HIP's __fmul_rn / __fadd_rn are plain `*` / `+` and hipcc contracts by default, so
+// the guarantee comes from the pragma: without it the compiler fused different products at the two call sites, and a static
+// camera (cur == ref, T = I) saw one-ulp residuals where the reference sees exact zeros (tests: static-camera cases).
 __device__ __forceinline__ float bilinear(float wTL, float wTR, float wBL, float wBR, float a, float b, float c, float d) {
-  return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(wTL, a), __fmul_rn(wTR, b)), __fmul_rn(wBL, c)), __fmul_rn(wBR, d));
+#pragma clang fp contract(off)
+  const float p0 = wTL * a, p1 = wTR * b, p2 = wBL * c, p3 = wBR * d;
+  return ((p0 + p1) + p2) + p3;
 }
 
 // (float)(1.0 / (1.0 + (double)a)) for a float a >= 0 -- the reference's robust weight

@@ -214,6 +214,7 @@ __device__ __forceinline__ void wave_solve6_core(double m, double* x) {
   int pos = diag_active ? i : 64;                        // current position of this diagonal entry under Eigen's transpositions
   unsigned zero_piv = 0u;
   double cutoff = 0.0;
+  int last_p = 0;
 #pragma unroll
   for (int step = 0; step < 6; ++step) {
     // pivot: largest original |diagonal| among the rows not yet eliminated
@@ -248,10 +249,17 @@ __device__ __forceinline__ void wave_solve6_core(double m, double* x) {
       zero_piv |= 1u << p;
     }
     diag_active = diag_active && (i != p);
+    last_p = p;
   }
   const double dgi = bpermute_f64(addr_col + 4 * i, m);     // M[i][i]
   const double tolerance = 1.0 / 1.7976931348623157e308;
-  const double xi = (((zero_piv >> i) & 1u) || !(fabs(dgi) > tolerance)) ? ((dgi != dgi || m != m) ? (m + dgi) : 0.0) : m / dgi;   // lanes 8i+6: m = rhs
+  double xi = (((zero_piv >> i) & 1u) || !(fabs(dgi) > tolerance)) ? ((dgi != dgi || m != m) ? (m + dgi) : 0.0) : m / dgi;   // lanes 8i+6: m = rhs
+  // An infinite diagonal (a line whose mean |residual| is exactly 0 -- a static camera -- makes `H += H_line * w / res_`,
+  // src/sparse_img_align.cpp:681, divide by zero): Eigen's cutoff and solve() tolerance are then inf as well, no column is scaled,
+  // D^+ zeroes every component and the back-substitution multiplies those zeros with the infinite L entries: NaN everywhere
+  // except in the component pivoted last (nothing left to subtract) and in components whose own row is finite.  x[0] = NaN is what
+  // makes the reference set stop_ (:700).
+  if (cutoff > 1.7976931348623157e308) xi = (i == last_p || fabs(dgi) <= 1.7976931348623157e308) ? 0.0 : __builtin_nan("");
 #pragma unroll
   for (int r = 0; r < 6; ++r) x[r] = readlane_f64(xi, 8 * r + 6);
 }

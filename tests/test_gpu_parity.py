@@ -311,6 +311,75 @@ def test_sparse_align_fewer_patches_than_unknowns(P, ob, gpu_ctx, npts):
         assert rd.n_meas == ro.n_meas
 
 
+def _adversarial_jobs(P, st):
+    """(tag, job, images identical?) -- inputs on which the reference's arithmetic leaves the well-behaved range"""
+    I = np.array([0, 0, 0, 1, 0, 0, 0.0])
+
+    def job_of(max_level=2, min_level=0, n_iter=30, **over):
+        a = dict(pt_px=st.pt_px, pt_xyz_ref=st.pt_xyz_ref, seg_spx=st.seg_spx, seg_epx=st.seg_epx, seg_len=st.seg_len,
+                 seg_p_ref=st.seg_p_ref, seg_q_ref=st.seg_q_ref, T_init=st.T_init)
+        a.update(over)
+        return P.abi.AlignJob(st.cam, max_level, min_level, n_iter, 1e-6, a["T_init"], a["pt_px"], a["pt_xyz_ref"], a["seg_spx"], a["seg_epx"],
+                              a["seg_len"], a["seg_p_ref"], a["seg_q_ref"])
+    out = []
+    # a static camera: cur == ref and T = I.  Every residual is exactly 0, a line's mean |res| is 0 and `H += H_line * w / res_`
+    # (:681) divides by it: H becomes inf/NaN, x[0] is NaN, the solver sets stop_ (:700) and leaves the pose alone
+    out.append(("static-camera", job_of(T_init=I), True))
+    out.append(("static-camera-points-only", P.abi.AlignJob(st.cam, 2, 0, 30, 1e-6, I, st.pt_px, st.pt_xyz_ref, st.seg_spx[:0], st.seg_epx[:0],
+                                                            st.seg_len[:0], st.seg_p_ref[:0], st.seg_q_ref[:0]), True))
+    x = st.pt_xyz_ref.copy(); x[:5, 2] *= -1
+    out.append(("points-behind-the-camera", job_of(pt_xyz_ref=x), False))
+    x = st.pt_xyz_ref.copy(); x[:5] = 0
+    out.append(("zero-depth-points", job_of(pt_xyz_ref=x), False))
+    x = st.pt_xyz_ref.copy(); x[3, 1] = np.nan
+    out.append(("nan-point", job_of(pt_xyz_ref=x), False))
+    T = st.T_init.copy(); T[5] = np.nan
+    out.append(("nan-pose", job_of(T_init=T), False))
+    e = st.seg_epx.copy(); e[:3] = st.seg_spx[:3]
+    L = st.seg_len.copy(); L[:3] = 0
+    out.append(("zero-length-segments", job_of(seg_epx=e, seg_len=L), False))
+    e = st.seg_epx.copy(); e[:3] = st.seg_spx[:3] + [2.0, 1.0]
+    out.append(("three-pixel-segments", job_of(seg_epx=e, seg_len=np.linalg.norm(e - st.seg_spx, axis=1)), False))
+    out.append(("no-iterations", job_of(n_iter=0), False))
+    out.append(("one-iteration", job_of(n_iter=1), False))
+    out.append(("level-0-only", job_of(max_level=0, min_level=0), False))
+    T = st.T_init.copy(); T[4:] += [3.0, 0, 0]
+    out.append(("start-3-m-off", job_of(T_init=T), False))
+    p = st.pt_px.copy(); p[:4] = [[-50, 20], [400, 100], [100, -3], [100, 900]]
+    out.append(("feature-pixels-outside-the-image", job_of(pt_px=p), False))
+    return out
+
+
+def test_sparse_align_adversarial_inputs(P, ob, gpu_ctx):
+    """inputs that drive the reference's arithmetic through inf / NaN / empty sets: the device must take the same decisions (stop_
+    flag path, culls, measurement counts) and return the same pose -- NaN where the reference returns NaN"""
+    st, ref, cur, _ = Hh.make_case(ob, 36, 320, 240, 40, 12, 3, 2, 0)
+    gpu_ctx.config_pyramids(2, 320, 240, 3)
+    gpu_ctx.upload_pyramid(0, ref)
+    for tag, job, static in _adversarial_jobs(P, st):
+        gpu_ctx.upload_pyramid(1, ref if static else cur)
+        ro, lo = ob.sparse_align(job, ref, ref if static else cur, max_log=200)
+        gpu_ctx.align_set_trace(200)
+        rd = gpu_ctx.sparse_align(job)
+        ld = gpu_ctx.align_fetch_trace(0)
+        To, Td = np.asarray(ro.T, float), np.asarray(rd.T, float)
+        assert np.array_equal(np.isnan(To), np.isnan(Td)), (tag, To, Td)
+        assert np.array_equal(rd.seg_alive, ro.seg_alive), tag
+        n = Hh.common_prefix(lo, ld)
+        assert n == min(len(lo), len(ld)) or n >= 1, (tag, n, len(lo), len(ld))
+        for a, b in list(zip(lo, ld))[:n]:
+            assert a["n_meas"] == b["n_meas"] and a["accepted"] == b["accepted"], (tag, a["level"], a["iter"])
+            assert np.array_equal(np.isnan(a["x"]), np.isnan(b["x"])) or not a["accepted"], (tag, a["x"], b["x"])
+        if Hh.same_path(lo, ld):
+            assert (rd.n_meas, rd.n_tracked, rd.iters_per_level) == (ro.n_meas, ro.n_tracked, ro.iters_per_level), tag
+            ok = ~np.isnan(To)
+            if ok.all():
+                assert Hh.pose_close(Td, To)[2], (tag, Hh.pose_close(Td, To))
+        else:
+            assert tag not in ("static-camera", "static-camera-points-only", "nan-pose", "no-iterations", "one-iteration"), tag
+            assert Hh.pose_close(Td, To)[2], (tag, Hh.pose_close(Td, To))
+
+
 def test_sparse_align_border_features_leave_holes_in_the_slot_table(P, ob, gpu_ctx):
     """points / segment end points inside the 3-pixel border of a COARSE level but not of a fine one (`:216-219`, `:299-301`): their
     slots are holes at the coarse levels and live at the fine ones; points that project outside the current image; segments
@@ -473,6 +542,47 @@ def test_pose_optimizer_degenerate_and_large_sizes(P, ob, gpu_ctx, case):
         assert np.allclose(b["dT"], a["dT"], rtol=1e-6, atol=1e-9 * max(1e-300, float(np.max(np.abs(lo[0]["dT"]))))), (tag, a["dT"], b["dT"])
     if npts + nseg == 0:
         assert np.array_equal(rd.T, np.asarray(job.c.T_f_w[:], dtype=np.float64))   # nothing to optimise: the pose comes back untouched
+
+
+def test_pose_optimizer_adversarial_inputs(P, ob, gpu_ctx):
+    """noise-free data at the true pose (every error ~1e-14, the MAD scale with it), NaN pose, far outliers, identical
+    observations, zero iterations: same masks, counts, iteration counts and NaN pattern as the reference"""
+    import copy
+    cases = []
+    cases.append(("exact-data-exact-start", P.synth.make_poseopt_frame(95, 60, 20, noise_px=0.0, outlier_frac=0.0, pert_t=0.0, pert_r=0.0), {}))
+    cases.append(("exact-points-only", P.synth.make_poseopt_frame(95, 60, 0, noise_px=0.0, outlier_frac=0.0, pert_t=0.0, pert_r=0.0), {}))
+    cases.append(("exact-data-start-off", P.synth.make_poseopt_frame(95, 60, 20, noise_px=0.0, outlier_frac=0.0), {}))
+    fr = P.synth.make_poseopt_frame(96, 60, 20)
+    # (NaN observations are not compared: vk::getMedian runs std::nth_element over floats that contain NaN -- not a strict weak
+    #  ordering, the reference's scale is undefined there)
+    f3 = copy.copy(fr); f3.pt_pos = fr.pt_pos.copy(); f3.pt_pos[:5] = 1e6
+    cases.append(("far-outliers", f3, {}))
+    f4 = copy.copy(fr); f4.T_init = fr.T_init.copy(); f4.T_init[6] = np.nan
+    cases.append(("nan-pose", f4, {}))
+    f5 = copy.copy(fr); f5.pt_pos = np.repeat(fr.pt_pos[:1], len(fr.pt_pos), 0); f5.pt_f = np.repeat(fr.pt_f[:1], len(fr.pt_f), 0)
+    cases.append(("identical-points", f5, {}))
+    cases.append(("zero-iterations", fr, {"n_iter": 0}))
+    gpu_ctx.poseopt_set_trace(0)
+    for tag, f, kw in cases:
+        job = P.poseopt_job_from_frame(f, **kw)
+        ro, _ = ob.pose_optimize(job)
+        rd = gpu_ctx.pose_optimize(job)
+        assert np.array_equal(np.isnan(rd.T), np.isnan(ro.T)), (tag, rd.T, ro.T)
+        assert np.array_equal(rd.pt_keep, ro.pt_keep) and np.array_equal(rd.seg_keep, ro.seg_keep), tag
+        assert (rd.num_obs_pt, rd.num_obs_ls, rd.iters) == (ro.num_obs_pt, ro.num_obs_ls, ro.iters), tag
+        if not np.isnan(ro.T).any():
+            assert Hh.pose_close(rd.T, ro.T)[2], (tag, Hh.pose_close(rd.T, ro.T))
+        if tag.startswith("exact-"):
+            # every error is rounding residue of the projection (1e-14 and below; the device rotates with a matrix, Sophus with the
+            # quaternion), the MAD scale with it, and the reference's line Jacobian divides by e.norm() (:156-157): whether a line's
+            # float ds, de come out as 1e-17 or as exact zeros -- 0/0, a NaN step, a rolled-back iteration, a NaN covariance --
+            # is decided by the last bit.  Pose, masks, counts and iteration counts (checked above) do not depend on it.
+            continue
+        for a, b in ((rd.error_init, ro.error_init), (rd.error_final, ro.error_final), (rd.estimated_scale, ro.estimated_scale)):
+            assert (np.isnan(a) and np.isnan(b)) or a == pytest.approx(b, rel=1e-5), (tag, a, b)
+        assert np.array_equal(np.isnan(rd.cov), np.isnan(ro.cov)), tag
+        if not np.isnan(ro.cov).any():
+            assert Hh.rel(rd.cov, ro.cov) < 1e-6, tag
 
 
 def test_pose_optimizer_seed_sweep(P, ob, gpu_ctx):
