@@ -445,6 +445,75 @@ def test_sparse_align_batch_equals_single(P, ob, gpu_ctx):
         assert Hh.pose_close(batch[i].T, ro.T)[2]
 
 
+def test_sparse_align_mixed_batch_with_degenerate_jobs(P, ob, gpu_ctx):
+    """a batch that mixes ordinary jobs with a job without features, a one-patch job (rank-2 H), a static-camera job (infinite H,
+    stop_ path) and a job whose features are all invisible: every job's result equals its single-job result bit for bit"""
+    W, H = 320, 240
+    streams = [P.synth.make_align_stream(520 + i, W, H, 40, 10, max_level=2) for i in range(3)]
+    imgs = P.synth.render_streams(streams).numpy()
+    gpu_ctx.config_pyramids(6, W, H, 3)
+    for i in range(3):
+        gpu_ctx.build_pyramid(2 * i, imgs[i, 0], 0)
+        gpu_ctx.build_pyramid(2 * i + 1, imgs[i, 1], 0)
+    st = streams[0]
+    I = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    none2, none3, none1 = np.zeros((0, 2)), np.zeros((0, 3)), np.zeros(0)
+
+    def job(s, ref_slot, cur_slot, T=None, pts=slice(None), segs=slice(None), pt_px=None):
+        return P.abi.AlignJob(s.cam, 2, 0, 30, 1e-6, s.T_init if T is None else T, s.pt_px[pts] if pt_px is None else pt_px, s.pt_xyz_ref[pts],
+                              s.seg_spx[segs], s.seg_epx[segs], s.seg_len[segs], s.seg_p_ref[segs], s.seg_q_ref[segs],
+                              ref_slot=ref_slot, cur_slot=cur_slot)
+    jobs = [job(streams[0], 0, 1),
+            job(st, 0, 1, pts=slice(0, 0), segs=slice(0, 0)),               # no features
+            job(streams[1], 2, 3),
+            job(st, 0, 1, pts=slice(0, 1), segs=slice(0, 0)),               # one patch
+            job(st, 0, 0, T=I),                                             # static camera: cur slot == ref slot
+            job(st, 0, 1, segs=slice(0, 0), pt_px=np.full((40, 2), 1.0)),   # every point inside the border: no measurement
+            job(streams[2], 4, 5)]
+    gpu_ctx.align_set_trace(0)
+    batch = gpu_ctx.sparse_align_batch(jobs)
+    for i, j in enumerate(jobs):
+        single = gpu_ctx.sparse_align(j)
+        assert np.array_equal(single.T, batch[i].T, equal_nan=True), i
+        assert single.n_meas == batch[i].n_meas and single.iters_per_level == batch[i].iters_per_level, i
+        assert np.array_equal(single.seg_alive, batch[i].seg_alive), i
+    assert batch[1].n_meas == 0 and np.array_equal(batch[1].T, st.T_init)
+    assert batch[5].n_meas == 0
+    assert np.array_equal(batch[4].T, I)                                   # stop_ at the first iteration of every level: pose untouched
+
+
+def test_errors_are_reported_not_swallowed(P, gpu_ctx):
+    """the C ABI's error behaviour: bad levels, slots out of range, a camera that does not match the pyramids, more features than the
+    slot tables can hold -- each one is an error code + message at the call that can detect it, and the context stays usable"""
+    W, H = 320, 240
+    st = P.synth.make_align_stream(530, W, H, 40, 10, max_level=2)
+    imgs = P.synth.render_streams([st]).numpy()
+    gpu_ctx.config_pyramids(2, W, H, 3)
+    gpu_ctx.build_pyramid(0, imgs[0, 0], 0)
+    gpu_ctx.build_pyramid(1, imgs[0, 1], 0)
+    good = P.align_job_from_stream(st, 2, 0)
+
+    def expect(code, fn):
+        with pytest.raises(P.capi.PlsvoError) as e:
+            fn()
+        assert e.value.code == code, (e.value.code, str(e.value))
+        assert len(str(e.value)) > 20
+    expect(P.abi.E_INVALID, lambda: gpu_ctx.sparse_align(P.align_job_from_stream(st, 5, 0)))             # level 5 of a 3-level pyramid
+    expect(P.abi.E_INVALID, lambda: gpu_ctx.sparse_align(P.align_job_from_stream(st, 1, 2)))             # max_level < min_level
+    expect(P.abi.E_CAPACITY, lambda: gpu_ctx.sparse_align(P.align_job_from_stream(st, 2, 0, ref_slot=0, cur_slot=7)))
+    wrong_cam = (st.cam[0], st.cam[1], st.cam[2], st.cam[3], 640, 480)
+    expect(P.abi.E_INVALID, lambda: gpu_ctx.sparse_align(P.abi.AlignJob(wrong_cam, 2, 0, 30, 1e-6, st.T_init, st.pt_px, st.pt_xyz_ref, st.seg_spx,
+                                                                        st.seg_epx, st.seg_len, st.seg_p_ref, st.seg_q_ref)))
+    n = 40000                                                                                             # 40000 patch slots: 480 KB of tables
+    rng = np.random.default_rng(1)
+    px = np.stack([rng.uniform(20, W - 20, n), rng.uniform(20, H - 20, n)], axis=1)
+    xyz = np.concatenate([(px - [st.cam[2], st.cam[3]]) / [st.cam[0], st.cam[1]], np.ones((n, 1))], axis=1) * 3.0
+    big = P.abi.AlignJob(st.cam, 2, 0, 30, 1e-6, st.T_init, px, xyz, st.seg_spx[:0], st.seg_epx[:0], st.seg_len[:0], st.seg_p_ref[:0], st.seg_q_ref[:0])
+    expect(P.abi.E_CAPACITY, lambda: gpu_ctx.sparse_align(big))
+    r = gpu_ctx.sparse_align(good)                                                                        # the context still works
+    assert r.n_meas > 0 and np.all(np.isfinite(r.T))
+
+
 @pytest.mark.parametrize("threads", [64, 128, 256, 512])
 def test_sparse_align_every_launch_shape(P, ob, gpu_ctx, threads, monkeypatch):
     """the library picks 64 / 128 / 256 / 512 threads per frame from the batch size (64: one wave per frame, no workgroup barrier
