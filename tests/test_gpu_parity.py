@@ -60,9 +60,9 @@ def test_sparse_align_matches_oracle(P, ob, gpu_ctx, case):
     # per-iteration linearisation while the two GN paths coincide
     n, worst = Hh.compare_align_logs(log_o, log_d)
     assert n >= 1
-    # (the two traces are evaluated at poses that drift apart by ~1e-7 per iteration, and the device sums
-    #  |res| per line in tree order, so agreement here is float-epsilon level, not double-epsilon level)
-    assert worst["H"] < 2e-5 and worst["Jres"] < 1e-3 and worst["chi2"] < 1e-4, worst
+    # measured: <= 7e-11 on the BASELINE workloads (6e-8 in the last shared record before two paths part); segments-only inputs
+    # are dominated by the per-line float sum of |res| (tree order on the device, sequential in the reference): 1e-6
+    assert worst["H"] < (1e-5 if tag.startswith("lines-only") else 1e-6) and worst["Jres"] < 1e-3 and worst["chi2"] < 1e-4, worst
     # final pose: the parity bar, on the pose run() writes back (cur_frame->T_f_w_, :92)
     ang, tr, ok = Hh.pose_close(Hh.frame_pose(res_d.T, st), Hh.frame_pose(res_o.T, st))
     # a diverged alignment (the oracle itself ends > 0.1 rad from where it started): the bar scales with the step both sides took
@@ -81,7 +81,7 @@ def test_sparse_align_matches_oracle(P, ob, gpu_ctx, case):
         if Hh.same_path(log_o, log_d):
             # same Gauss-Newton path: what is left is summation order, two orders of magnitude inside the bar
             # (1e-8 on the BASELINE workloads, 2e-7 on the 24-point 160x120 case)
-            assert ang < 1e-6 and tr < 1e-6 and ang2 < 1e-6 and tr2 < 1e-4, f"{tag}: same path but rot {ang:.3e} / {ang2:.3e}, trans {tr:.3e} / {tr2:.3e}"
+            assert ang < 1e-8 and tr < 1e-7 and ang2 < 1e-8 and tr2 < 1e-5, f"{tag}: same path but rot {ang:.3e} / {ang2:.3e}, trans {tr:.3e} / {tr2:.3e}"
     # culled segments (LineFeat::feat3D = NULL) and tracked count
     assert np.array_equal(res_d.seg_alive, res_o.seg_alive)
     assert res_d.status == res_o.status
@@ -115,7 +115,7 @@ def test_config2_seed_sweep_meets_the_pose_bar_on_every_seed(P, ob, gpu_ctx):
         assert ok, f"seed {seed}: rot {ang:.3e} rad, trans rel {tr:.3e}"
         assert np.array_equal(res_d.seg_alive, res_o.seg_alive), seed
         n, w = Hh.compare_align_logs(log_o, log_d)      # asserts n_meas equality on every shared iteration
-        assert n >= 1 and w["H"] < 2e-5, (seed, w)
+        assert n >= 1 and w["H"] < 1e-6, (seed, w)
         if ang > worst["rot_rad"]:
             worst["rot_rad"], worst["seed_rot"] = ang, seed
         if tr > worst["trans_rel"]:
@@ -228,10 +228,10 @@ def test_sparse_align_single_linearisation(P, ob, gpu_ctx):
     assert a["n_meas"] == b["n_meas"]
     # same pose on both sides: the only differences are the summation order of the per-line mean |res|
     # (float) and of chi2 (the oracle sums thousands of floats sequentially)
-    assert Hh.rel(b["H"], a["H"]) < 2e-6
-    assert Hh.rel(b["Jres"], a["Jres"]) < 2e-6
+    assert Hh.rel(b["H"], a["H"]) < 1e-9          # (measured 1e-12 ... 6e-12: the float residuals and gradients are the oracle's bit for bit)
+    assert Hh.rel(b["Jres"], a["Jres"]) < 1e-7
     assert abs(a["new_chi2"] - b["new_chi2"]) <= 5e-6 * abs(a["new_chi2"])
-    assert np.max(np.abs(a["x"] - b["x"])) < 1e-6
+    assert np.max(np.abs(a["x"] - b["x"])) < 1e-8
 
 
 def test_sparse_align_edge_cases(P, ob, gpu_ctx):
@@ -295,7 +295,7 @@ def test_sparse_align_fewer_patches_than_unknowns(P, ob, gpu_ctx, npts):
     assert np.all(np.isfinite(rd.T)) and len(ld) >= 1
     a, b = lo[0], ld[0]
     assert a["n_meas"] == b["n_meas"] == 16 * npts
-    assert Hh.rel(b["H"], a["H"]) < 2e-5 and Hh.rel(b["Jres"], a["Jres"]) < 2e-5   # (the reference rounds each pixel's Jacobian to float)
+    assert Hh.rel(b["H"], a["H"]) < 1e-9 and Hh.rel(b["Jres"], a["Jres"]) < 1e-7
     if npts == 2:
         return
     n = Hh.common_prefix(lo, ld)
@@ -413,7 +413,7 @@ def test_sparse_align_border_features_leave_holes_in_the_slot_table(P, ob, gpu_c
     rd = gpu_ctx.sparse_align(job)
     ld = gpu_ctx.align_fetch_trace(0)
     n, worst = Hh.compare_align_logs(lo, ld)            # asserts n_meas equality per shared iteration
-    assert n >= 3 and worst["H"] < 2e-5 and worst["chi2"] < 1e-4, worst
+    assert n >= 3 and worst["H"] < 1e-6 and worst["chi2"] < 1e-4, worst
     per_level = {r["level"]: r["n_meas"] for r in lo}
     assert per_level[3] < per_level[2] < per_level[1], "the case must gain measurements from level to level (border bands)"
     assert np.array_equal(rd.seg_alive, ro.seg_alive) and not rd.seg_alive[[3, 17, 39]].any()
@@ -536,7 +536,7 @@ def test_sparse_align_every_launch_shape(P, ob, gpu_ctx, threads, monkeypatch):
     for i, (st, j) in enumerate(zip(streams, jobs)):
         ro, lo = ob.sparse_align(j, pyr[i][0], pyr[i][1], max_log=200)
         n, worst = Hh.compare_align_logs(lo, logs[i])
-        assert n >= 1 and worst["H"] < 2e-5 and worst["chi2"] < 1e-4, (threads, i, worst)
+        assert n >= 1 and worst["H"] < 1e-6 and worst["chi2"] < 1e-4, (threads, i, worst)
         ang, tr, ok = Hh.pose_close(Hh.frame_pose(batch[i].T, st), Hh.frame_pose(ro.T, st))
         assert ok, (threads, i, ang, tr)
         assert np.array_equal(batch[i].seg_alive, ro.seg_alive)
