@@ -87,6 +87,71 @@ def ldlt_solve(H, b):
     return np.linalg.solve(H, b)
 
 
+def eigen32_ldlt_solve(H, b):
+    """A.ldlt().solve(b) as Eigen 3.1 ... 3.2.1 compute it, written from the mathematics rather than from the in-place code:
+    Eigen's unblocked LDLT is left-looking, so the diagonal it pivots on is never updated -- the pivot order is a selection sort of
+    the ORIGINAL |diagonal| (first maximum in the order the swaps leave behind).  Permute first, then factor P A P^T = L D L^T
+    without pivoting (column k = stored column minus the sum over j < k of L_ij * (D_j L_kj), summed first, subtracted once),
+    scale a column only if |D_k| > cutoff = eps * largest diagonal, stop when the largest remaining stored diagonal is below the
+    cutoff, and solve with the pseudo-inverse of D (|D_i| <= max(max|D| eps, DBL_MIN) -> 0).
+    Independent of oracle/plsvo_oracle.c::ldlt_solve_n; tests require bitwise agreement."""
+    A = np.array(H, dtype=np.float64)
+    n = A.shape[0]
+    eps = np.finfo(np.float64).eps
+    order = list(range(n))
+    cutoff = 0.0
+    stop_at = n
+    for k in range(n):                       # selection sort of the original diagonal, with Eigen's stopping rule
+        best, bestv = k, abs(A[order[k], order[k]])
+        for j in range(k + 1, n):
+            v = abs(A[order[j], order[j]])
+            if v > bestv:
+                best, bestv = j, v
+        if k == 0:
+            cutoff = abs(eps * bestv)
+        if bestv < cutoff:
+            stop_at = k
+            break
+        order[k], order[best] = order[best], order[k]
+    a = A[np.ix_(order, order)]
+    L = np.tril(a, -1).copy()                # unprocessed columns keep the stored (raw) entries, like the in-place algorithm
+    D = np.diag(a).copy()
+    for k in range(stop_at):
+        temp = [D[j] * L[k, j] for j in range(k)]
+        if k > 0:
+            acc = 0.0
+            for j in range(k):
+                acc += L[k, j] * temp[j]
+            D[k] = a[k, k] - acc
+            for i in range(k + 1, n):
+                acc = 0.0
+                for j in range(k):
+                    acc += L[i, j] * temp[j]
+                L[i, k] = a[i, k] - acc
+        if k < n - 1 and abs(D[k]) > cutoff:
+            with np.errstate(all="ignore"):
+                L[k + 1:, k] = L[k + 1:, k] / D[k]
+    y = np.array(b, dtype=np.float64)[order]
+    for i in range(n):
+        for j in range(i):
+            y[i] -= L[i, j] * y[j]
+    maxd = abs(D[0])
+    for i in range(1, n):
+        if abs(D[i]) > maxd:
+            maxd = abs(D[i])
+    tiny = 1.0 / np.finfo(np.float64).max
+    tol = maxd * eps if maxd * eps > tiny else tiny
+    with np.errstate(all="ignore"):
+        for i in range(n):
+            y[i] = y[i] / D[i] if abs(D[i]) > tol else 0.0
+        for i in range(n - 1, -1, -1):
+            for j in range(i + 1, n):
+                y[i] -= L[j, i] * y[j]
+    x = np.empty(n)
+    x[order] = y
+    return x
+
+
 def setup_sampling(spx, epx, length):
     dif = np.asarray(epx, float) - np.asarray(spx, float)
     a0, a1 = abs(dif[0]), abs(dif[1])

@@ -90,3 +90,36 @@ def test_oracle_edge_cases(P, ob):
     ro, log = ob.sparse_align(job, flat, flat, max_log=10)
     assert ro.status == 1 and log[0]["accepted"] == 0
     assert np.array_equal(ro.T, st.T_init)
+
+
+def test_ldlt_oracle_against_the_independent_eigen32_restatement(ob):
+    """oracle/plsvo_oracle.c follows Eigen's in-place code (swaps, partially updated columns); tests/np_restatement.py states the
+    same factorisation from the mathematics (sort the original diagonal, permute, factor without pivoting).  Bitwise agreement on
+    full-rank, rank-deficient, tied, indefinite, tiny, zero and badly scaled systems."""
+    rng = np.random.default_rng(31)
+    ob.set_ldlt_flavour(320)
+    cases = []
+    for cond_pow in (0, 2, 5, 8, 11):
+        for _ in range(6):
+            A = rng.normal(0, 1, (20, 6)) * np.logspace(0, -cond_pow / 2.0, 6)[rng.permutation(6)]
+            cases.append((A.T @ A, rng.normal(0, 1, 6)))
+    for rank in (1, 2, 3, 4, 5):                                    # rank-deficient J^T J, right-hand side in its range
+        for _ in range(6):
+            J = rng.normal(0, 1, (rank, 6))
+            cases.append((J.T @ J, J.T @ rng.normal(0, 1, rank)))
+    for n_obs in (1, 2, 3):                                         # point Jacobians: structural zeros and H00 == H11 ties
+        for _ in range(6):
+            Js = [ob.jacobian_xyz2uv(p) for p in rng.uniform([-1, -1, 2], [1, 1, 6], (n_obs, 3))]
+            cases.append((sum(J.T @ J for J in Js), sum(J.T @ rng.normal(0, 1e-2, 2) for J in Js)))
+    D = np.diag([3.0, 3.0, 3.0, 1.0, 1.0, 1.0])                     # exact ties everywhere
+    cases.append((D, np.arange(6.0)))
+    Q, _ = np.linalg.qr(rng.normal(0, 1, (6, 6)))
+    cases.append((Q @ np.diag([1.0, -2.0, 3.0, 4.0, -5.0, 6.0]) @ Q.T, np.arange(6.0)))      # indefinite
+    cases.append((np.zeros((6, 6)), np.ones(6)))
+    cases.append((1e-300 * (np.eye(6) + 0.1), np.ones(6)))
+    cases.append((np.diag([1.0, 1e-20, 1.0, 1e-17, 1.0, 1.0]), np.ones(6)))                   # diagonals below the cutoff
+    for H, b in cases:
+        H = 0.5 * (H + H.T)
+        x_c = ob.ldlt_solve6(H, b)
+        x_np = npr.eigen32_ldlt_solve(H, b)
+        assert np.array_equal(x_c, x_np, equal_nan=True), (H, b, x_c, x_np)
