@@ -137,3 +137,30 @@ def test_special_systems(ob):
     D = np.diag([3.0, 3.0, 3.0, 1.0, 1.0, 1.0]) + 0.1
     b = np.arange(6.0)
     assert np.allclose(wave_solve6_model(D, b), ob.ldlt_solve6(D, b), rtol=1e-13)
+
+
+def test_five_scalars_per_patch_reproduce_the_per_pixel_sums(ob):
+    """the identity the alignment kernel is built on: a patch's pixel Jacobians are J = fs (dx r0 + dy r1) with r0, r1
+    the rows of the patch's 2x6 projection Jacobian, so sum w J J^T = fs^2 (A r0 r0^T + B (r0 r1^T + r1 r0^T) + C r1 r1^T) and
+    sum w r J = fs (D r0 + E r1) with five scalars per patch -- checked against the reference's per-pixel accumulation
+    (src/sparse_img_align.cpp:262-264, 485-492)"""
+    rng = np.random.default_rng(44)
+    for _ in range(200):
+        xyz = rng.uniform([-2, -2, 1], [2, 2, 8])
+        r = ob.jacobian_xyz2uv(xyz)
+        fs = 416.0 / (1 << int(rng.integers(0, 4)))
+        dx, dy = rng.normal(0, 8, 16).astype(np.float32), rng.normal(0, 8, 16).astype(np.float32)
+        res = rng.normal(0, 5, 16).astype(np.float32)
+        w = (1.0 / (1.0 + np.abs(res.astype(np.float64)))).astype(np.float32)
+        H, g = np.zeros((6, 6)), np.zeros(6)
+        for k in range(16):                                        # the reference: one 6-vector per pixel
+            J = (float(dx[k]) * r[0] + float(dy[k]) * r[1]) * fs
+            H += np.outer(J, J) * float(w[k])
+            g -= J * float(res[k]) * float(w[k])
+        wd, dxd, dyd, rd = (a.astype(np.float64) for a in (w, dx, dy, res))
+        A, B, C = np.sum(wd * dxd * dxd), np.sum(wd * dxd * dyd), np.sum(wd * dyd * dyd)
+        D, E = np.sum(wd * rd * dxd), np.sum(wd * rd * dyd)
+        H5 = fs * fs * (A * np.outer(r[0], r[0]) + B * (np.outer(r[0], r[1]) + np.outer(r[1], r[0])) + C * np.outer(r[1], r[1]))
+        g5 = -fs * (D * r[0] + E * r[1])
+        assert np.allclose(H5, H, rtol=1e-12, atol=1e-12 * np.abs(H).max())
+        assert np.allclose(g5, g, rtol=1e-12, atol=1e-12 * np.abs(g).max())
