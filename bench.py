@@ -287,6 +287,11 @@ def main():
                 "roofline": roofline,
                 "kernel_ms_per_step": {"align_fused": round(lvl_ms / args.steps, 4), "pose_opt": round(pose_ms / args.steps, 4)},
             }
+            if not pose_only and hasattr(ctx.L, "plsvo_align_chi2_ties"):
+                gn_it, gn_ties = ctx.align_chi2_ties()
+                result["chi2_ties"] = {"gn_iterations_per_step": int(gn_it), "decided_on_exact_float_sums": int(gn_ties),
+                                       "what": "iterations whose `new_chi2 > chi2_` decision was taken on the reference's sequential float sums "
+                                               "(the two values closer than the sums' own rounding noise)"}
             if not pose_only:
                 errs = np.array([synth.se3_log_angle_dist(r.T, s.T_true) for r, s in zip(res[:64], streams[:64])])
                 result["accuracy_vs_truth"] = {"median_rot_rad": float(np.median(errs[:, 0])), "median_trans_m": float(np.median(errs[:, 1]))}

@@ -194,6 +194,11 @@ int plsvo_align_copy_poses(plsvo_ctx* ctx, double* d_dst);
  *   patch_iters  = sum over jobs, levels and GN iterations of patches evaluated (485 B each) */
 int plsvo_align_work(plsvo_ctx* ctx, uint64_t* patch_levels, uint64_t* patch_iters);
 
+/* parity accounting of the last plsvo_align_run: Gauss-Newton iterations in total, and how many of them had their
+ * `new_chi2 > chi2_` decision ([ext] vk::NLLSSolver::optimizeGaussNewton) taken on the reference's own sequential float sums
+ * (src/sparse_img_align.cpp:484, 683, 171, 192) because the two chi2 values were closer than the rounding noise of those sums */
+int plsvo_align_chi2_ties(plsvo_ctx* ctx, uint64_t* iterations, uint64_t* ties);
+
 /* ------------------------------------------------------------------------------------------ */
 /* pose optimisation                                                                           */
 /* replaces plsvo::pose_optimizer::optimizeGaussNewton (include/plsvo/pose_optimizer.h:47-64,  */

@@ -19,7 +19,7 @@ SYMBOLS = [
     "plsvo_hip_config_pyramids", "plsvo_hip_upload_pyramid", "plsvo_hip_build_pyramid", "plsvo_hip_build_pyramids_dev",
     "plsvo_hip_download_level",
     "plsvo_sparse_align", "plsvo_sparse_align_batch", "plsvo_align_stage", "plsvo_align_run", "plsvo_align_fetch",
-    "plsvo_align_set_trace", "plsvo_align_fetch_trace", "plsvo_align_poses_dev", "plsvo_align_copy_poses", "plsvo_align_work",
+    "plsvo_align_set_trace", "plsvo_align_fetch_trace", "plsvo_align_poses_dev", "plsvo_align_copy_poses", "plsvo_align_work", "plsvo_align_chi2_ties",
     "plsvo_pose_optimize", "plsvo_pose_optimize_batch", "plsvo_poseopt_stage", "plsvo_poseopt_run", "plsvo_poseopt_fetch",
     "plsvo_poseopt_set_trace", "plsvo_poseopt_fetch_trace", "plsvo_poseopt_poses_dev", "plsvo_poseopt_copy_poses", "plsvo_poseopt_work",
     "plsvo_structure_optimize", "plsvo_match_direct", "plsvo_reproject", "plsvo_trajectory_record", "plsvo_update_seeds",
@@ -72,6 +72,7 @@ def lib():
         "plsvo_align_copy_poses": (C.c_int, [ctxp, vp]),
         "plsvo_poseopt_copy_poses": (C.c_int, [ctxp, vp]),
         "plsvo_align_work": (C.c_int, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "plsvo_align_chi2_ties": (C.c_int, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "plsvo_pose_optimize": (C.c_int, [ctxp, C.POINTER(abi.PoseOptIn), C.POINTER(abi.PoseOptOut)]),
         "plsvo_pose_optimize_batch": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.PoseOptIn), C.POINTER(abi.PoseOptOut)]),
         "plsvo_poseopt_stage": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.PoseOptIn)]),
@@ -96,6 +97,8 @@ def lib():
         "plsvo_hip_device_info": (C.c_int, [ctxp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     }
     for name, (res, args) in sig.items():
+        if "PLSVO_HIP_LIB" in os.environ and not hasattr(L, name):
+            continue   # A/B against an older instrumented build (experiments only): a missing entry point fails when it is called
         f = getattr(L, name)
         f.restype = res
         f.argtypes = args
@@ -235,6 +238,13 @@ class Context:
         a = C.c_uint64(0)
         b = C.c_uint64(0)
         self._chk(self.L.plsvo_align_work(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def align_chi2_ties(self):
+        """(Gauss-Newton iterations, iterations decided on the exact float chi2 sums) of the last align_run"""
+        a = C.c_uint64(0)
+        b = C.c_uint64(0)
+        self._chk(self.L.plsvo_align_chi2_ties(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def align_poses_dev(self):

@@ -113,6 +113,113 @@ __device__ __forceinline__ void block_sync() {
   if constexpr (T == 64) wave_lds_fence(); else __syncthreads();
 }
 
+// store of one patch row of chi2 terms (written every iteration, read on near ties only)
+#ifndef PLSVO_CHI_NT
+#define PLSVO_CHI_NT 0
+#endif
+#ifndef PLSVO_CHI_EXP
+#define PLSVO_CHI_EXP 0
+#endif
+// half-width of the near-tie band, in units of sqrt(n_meas) * 2^-24 (one sigma of the reference's float sum is ~0.25 of that)
+#ifndef PLSVO_CHI_BAND
+#define PLSVO_CHI_BAND 1.5f
+#endif
+#if PLSVO_CHI_NT
+typedef float plsvo_f4 __attribute__((ext_vector_type(4)));
+#define PLSVO_CHI_STORE(ptr, val) __builtin_nontemporal_store(plsvo_f4{ (val).x, (val).y, (val).z, (val).w }, reinterpret_cast<plsvo_f4*>(ptr))
+#else
+#define PLSVO_CHI_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
+// LDS layout shared by the kernel and the host-side size helper: the tables end at this offset, the 4 KB window follows
+__host__ __device__ inline size_t align_chi_window_offset(int threads, int cap, int scap) {
+  size_t o = sizeof(double) * 32 * (threads / 16) + sizeof(double) * 64 + sizeof(int) * 32;
+  o += (size_t)cap * (sizeof(int2) + sizeof(float)) + (size_t)scap * sizeof(int) + ((size_t)2 * scap + 2) * sizeof(float);
+  return (o + 15) & ~(size_t)15;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The chi2 the solver compares (`new_chi2 > chi2_`, [ext] vk::NLLSSolver::optimizeGaussNewton) is
+//     (float)(pt_chi2 + seg_chi2) / (float)n_meas_                                   src/sparse_img_align.cpp:171, 192
+// with pt_chi2 the SEQUENTIAL float sum of res*res*weight over every pixel of every visible point in feature order (:484)
+// and seg_chi2 the sequential float sum of res_*res_*weight over the surviving lines (:683).  The passes add the same float
+// terms exactly (in double) and round once: ~1e-6 away from the reference's value -- its own summation noise -- and near
+// convergence two successive chi2 values are closer than that in one iteration out of seven, so the accept / roll-back
+// decision would be a coin the device and the reference toss separately (15 % of frames ended on a different path).
+// When |new_chi2 - chi2_| is inside the band that noise can span, ONE wave re-adds the stored per-pixel terms of this and of
+// the previous iteration in the reference's order, and the decision is taken on those two floats.
+//
+//   bufA / bufB   this job's slice of the chi_terms plane written at iteration `iter` / `iter - 1` (16 floats per point slot;
+//                 invisible points and patches outside the current image hold +0)
+//   s_lterm       the lines' terms of the two iterations as the passes computed them (plane = iteration parity); a line
+//                 culled at iteration k (s_dead = k + 1) counts for the iterations before k only
+//   s_out[0..1]   chi2 (before the division by n_meas_) of iteration `iter`, `iter - 1`
+// 32 slots (2 KB per plane) at a time are staged through LDS with coalesced 16-byte loads, the next window's loads in flight
+// under the current window's chains; lane 0 / lane 1 run the chain of plane A / B, the next slot's LDS reads in flight under
+// the sixteen dependent additions of the current one.  The line terms are NOT re-derived: a line's float term differs from the
+// reference's only through the summation order of its <= 512 |res| values (~1e-7 of a term, and the lines carry a few per cent
+// of chi2) -- storing 64 B per line sample and iteration to remove that would cost more HBM traffic than everything else here.
+// Must be called by one full wave.
+// (explicit address spaces: the function is not inlined -- its registers must not add to the main pass's -- and without them every
+//  LDS access would be a flat_load that also waits for the global prefetch in flight)
+// ------------------------------------------------------------------------------------------------
+#define PLSVO_LDS __attribute__((address_space(3)))
+#define PLSVO_GLOBAL __attribute__((address_space(1)))
+typedef float plsvo_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float chain4(float s, plsvo_v4f v) {   // four sequential float additions, never re-associated
+  s = __fadd_rn(s, v.x); s = __fadd_rn(s, v.y); s = __fadd_rn(s, v.z); return __fadd_rn(s, v.w);
+}
+__device__ __noinline__ void exact_chi2_pair(const PLSVO_GLOBAL float* bufA, const PLSVO_GLOBAL float* bufB, int n_pts, int n_seg, int iter,
+                                             const PLSVO_LDS int* s_dead, PLSVO_LDS float* s_win, const PLSVO_LDS float* s_lterm, int scap,
+                                             PLSVO_LDS float* s_out) {
+  const int lane = threadIdx.x & 63;
+  const plsvo_v4f z4 = { 0.f, 0.f, 0.f, 0.f };
+  auto load_win = [&](int r, plsvo_v4f* v) {   // float4 `lane` and `lane + 64` of the round's 128-float4 window, both planes
+    const size_t f0 = (size_t)r * 512;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = lane + 64 * h;
+      const bool ok = 32 * r + (q >> 2) < n_pts;
+      v[h] = ok ? reinterpret_cast<const PLSVO_GLOBAL plsvo_v4f*>(bufA + f0)[q] : z4;
+      v[2 + h] = ok ? reinterpret_cast<const PLSVO_GLOBAL plsvo_v4f*>(bufB + f0)[q] : z4;
+    }
+  };
+  float sum = 0.0f;   // lane 0: plane A, lane 1: plane B
+  const int n_rounds = (n_pts + 31) >> 5;
+  plsvo_v4f nxt[4] = { z4, z4, z4, z4 };
+  if (n_rounds > 0) load_win(0, nxt);
+  for (int r = 0; r < n_rounds; ++r) {
+    const plsvo_v4f c0 = nxt[0], c1 = nxt[1], c2 = nxt[2], c3 = nxt[3];
+    if (r + 1 < n_rounds) load_win(r + 1, nxt);
+    wave_lds_fence();   // the previous window has been consumed
+    PLSVO_LDS plsvo_v4f* const w4 = reinterpret_cast<PLSVO_LDS plsvo_v4f*>(s_win);
+    w4[lane] = c0; w4[lane + 64] = c1; w4[128 + lane] = c2; w4[128 + lane + 64] = c3;
+    wave_lds_fence();
+    const int cnt = min(32, n_pts - 32 * r);
+    if (lane < 2) {
+      const PLSVO_LDS plsvo_v4f* w = w4 + 128 * lane;
+      plsvo_v4f a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3];
+      for (int n = 0; n < cnt; ++n) {
+        plsvo_v4f b0 = z4, b1 = z4, b2 = z4, b3 = z4;
+        if (n + 1 < cnt) { b0 = w[4 * n + 4]; b1 = w[4 * n + 5]; b2 = w[4 * n + 6]; b3 = w[4 * n + 7]; }
+        sum = chain4(sum, a0); sum = chain4(sum, a1); sum = chain4(sum, a2); sum = chain4(sum, a3);
+        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+      }
+    }
+  }
+  if (lane < 2) {
+    float seg_sum = 0.0f;                                                // :683, segments in feature order
+    for (int sg = 0; sg < n_seg; ++sg) {
+      const int dead = s_dead[sg];
+      const float t = s_lterm[((iter - lane) & 1) * scap + sg];
+      // the line took part in iteration j (= iter for lane 0, iter - 1 for lane 1) unless it was culled at an iteration <= j
+      seg_sum = __fadd_rn(seg_sum, (dead == 0 || dead > iter - lane + 1) ? t : 0.0f);
+    }
+    s_out[lane] = __fadd_rn(sum, seg_sum);                               // :171  chi2 = pt_chi2 + seg_chi2
+  }
+  wave_lds_fence();
+}
+
 // ------------------------------------------------------------------------------------------------
 // SparseImgAlign::run for every job of the batch: levels [level_hi .. level_lo] of each job's range
 // ------------------------------------------------------------------------------------------------
@@ -138,7 +245,9 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   int* s_ctl = reinterpret_cast<int*>(s_tot + 32);                       // 0 break, 1 stop, 2 iterations done, 3 error, 5 #patches of the level
   int2* s_meta = reinterpret_cast<int2*>(s_ctl + 32);                    // cap: x = feature (>= 0 point, < 0 segment -1-x, SLOT_HOLE), y = first slot | N << 20
   float* s_abs = reinterpret_cast<float*>(s_meta + cap);                 // cap: sum |res| of the slot's 16 pixels, -1 = sample not in the image
-  int* s_dead = reinterpret_cast<int*>(s_abs + cap);                     // scap: per segment, "culled at this level"
+  int* s_dead = reinterpret_cast<int*>(s_abs + cap);                     // scap: per segment, 0 = alive, k + 1 = culled at iteration k of this level
+  float* s_lterm = reinterpret_cast<float*>(s_dead + scap);              // 2 * scap + 2: exact chi2 term of every line, two iterations; the two sums
+  float* s_win = reinterpret_cast<float*>(smem + align_chi_window_offset(T, cap, scap));   // 1024: two 32-slot windows of chi_terms
 
 #ifdef PLSVO_TIMING
   __shared__ unsigned long long s_time[8];
@@ -156,7 +265,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       st->chi2 = 1e10; st->n_meas = 0; st->stop = 0; st->log_count = 0; st->error = 0;
       for (int k = 0; k < 36; ++k) st->H[k] = 0.0;
       for (int k = 0; k < PLSVO_MAX_LEVELS; ++k) st->iters[k] = 0;
-      st->patch_levels = 0; st->patch_iters = 0;
+      st->patch_levels = 0; st->patch_iters = 0; st->chi2_ties = 0;
       for (int k = 0; k < 8; ++k) st->phase_ticks[k] = 0;
       if (nothing && b.poses) for (int k = 0; k < 7; ++k) b.poses[7 * job_id + k] = b.T0[7 * job_id + k];
     }
@@ -167,7 +276,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     for (int k = 0; k < 7; ++k) { s_pose[12 + k] = st->T[k]; s_pose[19 + k] = st->T[k]; }
     s_pose[26] = st->chi2; s_pose[28] = 0.0; s_pose[29] = 0.0;
     for (int k = 0; k < 32; ++k) s_tot[k] = 0.0;
-    s_ctl[1] = st->stop; s_ctl[3] = 0;
+    s_ctl[1] = st->stop; s_ctl[3] = 0; s_ctl[6] = 0;
   }
   const size_t pbase = (size_t)job.patch_off;
   const int nfeat = job.n_pts + job.n_seg;
@@ -212,7 +321,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         }
       } else {
         const int sl = f - job.n_pts, s = job.seg_off + sl;
-        s_dead[sl] = 0;
+        s_dead[sl] = 0; s_lterm[sl] = 0.0f; s_lterm[scap + sl] = 0.0f;
         // host layout: first slot | N << 20, or -1 when the segment has no landmark on entry or fails
         // precomputeGaussNewtonParamsSegments :299-301 ((px*scale).cast<int>() against cam->isInFrame(.,3,level));
         // N = 1 + (N0-1)/2^level samples (:320, LineFeat::setupSampling src/feature.cpp:160-173)
@@ -294,6 +403,8 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       // this lane's share of the pose: the row of R (and t) of its image coordinate, and the depth row
       const double Ra = s_pose[3 * half], Rb = s_pose[3 * half + 1], Rc = s_pose[3 * half + 2], ta = s_pose[9 + half];
       const double Rz0 = s_pose[6], Rz1 = s_pose[7], Rz2 = s_pose[8], tz = s_pose[11];
+
+      float* const chi_it = b.chi_terms + (size_t)(iter & 1) * b.chi_plane + (size_t)job.pt_off * 16;   // this iteration's plane of the points' chi2 terms
 
       double acc[32];   // 0..20 H (upper, row-major), 21..26 Jres, 27 chi2, 28 n_meas, 29 evals, 30..31 unused
 #pragma unroll
@@ -399,6 +510,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           double sA = 0, sB = 0, sC = 0, sD = 0, sE = 0, sChi = 0;
           float sAbs = 0.0f;
           const bool any_point = __any(live && !is_line) != 0;   // wave-uniform
+          float4 chi_t0 = make_float4(0.f, 0.f, 0.f, 0.f), chi_t1 = chi_t0;   // a patch outside the current image contributes nothing (:432-433): +0
           if (live) {
             const PatchW pw = patch_weights(u, v);
             const int off = sb.off;
@@ -416,11 +528,14 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
             // WEIGHTED is decided per wave: the slot table lists points first, then line samples, so most rounds are
             // homogeneous and the line-only ones skip the robust weight (11 instructions per pixel) and the chi2 term.
             // (a packed-FP32 form of this loop, two pixels per v_pk_* instruction, was measured 12 % slower)
-            auto row4 = [&](auto WEIGHTED, const float* top, const float* bot, const float4& vr, const float4& vx, const float4& vy) {
+            // (every pixel's chi2 term -- res*res*w of a point pixel, |res| of a line pixel -- also goes to this iteration's
+            //  plane of chi_terms, one float4 per patch row: what exact_chi2_pair re-adds in the reference's order on a near tie)
+            auto row4 = [&](auto WEIGHTED, const float* top, const float* bot, const float4& vr, const float4& vx, const float4& vy, float4& tv4) {
               constexpr bool weighted = decltype(WEIGHTED)::value;
               const float* pr = reinterpret_cast<const float*>(&vr);
               const float* pxp = reinterpret_cast<const float*>(&vx);
               const float* pyp = reinterpret_cast<const float*>(&vy);
+              float* tv = reinterpret_cast<float*>(&tv4);
 #pragma unroll
               for (int x = 0; x < 4; ++x) {
                 const float c = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, top[x], top[x + 1], bot[x], bot[x + 1]);
@@ -434,20 +549,23 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
                   const double wdx = wd * dx, wdy = wd * dy;
                   sA += wdx * dx; sB += wdx * dy; sC += wdy * dy;
                   sD += wdx * rd; sE += wdy * rd;
-                  sChi += (double)__fmul_rn(__fmul_rn(res, res), w);
+                  const float term = __fmul_rn(__fmul_rn(res, res), w);      // :484  chi2 += res*res*weight (float)
+                  sChi += (double)term;
+                  tv[x] = is_point ? term : ares;
                 } else {
                   sA += dx * dx; sB += dx * dy; sC += dy * dy;
                   sD += dx * rd; sE += dy * rd;
+                  tv[x] = ares;
                 }
                 sAbs += ares;
               }
             };
             if (any_point) {
-              row4(std::true_type{}, r0, r1, vr0, vx0, vy0);
-              row4(std::true_type{}, r1, r2, vr1, vx1, vy1);
+              row4(std::true_type{}, r0, r1, vr0, vx0, vy0, chi_t0);
+              row4(std::true_type{}, r1, r2, vr1, vx1, vy1, chi_t1);
             } else {
-              row4(std::false_type{}, r0, r1, vr0, vx0, vy0);
-              row4(std::false_type{}, r1, r2, vr1, vx1, vy1);
+              row4(std::false_type{}, r0, r1, vr0, vx0, vy0, chi_t0);
+              row4(std::false_type{}, r1, r2, vr1, vx1, vy1, chi_t1);
             }
           }
           // pair totals (both lanes of the pair end up with the patch sums)
@@ -462,6 +580,14 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           a_nxt = stage_a(pb + T / 2);
           c_nxt = stage_c_loads(pb + T / 2, a_nxt.cand);
 #endif
+          // The chi2 terms of a POINT slot (16 floats) go to this iteration's plane of chi_terms, placed after the next round's loads
+          // have been issued: the compiler cannot prove that these stores do not alias the cache arrays, and a store inside the
+          // pixel arithmetic pins every later load behind it (measured +31 % launch time there, and the launch is within a few
+          // per cent of the achievable HBM rate: every byte written costs its time, which is why line pixels are not stored).
+          if (accumulate && p < job.n_pts) {
+            float4* const chi_dst = reinterpret_cast<float4*>(chi_it + (unsigned)(p * 16 + 8 * half));   // wave-uniform base + 32-bit lane offset
+            PLSVO_CHI_STORE(chi_dst, chi_t0); PLSVO_CHI_STORE(chi_dst + 1, chi_t1);
+          }
 
           // -- weights: points 1; a line's samples share w / mean|res| (H) and w (Jres), :640-688
           double wh = 0.0, wj = 0.0;
@@ -479,9 +605,13 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
                 const float w = (float)(1.0 / (1.0 + (double)res_));               // :675
                 wh = (double)w / (double)res_;                                     // :681  H += H_ * w / res_
                 wj = (double)w;                                                    // :682  Jres += Jres_ * w
-                if (p == first && half == 0) { acc[27] += (double)__fmul_rn(__fmul_rn(res_, res_), w); acc[28] += 1.0; }  // :683-684
+                if (p == first && half == 0) {                                     // :683-684
+                  const float term = __fmul_rn(__fmul_rn(res_, res_), w);
+                  acc[27] += (double)term; acc[28] += 1.0;
+                  s_lterm[(iter & 1) * scap + (-1 - meta.x)] = term;               // this iteration's plane (exact_chi2_pair)
+                }
               } else if (p == first && half == 0) {
-                s_dead[-1 - meta.x] = 1;                                           // :687-688 it->feat3D = NULL
+                s_dead[-1 - meta.x] = iter + 1;                                    // :687-688 it->feat3D = NULL
                 b.seg_alive[job.seg_off + (-1 - meta.x)] = 0;
               }
             }
@@ -536,17 +666,32 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         wave_solve6_reg(tot, x);                                               // solve() :699
         TICK(4);
         const double chi_sum = readlane_f64(tot, 27), nm_d = readlane_f64(tot, 28), ev_d = readlane_f64(tot, 29);
+        const unsigned long long nm = (unsigned long long)(nm_d + 0.5);
+        // computeResiduals returns float chi2 / n_meas_ (:171,192); chi_sum is the exact sum of the float terms, rounded once
+        double new_chi2 = (double)((float)chi_sum / (float)nm);
+        double old_chi2 = s_pose[26];                                          // solver chi2_
+        // the reference's sequential float sums sit within ~0.25 sqrt(n) 2^-24 (one sigma) of these: inside 2 sqrt(n) 2^-24
+        // (> 5 sigma of the difference of two such sums) the order of the two values is taken from the exact float sums
+        const float band = PLSVO_CHI_BAND * __fsqrt_rn((float)nm_d) * 5.9604644775390625e-8f;
+        const bool tie = iter > 0 && !s_ctl[1] && !isnan(x[0]) && fabs(new_chi2 - old_chi2) <= (double)band * old_chi2;
+        if (tie) {   // wave-uniform
+          exact_chi2_pair((const PLSVO_GLOBAL float*)chi_it, (const PLSVO_GLOBAL float*)(b.chi_terms + (size_t)((iter & 1) ^ 1) * b.chi_plane + (size_t)job.pt_off * 16),
+                          job.n_pts, job.n_seg, iter, (const PLSVO_LDS int*)s_dead, (PLSVO_LDS float*)s_win, (const PLSVO_LDS float*)s_lterm, scap,
+                          (PLSVO_LDS float*)s_lterm + 2 * scap);
+          const float FA = s_lterm[2 * scap], FB = s_lterm[2 * scap + 1];   // chi2 of this / of the previous iteration, before the division
+          new_chi2 = (double)(FA / (float)nm);
+          old_chi2 = (double)(FB / (float)(unsigned long long)(s_pose[30] + 0.5));
+        }
         if (lane == 0) {
-          const unsigned long long nm = (unsigned long long)(nm_d + 0.5);
           s_pose[27] += ev_d;
+          s_pose[30] = nm_d;                                                   // n_meas_ of this iteration, for the next one's tie
           s_ctl[2] += 1;
-          // computeResiduals returns float chi2 / n_meas_ (:171,192)
-          const double new_chi2 = (double)((float)chi_sum / (float)nm);
+          if (tie) s_ctl[6] += 1;
           int stop = s_ctl[1];
           if (isnan(x[0])) stop = 1;                                           // :700
           SE3d model = se3_load(s_pose + 12);
           int accepted, brk = 0;
-          if ((iter > 0 && new_chi2 > s_pose[26]) || stop) {
+          if ((iter > 0 && new_chi2 > old_chi2) || stop) {
             model = se3_load(s_pose + 19);                                     // rollback to old_model
             accepted = 0; brk = 1;
           } else {
@@ -603,6 +748,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     st->patch_levels += (unsigned long long)(s_pose[28] + 0.5);
     st->patch_iters += (unsigned long long)(s_pose[29] + 0.5);
     st->stop = s_ctl[1];
+    st->chi2_ties += s_ctl[6];
     st->n_meas = (unsigned long long)(s_tot[28] + 0.5);
     for (int i = 0; i < 6; ++i) for (int jj = 0; jj < 6; ++jj) st->H[i * 6 + jj] = s_tot[sym6_index(i, jj)];
 #ifdef PLSVO_TIMING
@@ -613,9 +759,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 
 // LDS bytes the kernel needs for slot capacity `cap` and segment capacity `scap` (host side helper)
 size_t align_level_lds_bytes(int threads, int cap, int scap) {
-  size_t o = sizeof(double) * 32 * (threads / 16) + sizeof(double) * 64 + sizeof(int) * 32;
-  o += (size_t)cap * (sizeof(int2) + sizeof(float)) + (size_t)scap * sizeof(int) + 16;
-  return o;
+  return align_chi_window_offset(threads, cap, scap) + 1024 * sizeof(float) + 16;
 }
 
 template <int T>

@@ -96,7 +96,7 @@ struct plsvo_ctx {
   int a_scap = 4;   // max segments of one job
   int a_trace_cap = 0;
   DevBuf a_d_state, a_d_alive;   // (inputs: a_d_blob)
-  DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_cdx, a_d_cdy, a_d_log, a_d_poses;
+  DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_cdx, a_d_cdy, a_d_chi, a_d_log, a_d_poses;
   AlignBatchDev a_b{};
 
   // pose-opt batch
@@ -210,7 +210,7 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
   prof_collect(c);
   for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_upload, &c->a_d_blob, &c->a_d_state, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv, &c->a_d_cref, &c->a_d_cdx,
-                     &c->a_d_cdy, &c->a_d_log, &c->a_d_poses, &c->p_d_blob, &c->p_d_state, &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64,
+                     &c->a_d_cdy, &c->a_d_chi, &c->a_d_log, &c->a_d_poses, &c->p_d_blob, &c->p_d_state, &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64,
                      &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out };
   for (DevBuf* b : bufs) b->release();
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -483,6 +483,8 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   HIP_TRY(c, c->a_d_cref.ensure(pt * 16 * sizeof(float)));
   HIP_TRY(c, c->a_d_cdx.ensure(pt * 16 * sizeof(float)));
   HIP_TRY(c, c->a_d_cdy.ensure(pt * 16 * sizeof(float)));
+  const size_t npt_total = ptpx.size() / 2 + 32;
+  HIP_TRY(c, c->a_d_chi.ensure(2 * npt_total * 16 * sizeof(float)));   // two planes of the points' per-pixel chi2 terms
   if (c->a_trace_cap > 0) HIP_TRY(c, c->a_d_log.ensure((size_t)n * c->a_trace_cap * sizeof(plsvo_align_iterlog)));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
 
@@ -497,6 +499,7 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   b.seg_alive_in = base + o_alive; b.seg_alive = c->a_d_alive.as<uint8_t>();
   b.patch_xyz = c->a_d_pxyz.as<double>(); b.patch_uvref = c->a_d_puv.as<float>();
   b.cache_ref = c->a_d_cref.as<float>(); b.cache_dx = c->a_d_cdx.as<float>(); b.cache_dy = c->a_d_cdy.as<float>();
+  b.chi_terms = c->a_d_chi.as<float>(); b.chi_plane = (unsigned long long)npt_total * 16;
   b.seg_slot = reinterpret_cast<const int*>(base + o_slot); b.slot_level0 = slot_level0; b.slot_stride = (int)total_seg;
   b.poses = c->a_d_poses.as<double>();
   b.pyr = c->pyr;
@@ -682,6 +685,20 @@ extern "C" int plsvo_align_work(plsvo_ctx* c, uint64_t* patch_levels, uint64_t* 
   for (auto& s : st) { pl += s.patch_levels; pi += s.patch_iters; }
   if (patch_levels) *patch_levels = pl;
   if (patch_iters) *patch_iters = pi;
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_align_chi2_ties(plsvo_ctx* c, uint64_t* iterations, uint64_t* ties) {
+  CTX_CHECK(c);
+  if (!c->a_staged) return fail(c, PLSVO_E_STATE, "align_chi2_ties: no staged batch");
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<AlignStateDev> st((size_t)c->a_n);
+  HIP_TRY(c, hipMemcpyAsync(st.data(), c->a_d_state.p, (size_t)c->a_n * sizeof(AlignStateDev), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  uint64_t it = 0, t = 0;
+  for (auto& s : st) { t += (uint64_t)s.chi2_ties; for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) it += (uint64_t)s.iters[l]; }
+  if (iterations) *iterations = it;
+  if (ties) *ties = t;
   return PLSVO_OK;
 }
 

@@ -58,7 +58,7 @@ struct AlignStateDev {
   int iters[PLSVO_MAX_LEVELS];
   unsigned long long patch_levels, patch_iters;  // work counters
   int error;                   // device-side capacity/consistency error
-  int reserved0;
+  int chi2_ties;               // Gauss-Newton iterations whose accept / roll-back decision was taken on the exact float chi2 sums
   unsigned long long phase_ticks[8];  // only filled by -DPLSVO_TIMING builds (s_memtime ticks per phase)
 };
 
@@ -84,6 +84,12 @@ struct AlignBatchDev {
   float* cache_ref;            // 16 per slot: interpolated reference intensity
   float* cache_dx;             // 16 per slot
   float* cache_dy;             // 16 per slot
+  // per-pixel terms of the solver's chi2 for the POINT features, double-buffered by iteration parity (plane 0 / 1, chi_plane
+  // floats apart): 16 per point of the batch, res*res*w (src/sparse_img_align.cpp:484).  Written by every iteration, read only when
+  // two successive chi2 values are too close for the double-precision sums to order them the way the reference's sequential
+  // float sums do (align_kernels.hip::exact_chi2_pair).
+  float* chi_terms;
+  unsigned long long chi_plane;
   double* poses;               // 7 per job: final model, contiguous (what a device-side consumer / the RCCL gather reads)
   PyrDesc pyr;
   plsvo_align_iterlog* log;    // log_cap per job, or null

@@ -74,10 +74,11 @@ def test_sparse_align_matches_oracle(P, ob, gpu_ctx, case):
         assert ang <= Hh.ROT_TOL * step_rot / 0.01 and tr <= Hh.TRANS_REL_TOL * step_rot / 0.01, f"{tag}: rot {ang:.3e} rad, trans rel {tr:.3e}"
     else:
         assert ok, f"{tag}: rot {ang:.3e} rad, trans rel {tr:.3e}"
-        # and on the inter-frame motion itself (looser: the reference's GN termination is decided by the
-        # rounding noise of its float chi2 sum, so the last sub-1e-5 step may or may not be taken)
+        # and on the inter-frame motion itself, T_cur_from_ref (src/sparse_img_align.cpp:80), relative to ITS translation: the
+        # same bar.  (The reference's GN termination is decided by comparisons of float chi2 sums; the device takes those
+        # decisions on the same float sums whenever they are close, so the two paths are the same path.)
         ang2, tr2, _ = Hh.pose_close(res_d.T, res_o.T)
-        assert ang2 < 1e-4 and tr2 < 1e-3, f"{tag}: inter-frame rot {ang2:.3e} rad, trans rel {tr2:.3e}"
+        assert ang2 < 1e-4 and tr2 < 1e-4, f"{tag}: inter-frame rot {ang2:.3e} rad, trans rel {tr2:.3e}"
         if Hh.same_path(log_o, log_d):
             # same Gauss-Newton path: what is left is summation order, two orders of magnitude inside the bar
             # (1e-8 on the BASELINE workloads, 2e-7 on the 24-point 160x120 case)
@@ -93,6 +94,7 @@ def test_sparse_align_matches_oracle(P, ob, gpu_ctx, case):
     assert res_d.n_meas == log_d[-1]["n_meas"] and res_d.n_tracked == res_d.n_meas // 16
     # ... and when the two Gauss-Newton paths are the same path, so are the returned counts
     same = Hh.same_path(log_o, log_d)
+    assert same, f"{tag}: the device left the oracle's Gauss-Newton path at record {Hh.common_prefix(log_o, log_d)}"
     PATH_STATS["cases"] += 1
     PATH_STATS["different_paths"] += 0 if same else 1
     if same:
@@ -103,55 +105,102 @@ def test_sparse_align_matches_oracle(P, ob, gpu_ctx, case):
 PATH_STATS = {"cases": 0, "different_paths": 0}
 
 
-def test_config2_seed_sweep_meets_the_pose_bar_on_every_seed(P, ob, gpu_ctx):
-    """40 seeds of BASELINE config 2: the parity bar on cur_frame->T_f_w_ for every one of them; the worst case and the number of
-    seeds whose Gauss-Newton paths differ (a float chi2 comparison decided the other way) go to gpurun_out/ for profiles/."""
+SWEEPS = [
+    # tag, first seed, seeds, W, H, points, segments, pyramid images, max_level, min_level
+    ("config2", 4000, 150, 640, 480, 200, 80, 4, 3, 1),
+    ("config3", 5000, 60, 1280, 720, 400, 150, 5, 4, 2),
+]
+
+
+@pytest.mark.parametrize("sweep", SWEEPS, ids=[c[0] for c in SWEEPS])
+def test_seed_sweep_follows_the_oracle_path_on_every_seed(P, ob, gpu_ctx, sweep):
+    """210 seeds of BASELINE configs 2 and 3.  On EVERY seed the parity bar of BASELINE.json holds on cur_frame->T_f_w_ AND on
+    T_cur_from_ref itself: 1e-4 rad, 1e-4 of the inter-frame translation.  The device takes the oracle's Gauss-Newton path record for
+    record (same iterations, same accept / roll-back decisions) because the chi2 comparison is taken on the reference's own sequential
+    float sums whenever the two values are close (align_kernels.hip::exact_chi2_pair) -- except where the reference's decision hangs on
+    the LAST bits of its input: the device's pose differs from the oracle's by ~1e-11 (summation order of H in double), which now and
+    then moves the float pixel position of one patch by one ulp and chi2 by a few ulps; a comparison closer than that (<= 4 float ulps
+    between the two chi2 values, or ||x||_inf within 2 % of eps) may still go the other way.  Measured: 3 of 210 seeds (round 2, when
+    the comparison was made on exactly-rounded sums: 6 of 40).  Worst cases go to gpurun_out/ for profiles/."""
     import json, os
-    worst = {"rot_rad": 0.0, "trans_rel": 0.0, "seed_rot": None, "seed_trans": None}
-    different, iters_d, iters_o = [], 0, 0
-    for seed in range(4000, 4040):
-        st, res_o, log_o, res_d, log_d = _run_both(P, ob, gpu_ctx, seed, 640, 480, 200, 80, 4, 3, 1)
-        ang, tr, ok = Hh.pose_close(Hh.frame_pose(res_d.T, st), Hh.frame_pose(res_o.T, st))
-        assert ok, f"seed {seed}: rot {ang:.3e} rad, trans rel {tr:.3e}"
-        assert np.array_equal(res_d.seg_alive, res_o.seg_alive), seed
-        n, w = Hh.compare_align_logs(log_o, log_d)      # asserts n_meas equality on every shared iteration
-        assert n >= 1 and w["H"] < 1e-6, (seed, w)
-        if ang > worst["rot_rad"]:
-            worst["rot_rad"], worst["seed_rot"] = ang, seed
-        if tr > worst["trans_rel"]:
-            worst["trans_rel"], worst["seed_trans"] = tr, seed
-        iters_d += len(log_d); iters_o += len(log_o)
-        if Hh.same_path(log_o, log_d):
-            assert res_d.n_meas == res_o.n_meas and res_d.n_tracked == res_o.n_tracked, seed
-        else:
-            # the paths part at ONE record (same level, same iteration, same linearisation), on a near tie of one of the solver's two
-            # stopping rules:
-            #  (i)  opposite accept / roll-back decisions, where the chi2 the reference compares (a float sum of thousands of float
-            #       terms) moved by less than 1e-4 relative against the previous iteration's, on both sides;
-            #  (ii) both accept, one side stops on ||x||_inf <= eps (1e-6) and the other goes on, with ||x||_inf within 2 % of eps.
-            k = Hh.common_prefix(log_o, log_d) - 1
-            a, b = log_o[k], log_d[k]
-            assert (a["level"], a["iter"]) == (b["level"], b["iter"]), seed
-            info = {"seed": seed, "oracle_iters": res_o.iters_per_level[:4], "device_iters": res_d.iters_per_level[:4],
-                    "shared_records": k + 1, "level": a["level"], "iter": a["iter"]}
-            if a["accepted"] != b["accepted"]:
-                assert k >= 1 and log_o[k - 1]["level"] == a["level"], seed
-                gap_o = abs(a["new_chi2"] - log_o[k - 1]["new_chi2"]) / log_o[k - 1]["new_chi2"]
-                gap_d = abs(b["new_chi2"] - log_d[k - 1]["new_chi2"]) / log_d[k - 1]["new_chi2"]
-                assert gap_o < 1e-4 and gap_d < 1e-4, (seed, gap_o, gap_d)
-                info.update(kind="chi2 near tie", chi2_step_rel_oracle=gap_o, chi2_step_rel_device=gap_d)
+    tag, seed0, n_seeds, W, H, npts, nseg, nlev, maxl, minl = sweep
+    worst = {"rot_rad": 0.0, "trans_rel": 0.0, "inter_rot_rad": 0.0, "inter_trans_rel": 0.0, "inter_trans_abs_m": 0.0, "min_inter_translation_m": 1e9}
+    different, failures, iters_d, iters_o = [], [], 0, 0
+    worst_lin = {"H": 0.0, "x": 0.0, "chi2": 0.0}
+    chunk = 30
+    ties = its = 0
+    for c0 in range(0, n_seeds, chunk):
+        seeds = list(range(seed0 + c0, seed0 + min(c0 + chunk, n_seeds)))
+        cases = [Hh.make_case(ob, sd, W, H, npts, nseg, nlev, maxl, minl) for sd in seeds]
+        gpu_ctx.config_pyramids(2 * len(seeds), W, H, nlev)
+        jobs = []
+        for k, (st, ref, cur, job) in enumerate(cases):
+            gpu_ctx.upload_pyramid(2 * k, ref)
+            gpu_ctx.upload_pyramid(2 * k + 1, cur)
+            jobs.append(P.align_job_from_stream(st, maxl, minl, ref_slot=2 * k, cur_slot=2 * k + 1))
+        gpu_ctx.align_set_trace(200)
+        res_dev = gpu_ctx.sparse_align_batch(jobs)
+        a, b = gpu_ctx.align_chi2_ties()
+        its += a; ties += b
+        for k, seed in enumerate(seeds):
+            st, ref, cur, job = cases[k]
+            res_o, log_o = ob.sparse_align(job, ref, cur, max_log=200)
+            res_d, log_d = res_dev[k], gpu_ctx.align_fetch_trace(k)
+            iters_d += len(log_d); iters_o += len(log_o)
+            ang, tr, ok = Hh.pose_close(Hh.frame_pose(res_d.T, st), Hh.frame_pose(res_o.T, st))
+            t_inter = float(np.linalg.norm(np.asarray(res_o.T)[4:]))
+            ang2, dist2 = P.synth.se3_log_angle_dist(np.asarray(res_d.T), np.asarray(res_o.T))
+            tr2 = dist2 / max(t_inter, 1e-3)
+            worst["min_inter_translation_m"] = min(worst["min_inter_translation_m"], t_inter)
+            for key, val in (("rot_rad", ang), ("trans_rel", tr), ("inter_rot_rad", ang2), ("inter_trans_rel", tr2), ("inter_trans_abs_m", dist2)):
+                if val > worst[key]:
+                    worst[key], worst["seed_" + key] = val, seed
+            if not (ok and ang2 <= Hh.ROT_TOL and tr2 <= Hh.TRANS_REL_TOL):
+                failures.append({"seed": seed, "rot": ang, "trans_rel": tr, "inter_rot": ang2, "inter_trans_rel": tr2})
+            if not np.array_equal(res_d.seg_alive, res_o.seg_alive):
+                failures.append({"seed": seed, "what": "seg_alive differs"})
+            n, w = Hh.compare_align_logs(log_o, log_d)      # asserts n_meas equality on every shared iteration
+            worst_lin["H"] = max(worst_lin["H"], float(w["H"])); worst_lin["x"] = max(worst_lin["x"], float(w["x"]))
+            worst_lin["chi2"] = max(worst_lin["chi2"], float(w["chi2"]))
+            # (1e-11 while the poses are equal to rounding; a few 1e-6 once one patch position has moved by a float ulp)
+            if not (n >= 1 and w["H"] < 1e-4):
+                failures.append({"seed": seed, "what": "linearisation differs on the shared records", "worst": {k_: float(v_) for k_, v_ in w.items()}})
+            if Hh.same_path(log_o, log_d):
+                assert res_d.n_meas == res_o.n_meas and res_d.n_tracked == res_o.n_tracked, seed
+                assert res_d.iters_per_level == res_o.iters_per_level, seed
             else:
-                xo, xd = float(np.max(np.abs(a["x"]))), float(np.max(np.abs(b["x"])))
-                assert (xo <= 1e-6) != (xd <= 1e-6) and abs(xo - 1e-6) < 2e-8 and abs(xd - 1e-6) < 2e-8, (seed, xo, xd)
-                info.update(kind="eps near tie", x_norm_oracle=xo, x_norm_device=xd)
-            different.append(info)
-    out = {"what": "40 seeds (4000..4039) of BASELINE config 2 (640x480, 200 points + 80 segments, levels 3..1): HIP path vs CPU oracle",
-           "bar": {"rot_rad": Hh.ROT_TOL, "trans_rel": Hh.TRANS_REL_TOL}, "worst": worst, "seeds_with_different_gn_path": len(different),
-           "different": different, "gn_iterations_device": iters_d, "gn_iterations_oracle": iters_o}
+                k_ = Hh.common_prefix(log_o, log_d) - 1
+                ra, rb = log_o[k_], log_d[k_]
+                info = {"seed": seed, "oracle_iters": res_o.iters_per_level[:5], "device_iters": res_d.iters_per_level[:5],
+                        "shared_records": k_ + 1, "level": ra["level"], "iter": ra["iter"], "accepted": [ra["accepted"], rb["accepted"]],
+                        "new_chi2": [ra["new_chi2"], rb["new_chi2"]],
+                        "x_norm": [float(np.max(np.abs(ra["x"]))), float(np.max(np.abs(rb["x"])))]}
+                if k_ >= 1:
+                    info["prev_chi2"] = [log_o[k_ - 1]["new_chi2"], log_d[k_ - 1]["new_chi2"]]
+                # the two paths may part only on a decision that hangs on the last bits (see the docstring)
+                if ra["accepted"] != rb["accepted"]:
+                    gaps = [abs(info["new_chi2"][i] - info["prev_chi2"][i]) / info["prev_chi2"][i] for i in range(2)] if k_ >= 1 else [1.0, 1.0]
+                    info["kind"], info["chi2_gap_rel"] = "chi2 within 4 float ulps", gaps
+                    if not max(gaps) <= 4 * 1.2e-7:
+                        failures.append({"seed": seed, "what": "paths part on a chi2 comparison that is not a last-bit tie", "info": info})
+                else:
+                    info["kind"] = "||x|| within 2 % of eps"
+                    if not all(abs(v - 1e-6) < 2e-8 for v in info["x_norm"]):
+                        failures.append({"seed": seed, "what": "paths part without a near tie of either stopping rule", "info": info})
+                different.append(info)
+    out = {"what": f"{n_seeds} seeds ({seed0}..{seed0 + n_seeds - 1}) of BASELINE {tag} ({W}x{H}, {npts} points + {nseg} segments, levels {maxl}..{minl}): "
+                   "HIP path vs CPU oracle",
+           "bar": {"rot_rad": Hh.ROT_TOL, "trans_rel": Hh.TRANS_REL_TOL,
+                   "applies_to": "cur_frame->T_f_w_ (relative to |t|) and T_cur_from_ref (relative to the inter-frame translation)"},
+           "worst": worst, "worst_per_record_while_paths_coincide": worst_lin, "seeds_with_different_gn_path": len(different), "different": different, "outside_the_bar": failures,
+           "gn_iterations_device": iters_d, "gn_iterations_oracle": iters_o,
+           "iterations_decided_on_exact_float_chi2": ties, "iterations_counted_by_the_device": its}
     root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(root, "gpurun_out", "parity_seed_sweep.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(root, "gpurun_out", f"parity_seed_sweep_{tag}.json"), "w"), indent=1)
     print(json.dumps(out))
+    assert not failures, failures
+    assert len(different) <= max(2, n_seeds // 25), different     # measured: 2 of 150 (config 2), 1 of 60 (config 3)
 
 
 def test_device_trace_against_scipy(P, ob, gpu_ctx):
@@ -717,6 +766,7 @@ def test_full_size_properties(P, gpu_ctx):
     B, W, H = 32, 640, 480
     streams = [P.synth.make_align_stream(2000 + i, W, H, 200, 80, max_level=3) for i in range(B)]
     imgs = P.synth.render_streams(streams, device="cuda")
+    torch.cuda.synchronize()   # the library enqueues on its own stream: the rendered images must be complete before it reads them
     gpu_ctx.config_pyramids(2 * B, W, H, 4)
     gpu_ctx.build_pyramids_dev(0, 2 * B, imgs.data_ptr(), W, W * H, 0)
     gpu_ctx.synchronize()
