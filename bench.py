@@ -17,6 +17,8 @@ workload, one GPU -- `latency`: the small-batch operating points (1 / 8 / 64 str
 BASELINE config 4's 8 streams per GPU see) and the C++ drop-in's per-call wall time including the PCIe upload.
 Other workloads (extra lines for profiles/, the driver's invocation is the default one):
   --config 3   BASELINE configs[2]: 1280x720, 400 points + 150 segments, 5-image pyramid, levels 4..2
+  --config 4   BASELINE configs[3]: 64 streams in eight shards of 8 (one shard per GPU at --gpus 8; on fewer GPUs a rank runs its
+               shards back to back), pose all-gather through the C ABI (plsvo_gather_poses) every step
   --config 5   BASELINE configs[4]: pose_optimizer only, 500 points + 200 segments, 10 iterations
 """
 import argparse
@@ -41,10 +43,16 @@ BYTES_PER_PATCH_ITER = 485      # residual/Jacobian, per patch-i
 BYTES_PER_POINT_ITER = 24       # pose-opt, per point-iteration
 BYTES_PER_SEG_ITER = 40         # pose-opt, per segment-iteration
 # what align_fused_kernel itself requests: per patch-iteration 192 B of ref/dx/dy cache + 24 B 3-D point
-# + 2 lanes x 3 rows x 2 aligned dwords of the current image; per patch-level 4 lanes x 4 rows x 3 dwords of the reference
-# image read, 192 + 24 + 8 B written
+# + 2 lanes x 3 rows x 2 aligned dwords of the current image (+ 64 B of chi2 terms written per POINT patch-iteration); per
+# patch-level 4 lanes x 4 rows x 3 dwords of the reference image read, 192 + 24 + 8 B written
 OWN_BYTES_PER_PATCH_ITER = 192 + 24 + 48
 OWN_BYTES_PER_PATCH_LEVEL = 192 + 192 + 24 + 8
+CHI_BYTES_PER_POINT_ITER = 64
+# the bytes THIS formulation cannot avoid moving (the bound `roofline.frac` is priced against): per patch-iteration the 5x5 u8
+# window of the current image, the cached reference patch + gradients (3 x 16 floats) and the 3-D point; per point
+# patch-iteration also the 16 chi2 terms; per patch-level the 7x7 u8 window of the reference image read, cache + point written
+MIN_BYTES_PER_PATCH_ITER = 25 + 192 + 24
+MIN_BYTES_PER_PATCH_LEVEL = 49 + 192 + 24
 
 METRIC = "sparse-align+pose-opt frames/sec, 640×480, ~200 pts+80 lines; 1/2/4/8 GPU"   # BASELINE.json's metric, verbatim
 CONFIGS = {
@@ -55,6 +63,10 @@ CONFIGS = {
             metric="sparse-align+pose-opt frames/sec, 1280×720, 400 pts+150 lines (BASELINE configs[2])",
             workload="BASELINE configs[2]: 1280x720, 400 points + 150 line segments, 5-image pyramid (levels 4..2 = the reference's "
                      "defaults, src/config.cpp:98-99), sparse_img_align (<=30 GN it/level) + pose_optimizer (<=10 it, Tukey/MAD)"),
+    4: dict(W=640, H=480, pts=200, seg=80, pyr=4, maxl=3, minl=1, batch=8, shards=8, pose_pts=200, pose_seg=80,
+            metric="sparse-align+pose-opt frames/sec, 64 streams of 640×480 (~200 pts+80 lines) in 8 shards of 8 (BASELINE configs[3])",
+            workload="BASELINE configs[3]: 64 independent 640x480 streams (200 points + 80 line segments, levels 3..1) in eight shards of 8 streams, "
+                     "one shard per GPU on an 8-GPU node (with fewer GPUs a rank runs its shards back to back), pose all-gather per step"),
     5: dict(W=640, H=480, pts=0, seg=0, pyr=0, maxl=0, minl=0, batch=32768, pose_pts=500, pose_seg=200,
             metric="pose-opt frames/sec, 500 pts+200 lines, 10 GN iterations (BASELINE configs[4])",
             workload="BASELINE configs[4]: pose_optimizer::optimizeGaussNewton only, 500 points + 200 line segments, <=10 iterations, "
@@ -82,10 +94,11 @@ def host_cores():
     return n
 
 
-def offline_traffic(B):
-    """HBM-side traffic of the dominant kernel from the committed PMC passes (profiles/hbm_traffic.json): measured OFFLINE with
-    rocprofv3 on this same command, stored per stream so that it follows --batch.  Returns (bytes per launch or None, source)."""
-    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def offline_traffic(B, config=2):
+    """HBM-side traffic of the dominant kernel from the committed PMC passes (profiles/hbm_traffic.json for the default workload,
+    profiles/hbm_traffic_config3.json for --config 3): measured OFFLINE with rocprofv3 on this same command, stored per stream so
+    that it follows --batch.  Returns (bytes per launch or None, source, uncorrected bytes)."""
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json" if config == 2 else f"hbm_traffic_config{config}.json")
     try:
         d = json.load(open(tfile))
         per_stream = d.get("align_fused_kernel_bytes_per_stream")
@@ -180,6 +193,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="CPU-baseline budget (rank 0, N=1 only): half single-thread, half all cores")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the small-batch / per-call latency leg")
+    ap.add_argument("--dist-selftest", action="store_true", help="run the N>1 code path (process group, RCCL communicator, pose copy + "
+                    "plsvo_gather_poses every step) with a single rank: what a 1-GPU box can exercise of it")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     pose_only = args.config == 5
@@ -191,8 +206,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.dist_selftest
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
@@ -201,54 +218,85 @@ def main():
     capi, synth, abi, D = P.capi, P.synth, P.abi, P.dist
     B = args.batch if args.batch > 0 else cfg["batch"]
     W, H = cfg["W"], cfg["H"]
+    # shards: blocks of B streams with their own context.  Normally one per rank; BASELINE configs[3] fixes eight of them, so with
+    # fewer than eight ranks a rank owns several and runs them back to back.
+    shards_total = cfg.get("shards", world)
+    if shards_total % world:
+        raise SystemExit(f"--config {args.config} has {shards_total} shards: --gpus must divide it")
+    local_shards = shards_total // world
 
     # ONE stream for everything: the library enqueues on it (plsvo_hip_create_on_stream), it is torch's current stream while the
-    # benchmark runs, so torch.cuda.synchronize / the RCCL all-gather are ordered after the library's kernels and copies
+    # benchmark runs, so torch.cuda.synchronize and the RCCL all-gather (plsvo_gather_poses, same stream) are ordered after the
+    # library's kernels and copies
     stream = torch.cuda.Stream(dev)
     with torch.cuda.stream(stream):
-        ctx = capi.Context(local_rank, stream=stream.cuda_stream)
-
-        # ---- synthetic inputs, generated in HBM (untimed) ----
-        seeds = D.rank_seeds(rank, world, B)          # 1234 + global stream index
-        streams, align_jobs = [], []
-        if not pose_only:
-            streams = [synth.make_align_stream(s, W, H, cfg["pts"], cfg["seg"], max_level=cfg["maxl"]) for s in seeds]
-            ctx.config_pyramids(2 * B, W, H, cfg["pyr"])
-            chunk = 256 if W <= 640 else 64
-            for c0 in range(0, B, chunk):
-                sub = streams[c0:c0 + chunk]
-                imgs = synth.render_streams(sub, device=dev)                      # [b, 2, H, W] u8 in HBM
-                ctx.build_pyramids_dev(2 * c0, 2 * len(sub), imgs.data_ptr(), W, W * H, 0)   # device half-sampler
-                ctx.synchronize()
-                del imgs
-            align_jobs = [P.align_job_from_stream(s, cfg["maxl"], cfg["minl"], ref_slot=2 * i, cur_slot=2 * i + 1) for i, s in enumerate(streams)]
-            ctx.align_stage(align_jobs)      # features + job descriptors -> HBM; the timed region only launches kernels
-        pose_frames = [synth.make_poseopt_frame(s, cfg["pose_pts"], cfg["pose_seg"], W, H) for s in seeds]
-        pose_jobs = [P.poseopt_job_from_frame(f) for f in pose_frames]
-        ctx.poseopt_stage(pose_jobs)
-        ctx.synchronize()
+        shard = []      # per local shard: dict(ctx, streams, align_jobs, pose_frames, pose_jobs)
+        for v in range(local_shards):
+            c = capi.Context(local_rank, stream=stream.cuda_stream)
+            seeds = D.rank_seeds(rank * local_shards + v, shards_total, B)          # 1234 + global stream index
+            streams, align_jobs = [], []
+            if not pose_only:
+                streams = [synth.make_align_stream(s_, W, H, cfg["pts"], cfg["seg"], max_level=cfg["maxl"]) for s_ in seeds]
+                c.config_pyramids(2 * B, W, H, cfg["pyr"])
+                chunk = 256 if W <= 640 else 64
+                for c0 in range(0, B, chunk):
+                    sub = streams[c0:c0 + chunk]
+                    imgs = synth.render_streams(sub, device=dev)                      # [b, 2, H, W] u8 in HBM
+                    c.build_pyramids_dev(2 * c0, 2 * len(sub), imgs.data_ptr(), W, W * H, 0)   # device half-sampler
+                    c.synchronize()
+                    del imgs
+                align_jobs = [P.align_job_from_stream(s_, cfg["maxl"], cfg["minl"], ref_slot=2 * i, cur_slot=2 * i + 1) for i, s_ in enumerate(streams)]
+                c.align_stage(align_jobs)      # features + job descriptors -> HBM; the timed region only launches kernels
+            pose_frames = [synth.make_poseopt_frame(s_, cfg["pose_pts"], cfg["pose_seg"], W, H) for s_ in seeds]
+            pose_jobs = [P.poseopt_job_from_frame(f) for f in pose_frames]
+            c.poseopt_stage(pose_jobs)
+            c.synchronize()
+            shard.append(dict(ctx=c, streams=streams, align_jobs=align_jobs, pose_frames=pose_frames, pose_jobs=pose_jobs))
+        ctx, streams, align_jobs, pose_frames, pose_jobs = (shard[0][k] for k in ("ctx", "streams", "align_jobs", "pose_frames", "pose_jobs"))
 
         def step_local():
-            if not pose_only:
-                ctx.align_run()
-            ctx.poseopt_run()
+            for sh in shard:
+                if not pose_only:
+                    sh["ctx"].align_run()
+                sh["ctx"].poseopt_run()
 
-        local_poses = torch.empty((B, 7), dtype=torch.float64, device=dev)
+        n_local = local_shards * B
+        local_poses = torch.empty((n_local, 7), dtype=torch.float64, device=dev)
+
+        def copy_local(t):
+            for v, sh in enumerate(shard):
+                sh["ctx"].poseopt_copy_poses(t.data_ptr() + v * B * 7 * 8)
+
+        comm = P.rccl.comm_over_process_group() if use_dist else None       # the gather is the C ABI's, on the library's stream
+        def gather(local, out):
+            ctx.gather_poses(comm, local.data_ptr(), n_local, out.data_ptr())
+
         def timers_on():                        # hipEvent pairs around every launch of the timed steps only
-            ctx.set_profiling(True)
-            ctx.reset_profiling()
-        elapsed, gathered = D.timed_sharded_steps(step_local, lambda t: ctx.poseopt_copy_poses(t.data_ptr()), local_poses,
-                                                  args.steps, args.warmup, device_sync=lambda: torch.cuda.synchronize(dev), before_timed=timers_on)
-        ctx.set_profiling(False)
+            for sh in shard:
+                sh["ctx"].set_profiling(True)
+                sh["ctx"].reset_profiling()
+        elapsed, gathered = D.timed_sharded_steps(step_local, copy_local, local_poses, args.steps, args.warmup,
+                                                  device_sync=lambda: torch.cuda.synchronize(dev), before_timed=timers_on,
+                                                  gather=gather if use_dist else None, force_gather=args.dist_selftest)
+        for sh in shard:
+            sh["ctx"].set_profiling(False)
+        if comm is not None:
+            torch.cuda.synchronize(dev)
+            P.rccl.comm_destroy(comm)
 
         # ---- roofline of the dominant kernel, from live hipEvent timings on the launch stream ----
-        lvl_ms, lvl_launches = (0.0, 0) if pose_only else ctx.kernel_time(abi.K_ALIGN_LEVEL)
-        pose_ms, pose_launches = ctx.kernel_time(abi.K_POSEOPT)
+        lvl_ms, lvl_launches, pose_ms, pose_launches = 0.0, 0, 0.0, 0
+        for sh in shard:
+            if not pose_only:
+                a_ms, a_n = sh["ctx"].kernel_time(abi.K_ALIGN_LEVEL)
+                lvl_ms += a_ms; lvl_launches += a_n
+            p_ms, p_n = sh["ctx"].kernel_time(abi.K_POSEOPT)
+            pose_ms += p_ms; pose_launches += p_n
         res = [] if pose_only else ctx.align_fetch()
         pres = ctx.poseopt_fetch()
         result = None
         if rank == 0:
-            frames = world * B * args.steps
+            frames = world * n_local * args.steps
             value = frames / elapsed
             if pose_only:
                 pt_it, seg_it = ctx.poseopt_work()
@@ -261,34 +309,70 @@ def main():
                             "definition": "SURVEY.md 8(d) algorithmic bytes (24 B per point-iteration, 40 B per segment-iteration, device-side counters) / "
                                           "hipEvent time of the launch; informational: the kernel is latency-bound by construction (DESIGN.md 3.2)"}
             else:
-                patch_levels, patch_iters = ctx.align_work()       # counted on the device, per run of the staged batch
-                alg_bytes = patch_levels * BYTES_PER_PATCH_LEVEL + patch_iters * BYTES_PER_PATCH_ITER
-                own_bytes = patch_levels * OWN_BYTES_PER_PATCH_LEVEL + patch_iters * OWN_BYTES_PER_PATCH_ITER
+                patch_levels = patch_iters = 0                      # counted on the device, per run of the staged batch
+                for sh in shard:
+                    a_, b_ = sh["ctx"].align_work()
+                    patch_levels += a_; patch_iters += b_
+                pt_iters = sum(sh["ctx"].align_work_points() for sh in shard)
+                survey_bytes = patch_levels * BYTES_PER_PATCH_LEVEL + patch_iters * BYTES_PER_PATCH_ITER
+                own_bytes = patch_levels * OWN_BYTES_PER_PATCH_LEVEL + patch_iters * OWN_BYTES_PER_PATCH_ITER + pt_iters * CHI_BYTES_PER_POINT_ITER
+                min_bytes = patch_levels * MIN_BYTES_PER_PATCH_LEVEL + patch_iters * MIN_BYTES_PER_PATCH_ITER + pt_iters * CHI_BYTES_PER_POINT_ITER
+                launches_per_step = max(lvl_launches, 1) / max(args.steps, 1)          # one per shard
                 avg_ms = lvl_ms / max(lvl_launches, 1)
-                achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-                traffic, traffic_src, traffic_raw = offline_traffic(B) if args.config == 2 else (None, None, None)
+                per_launch = lambda nbytes: nbytes / launches_per_step
+                rate = lambda nbytes: per_launch(nbytes) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+                achieved = rate(min_bytes)
+                traffic, traffic_src, traffic_raw = offline_traffic(n_local, args.config) if args.config in (2, 3) else (None, None, None)
                 roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                             "traffic": traffic, "traffic_source": traffic_src, "traffic_uncorrected": traffic_raw,
                             "kernel": "align_fused_kernel", "avg_launch_ms": round(avg_ms, 4), "launches": int(lvl_launches),
-                            "algorithmic_bytes_per_launch": int(alg_bytes),
-                            "definition": "ALGORITHMIC bytes per SURVEY.md 8(d) (485 B per patch-iteration, 497 B per patch-level, fixed figures that "
-                                          "charge a 384-B per-pixel Jacobian cache this kernel never materialises; device-side work counters) / "
-                                          "hipEvent time of the launch on the launch stream.  NOT measured DRAM bandwidth: see kernel_requested_*, traffic",
-                            "kernel_requested_bytes_per_launch": int(own_bytes),
-                            "kernel_requested_GBps": round(own_bytes / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else 0.0,
-                            "patch_levels_per_step": int(patch_levels), "patch_iters_per_step": int(patch_iters)}
+                            "algorithmic_bytes_per_launch": int(per_launch(min_bytes)),
+                            "definition": "bytes this formulation cannot avoid moving (per patch-iteration: 25 B window of the current image + 192 B "
+                                          "cached reference patch and gradients + 24 B 3-D point, + 64 B of chi2 terms per POINT patch-iteration; per "
+                                          "patch-level: 49 B reference window + 216 B cache and point written; device-side work counters) / hipEvent time "
+                                          "of the launch on the launch stream / 8 TB/s.  A bound: no workload can exceed 1.  The kernel's own requests "
+                                          "(sector-granular gathers: kernel_requested_*) and the memory-side traffic (traffic, offline PMC passes) sit above it",
+                            "kernel_requested_bytes_per_launch": int(per_launch(own_bytes)),
+                            "kernel_requested_GBps": round(rate(own_bytes), 1),
+                            "traffic_over_requested": round(traffic / per_launch(own_bytes), 3) if traffic else None,
+                            "traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic and avg_ms > 0 else None,
+                            "work_rate_survey_units": {"GBps": round(rate(survey_bytes), 1), "bytes_per_launch": int(per_launch(survey_bytes)),
+                                                       "note": "SURVEY.md 8(d): 485 B per patch-iteration, 497 B per patch-level -- the reference's layout, "
+                                                               "charging a 384-B per-pixel Jacobian cache this kernel never materialises: a work rate, not bandwidth"},
+                            "patch_levels_per_step": int(patch_levels), "patch_iters_per_step": int(patch_iters), "point_patch_iters_per_step": int(pt_iters)}
             result = {
                 "metric": cfg["metric"],
                 "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                "config": {"workload": cfg["workload"], "streams_per_gpu": B, "global_batch": world * B,
-                           "parallelism": f"streams sharded x{world}, RCCL all-gather of poses" if world > 1 else "single GPU"},
+                "config": {"workload": cfg["workload"], "streams_per_gpu": n_local, "global_batch": world * n_local,
+                           "shards": shards_total, "streams_per_shard": B,
+                           "parallelism": (f"streams sharded x{world}, pose all-gather through plsvo_gather_poses (RCCL)" if world > 1 else
+                                           ("single GPU, N>1 code path with one rank (--dist-selftest)" if args.dist_selftest else "single GPU"))},
                 "roofline": roofline,
                 "kernel_ms_per_step": {"align_fused": round(lvl_ms / args.steps, 4), "pose_opt": round(pose_ms / args.steps, 4)},
             }
+            if local_shards > 1:
+                # every shard alone: K steps, then a host synchronisation (what one GPU of the 8-GPU deployment would do per step)
+                per = []
+                for sh in shard:
+                    c = sh["ctx"]
+                    t0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        if not pose_only:
+                            c.align_run()
+                        c.poseopt_run()
+                    c.synchronize()
+                    per.append((time.perf_counter() - t0) / args.steps)
+                result["per_shard"] = {"us_per_step": [round(1e6 * t, 1) for t in per], "us_per_step_mean": round(1e6 * float(np.mean(per)), 1),
+                                       "frames_per_s_of_one_shard": round(B / float(np.mean(per)), 1),
+                                       "note": f"{local_shards} shards of {B} streams run back to back on this GPU; with one shard per GPU the step "
+                                               "time of the job is the slowest shard's (plus the pose all-gather): that run is the driver's --gpus 8"}
             if not pose_only and hasattr(ctx.L, "plsvo_align_chi2_ties"):
-                gn_it, gn_ties = ctx.align_chi2_ties()
+                gn_it = gn_ties = 0
+                for sh in shard:
+                    a_, b_ = sh["ctx"].align_chi2_ties()
+                    gn_it += a_; gn_ties += b_
                 result["chi2_ties"] = {"gn_iterations_per_step": int(gn_it), "decided_on_exact_float_sums": int(gn_ties),
                                        "what": "iterations whose `new_chi2 > chi2_` decision was taken on the reference's sequential float sums "
                                                "(the two values closer than the sums' own rounding noise)"}
@@ -337,8 +421,9 @@ def main():
                 if cb and "B8" in result["latency"]:
                     result["latency"]["B8_vs_cpu_all_cores"] = round(result["latency"]["B8"]["frames_per_s"] / cb["value"], 2)
             print(json.dumps(result), flush=True)
-        ctx.close()
-    if world > 1:
+        for sh in shard:
+            sh["ctx"].close()
+    if use_dist:
         dist.destroy_process_group()
 
 

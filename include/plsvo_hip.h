@@ -63,6 +63,13 @@ int plsvo_hip_create(int device_id, void* stream, plsvo_ctx** out);
  * non-NULL stream: plsvo_hip_create(.., NULL, ..) enqueues on a private stream the caller's work is not ordered with. */
 int plsvo_hip_create_on_stream(int device_id, void* stream, plsvo_ctx** out);
 void plsvo_hip_destroy(plsvo_ctx* ctx);
+/* Options of a context.  PLSVO_OPT_LDLT_FLAVOUR selects the zero-pivot rule of the 6x6 `H.ldlt().solve()` the two optimisers call
+ * (src/sparse_img_align.cpp:699, src/pose_optimizer.cpp:170), which changed between the Eigen releases PL-SVO's named platforms
+ * ship: 320 (default) = Eigen 3.1 ... 3.2.1 (Ubuntu 12.04 / 14.04: stop at eps * max|A_ii|, drop |d| <= eps * max|D|),
+ * 330 = Eigen 3.2.2 and later (Ubuntu 16.04's 3.3-beta: exact zeros only).  Identical arithmetic on every full-rank system; they
+ * differ with fewer than three point observations.  Takes effect at the next *_stage call. */
+#define PLSVO_OPT_LDLT_FLAVOUR 1
+int plsvo_hip_set_option(plsvo_ctx* ctx, int option, int value);
 const char* plsvo_hip_last_error(const plsvo_ctx* ctx);   /* ctx may be NULL: last create error */
 void* plsvo_hip_stream(plsvo_ctx* ctx);                   /* the hipStream_t all work is enqueued on */
 int plsvo_hip_synchronize(plsvo_ctx* ctx);
@@ -193,6 +200,8 @@ int plsvo_align_copy_poses(plsvo_ctx* ctx, double* d_dst);
  *   patch_levels = sum over jobs and levels of patches precomputed (497 B each)
  *   patch_iters  = sum over jobs, levels and GN iterations of patches evaluated (485 B each) */
 int plsvo_align_work(plsvo_ctx* ctx, uint64_t* patch_levels, uint64_t* patch_iters);
+/* of patch_iters, the evaluations of POINT patches (those also write 64 B of per-pixel chi2 terms, see plsvo_align_chi2_ties) */
+int plsvo_align_work_points(plsvo_ctx* ctx, uint64_t* point_patch_iters);
 
 /* parity accounting of the last plsvo_align_run: Gauss-Newton iterations in total, and how many of them had their
  * `new_chi2 > chi2_` decision ([ext] vk::NLLSSolver::optimizeGaussNewton) taken on the reference's own sequential float sums

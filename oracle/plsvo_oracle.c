@@ -13,6 +13,7 @@
 #include "plsvo_oracle.h"
 
 #include <float.h>
+#include <stdatomic.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -159,13 +160,13 @@ void plsvo_oracle_se3_matrix(const double T[7], double R[9], double t[3]) {
  * differ on rank-deficient normal equations (fewer than three point observations), where 330 divides rounding residue by
  * rounding residue and 320 returns zero components for the unobservable directions.
  * NaN/Inf propagate into x. */
-static int g_ldlt_flavour = 320;
-void plsvo_oracle_set_ldlt_flavour(int flavour) { g_ldlt_flavour = (flavour == 330) ? 330 : 320; }
-int plsvo_oracle_get_ldlt_flavour(void) { return g_ldlt_flavour; }
+static _Atomic int g_ldlt_flavour = 320;   /* read by the threads of plsvo_oracle_bench while a test may set it: atomic */
+void plsvo_oracle_set_ldlt_flavour(int flavour) { atomic_store(&g_ldlt_flavour, (flavour == 330) ? 330 : 320); }
+int plsvo_oracle_get_ldlt_flavour(void) { return atomic_load(&g_ldlt_flavour); }
 
 static void ldlt_solve_n(const int N, const double* A, const double* b, double* x) {
   double m[6][6]; int tr[6];
-  const int flavour = g_ldlt_flavour;
+  const int flavour = atomic_load(&g_ldlt_flavour);
   double cutoff = 0.0;
   for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) m[i][j] = A[i * N + j];
   for (int k = 0; k < N; ++k) {

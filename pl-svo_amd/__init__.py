@@ -16,7 +16,7 @@ synth = _il.import_module(__name__ + ".synth")
 
 
 def __getattr__(name):
-    if name in ("capi", "trajectory", "dist", "adapter_io", "sequence"):
+    if name in ("capi", "trajectory", "dist", "adapter_io", "sequence", "rccl"):
         return _il.import_module(__name__ + "." + name)
     raise AttributeError(name)
 

@@ -15,11 +15,11 @@ LIB_PATH = os.environ.get("PLSVO_HIP_LIB", os.path.join(_HERE, "libplsvo_hip.so"
 
 # every symbol include/plsvo_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "plsvo_hip_create", "plsvo_hip_create_on_stream", "plsvo_align_slot_layout", "plsvo_hip_destroy", "plsvo_hip_last_error", "plsvo_hip_stream", "plsvo_hip_synchronize",
+    "plsvo_hip_create", "plsvo_hip_create_on_stream", "plsvo_hip_set_option", "plsvo_align_slot_layout", "plsvo_hip_destroy", "plsvo_hip_last_error", "plsvo_hip_stream", "plsvo_hip_synchronize",
     "plsvo_hip_config_pyramids", "plsvo_hip_upload_pyramid", "plsvo_hip_build_pyramid", "plsvo_hip_build_pyramids_dev",
     "plsvo_hip_download_level",
     "plsvo_sparse_align", "plsvo_sparse_align_batch", "plsvo_align_stage", "plsvo_align_run", "plsvo_align_fetch",
-    "plsvo_align_set_trace", "plsvo_align_fetch_trace", "plsvo_align_poses_dev", "plsvo_align_copy_poses", "plsvo_align_work", "plsvo_align_chi2_ties",
+    "plsvo_align_set_trace", "plsvo_align_fetch_trace", "plsvo_align_poses_dev", "plsvo_align_copy_poses", "plsvo_align_work", "plsvo_align_work_points", "plsvo_align_chi2_ties",
     "plsvo_pose_optimize", "plsvo_pose_optimize_batch", "plsvo_poseopt_stage", "plsvo_poseopt_run", "plsvo_poseopt_fetch",
     "plsvo_poseopt_set_trace", "plsvo_poseopt_fetch_trace", "plsvo_poseopt_poses_dev", "plsvo_poseopt_copy_poses", "plsvo_poseopt_work",
     "plsvo_structure_optimize", "plsvo_match_direct", "plsvo_reproject", "plsvo_trajectory_record", "plsvo_update_seeds",
@@ -53,6 +53,7 @@ def lib():
         "plsvo_hip_create": (C.c_int, [C.c_int, vp, C.POINTER(ctxp)]),
         "plsvo_hip_create_on_stream": (C.c_int, [C.c_int, vp, C.POINTER(ctxp)]),
         "plsvo_hip_destroy": (None, [ctxp]),
+        "plsvo_hip_set_option": (C.c_int, [ctxp, C.c_int, C.c_int]),
         "plsvo_hip_last_error": (C.c_char_p, [ctxp]),
         "plsvo_hip_stream": (vp, [ctxp]),
         "plsvo_hip_synchronize": (C.c_int, [ctxp]),
@@ -73,6 +74,7 @@ def lib():
         "plsvo_poseopt_copy_poses": (C.c_int, [ctxp, vp]),
         "plsvo_align_work": (C.c_int, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "plsvo_align_chi2_ties": (C.c_int, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "plsvo_align_work_points": (C.c_int, [ctxp, C.POINTER(C.c_uint64)]),
         "plsvo_pose_optimize": (C.c_int, [ctxp, C.POINTER(abi.PoseOptIn), C.POINTER(abi.PoseOptOut)]),
         "plsvo_pose_optimize_batch": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.PoseOptIn), C.POINTER(abi.PoseOptOut)]),
         "plsvo_poseopt_stage": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.PoseOptIn)]),
@@ -122,6 +124,10 @@ class Context:
             raise PlsvoError(rc, (self.L.plsvo_hip_last_error(None) or b"").decode())
         self.h = h
         self._keep = None
+
+    def set_ldlt_flavour(self, flavour):
+        """320 (Eigen 3.1 ... 3.2.1, default) or 330 (Eigen 3.2.2+): zero-pivot rule of the optimisers' 6x6 LDLT solve"""
+        self._chk(self.L.plsvo_hip_set_option(self.h, 1, int(flavour)))
 
     def close(self):
         if getattr(self, "h", None):
@@ -239,6 +245,11 @@ class Context:
         b = C.c_uint64(0)
         self._chk(self.L.plsvo_align_work(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def align_work_points(self):
+        a = C.c_uint64(0)
+        self._chk(self.L.plsvo_align_work_points(self.h, C.byref(a)))
+        return a.value
 
     def align_chi2_ties(self):
         """(Gauss-Newton iterations, iterations decided on the exact float chi2 sums) of the last align_run"""

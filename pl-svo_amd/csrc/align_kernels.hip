@@ -240,7 +240,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 
   extern __shared__ __align__(16) unsigned char smem[];
   double* s_red = reinterpret_cast<double*>(smem);                       // ROWS * 32: row partials
-  double* s_pose = s_red + ROWS * 32;                                    // 0..8 R, 9..11 t, 12..18 model, 19..25 old model, 26 chi2_, 27 #evals, 28/29 work counters
+  double* s_pose = s_red + ROWS * 32;                                    // 0..8 R, 9..11 t, 12..18 model, 19..25 old model, 26 chi2_, 27 #evals, 28/29/31 work counters, 30 n_meas_ of the previous iteration
   double* s_tot = s_pose + 32;                                           // block totals of the last iteration: 21 H, 6 Jres, chi2, n_meas, evals
   int* s_ctl = reinterpret_cast<int*>(s_tot + 32);                       // 0 break, 1 stop, 2 iterations done, 3 error, 5 #patches of the level
   int2* s_meta = reinterpret_cast<int2*>(s_ctl + 32);                    // cap: x = feature (>= 0 point, < 0 segment -1-x, SLOT_HOLE), y = first slot | N << 20
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       st->chi2 = 1e10; st->n_meas = 0; st->stop = 0; st->log_count = 0; st->error = 0;
       for (int k = 0; k < 36; ++k) st->H[k] = 0.0;
       for (int k = 0; k < PLSVO_MAX_LEVELS; ++k) st->iters[k] = 0;
-      st->patch_levels = 0; st->patch_iters = 0; st->chi2_ties = 0;
+      st->patch_levels = 0; st->patch_iters = 0; st->patch_iters_pt = 0; st->chi2_ties = 0;
       for (int k = 0; k < 8; ++k) st->phase_ticks[k] = 0;
       if (nothing && b.poses) for (int k = 0; k < 7; ++k) b.poses[7 * job_id + k] = b.T0[7 * job_id + k];
     }
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   block_sync<T>();   // seg_alive / state of this job initialised (same workgroup: visible after the barrier)
   if (tid == 0) {
     for (int k = 0; k < 7; ++k) { s_pose[12 + k] = st->T[k]; s_pose[19 + k] = st->T[k]; }
-    s_pose[26] = st->chi2; s_pose[28] = 0.0; s_pose[29] = 0.0;
+    s_pose[26] = st->chi2; s_pose[28] = 0.0; s_pose[29] = 0.0; s_pose[31] = 0.0;
     for (int k = 0; k < 32; ++k) s_tot[k] = 0.0;
     s_ctl[1] = st->stop; s_ctl[3] = 0; s_ctl[6] = 0;
   }
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 
       float* const chi_it = b.chi_terms + (size_t)(iter & 1) * b.chi_plane + (size_t)job.pt_off * 16;   // this iteration's plane of the points' chi2 terms
 
-      double acc[32];   // 0..20 H (upper, row-major), 21..26 Jres, 27 chi2, 28 n_meas, 29 evals, 30..31 unused
+      double acc[32];   // 0..20 H (upper, row-major), 21..26 Jres, 27 chi2, 28 n_meas, 29 evals, 30 evals of point patches, 31 unused
 #pragma unroll
       for (int k = 0; k < 32; ++k) acc[k] = 0.0;
 
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
               wh = 1.0; wj = 1.0;
               if (half == 0) { acc[27] += sChi; acc[28] += (double)PLSVO_PATCH_AREA; }
             }
-            if (live && half == 0) acc[29] += 1.0;
+            if (live && half == 0) { acc[29] += 1.0; if (!is_line) acc[30] += 1.0; }
             // -- 6x6 expansion shared by the lane pair: lane 0 adds r0 (A r0 + B r1)^T and D r0, lane 1 adds r1 (B r0 + C r1)^T and E r1
             if (wh != 0.0 || wj != 0.0) {
               const double xyz[3] = { X, Y, Z };
@@ -663,9 +663,9 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         if (lane < 30) s_tot[lane] = tot;
         TICK(3);
         double x[6];
-        wave_solve6_reg(tot, x);                                               // solve() :699
+        wave_solve6_reg(tot, x, job.ldlt_flavour);                             // solve() :699
         TICK(4);
-        const double chi_sum = readlane_f64(tot, 27), nm_d = readlane_f64(tot, 28), ev_d = readlane_f64(tot, 29);
+        const double chi_sum = readlane_f64(tot, 27), nm_d = readlane_f64(tot, 28), ev_d = readlane_f64(tot, 29), ev_pt = readlane_f64(tot, 30);
         const unsigned long long nm = (unsigned long long)(nm_d + 0.5);
         // computeResiduals returns float chi2 / n_meas_ (:171,192); chi_sum is the exact sum of the float terms, rounded once
         double new_chi2 = (double)((float)chi_sum / (float)nm);
@@ -684,6 +684,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         }
         if (lane == 0) {
           s_pose[27] += ev_d;
+          s_pose[31] += ev_pt;
           s_pose[30] = nm_d;                                                   // n_meas_ of this iteration, for the next one's tie
           s_ctl[2] += 1;
           if (tie) s_ctl[6] += 1;
@@ -747,6 +748,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     st->chi2 = s_pose[26];
     st->patch_levels += (unsigned long long)(s_pose[28] + 0.5);
     st->patch_iters += (unsigned long long)(s_pose[29] + 0.5);
+    st->patch_iters_pt += (unsigned long long)(s_pose[31] + 0.5);
     st->stop = s_ctl[1];
     st->chi2_ties += s_ctl[6];
     st->n_meas = (unsigned long long)(s_tot[28] + 0.5);

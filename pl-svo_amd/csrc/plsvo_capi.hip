@@ -3,7 +3,7 @@
 // hipEvent timing, RCCL gather.  All device work is enqueued on the ctx stream; nothing here computes
 // any part of the hot path on the CPU (there is no fallback).
 #include <hip/hip_runtime.h>
-#include <rocprofiler-sdk-roctx/roctx.h>
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -79,6 +79,10 @@ struct plsvo_ctx {
   std::string err;
   int cu_count = 0;
   size_t lds_per_block = 65536;
+  // experiment switches, read from the environment ONCE, at plsvo_hip_create (never on a launch path)
+  int env_align_threads = 0, env_align_lds_pad = 0, env_poseopt_threads = 0;
+  bool env_align_per_level = false, env_align_no_lpt = false, env_host_timing = false;
+  int ldlt_flavour = 320;   // plsvo_hip_set_option(PLSVO_OPT_LDLT_FLAVOUR)
 
   // pyramids
   DevBuf pyr_slab;
@@ -199,6 +203,12 @@ static int create_ctx(int device_id, void* stream, bool use_given_stream, plsvo_
     c->own_stream = true;
   }
   if (const char* s = getenv("PLSVO_LDS_LIMIT")) c->lds_per_block = (size_t)atol(s);
+  if (const char* s = getenv("PLSVO_ALIGN_THREADS")) { const int v = atoi(s); if (v == 64 || v == 128 || v == 256 || v == 512) c->env_align_threads = v; }
+  if (const char* s = getenv("PLSVO_ALIGN_LDS_PAD")) c->env_align_lds_pad = std::max(0, atoi(s));
+  if (const char* s = getenv("PLSVO_POSEOPT_THREADS")) { const int v = atoi(s); if (v == 64 || v == 256 || v == 512) c->env_poseopt_threads = v; }
+  if (const char* s = getenv("PLSVO_ALIGN_PER_LEVEL")) c->env_align_per_level = atoi(s) != 0;
+  c->env_align_no_lpt = getenv("PLSVO_ALIGN_NO_LPT") != nullptr;
+  c->env_host_timing = getenv("PLSVO_HOST_TIMING") != nullptr;
   *out = c;
   return PLSVO_OK;
 }
@@ -216,6 +226,17 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+extern "C" int plsvo_hip_set_option(plsvo_ctx* c, int option, int value) {
+  CTX_CHECK(c);
+  if (option == PLSVO_OPT_LDLT_FLAVOUR) {
+    if (value != 320 && value != 330) return fail(c, PLSVO_E_INVALID, "set_option: the LDLT flavour is 320 (Eigen 3.1 ... 3.2.1) or 330 (Eigen 3.2.2 and later)");
+    c->ldlt_flavour = value;
+    c->a_staged = false; c->p_staged = false;   // the rule travels with the staged jobs
+    return PLSVO_OK;
+  }
+  return fail(c, PLSVO_E_INVALID, "set_option: unknown option");
 }
 
 extern "C" const char* plsvo_hip_last_error(const plsvo_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
@@ -386,6 +407,9 @@ static int upload_blob(plsvo_ctx* c, DevBuf& buf, const Blob& blob) {
     if (c->pinned) { memcpy(c->pinned, blob.host.data(), blob.host.size()); src = c->pinned; }
   }
   HIP_TRY(c, hipMemcpyAsync(buf.p, src, blob.host.size(), hipMemcpyHostToDevice, c->stream));
+  // the source (the caller's Blob, or the ctx-wide pinned bounce buffer the next stage call writes into) must not be touched while
+  // the DMA is in flight, whatever early return follows: wait here (this is the one synchronisation a stage call makes)
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return PLSVO_OK;
 }
 
@@ -434,7 +458,7 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
     // 3-pixel border test of the level (src/sparse_img_align.cpp:299-301), get no slots.
     int ub_max = 0;
     long long ub_sum = 0;
-    J.long_mask = 0; J.reserved0 = 0;
+    J.long_mask = 0; J.ldlt_flavour = c->ldlt_flavour;
     for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) J.n_slots[l] = 0;
     std::vector<int> codes((size_t)std::max(a.n_seg, 1));
     for (int l = a.max_level; l >= a.min_level; --l) {
@@ -462,7 +486,7 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   // launch order: most patches (summed over the levels) first; stable, so equal jobs keep their batch order
   std::vector<int> order((size_t)n);
   for (int j = 0; j < n; ++j) order[(size_t)j] = j;
-  if (!getenv("PLSVO_ALIGN_NO_LPT")) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return work[(size_t)x] > work[(size_t)y]; });
+  if (!c->env_align_no_lpt) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return work[(size_t)x] > work[(size_t)y]; });
   int rc;
   const int slot_level0 = (gmax >= gmin && gmax >= 0) ? gmin : 0;
   const size_t total_seg = len.size();
@@ -486,7 +510,6 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   const size_t npt_total = ptpx.size() / 2 + 32;
   HIP_TRY(c, c->a_d_chi.ensure(2 * npt_total * 16 * sizeof(float)));   // two planes of the points' per-pixel chi2 terms
   if (c->a_trace_cap > 0) HIP_TRY(c, c->a_d_log.ensure((size_t)n * c->a_trace_cap * sizeof(plsvo_align_iterlog)));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
 
   AlignBatchDev& b = c->a_b;
   uint8_t* const base = c->a_d_blob.as<uint8_t>();
@@ -520,20 +543,39 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
 // how many threads it gets depends on how many frames there are to fill the chip with:
 //   large batches (throughput): 128 threads, several workgroups per CU hide each other's serial solve/update tails;
 //   small batches (latency):    512 threads, the whole CU works on one frame and a Gauss-Newton iteration is one or two rounds.
-// Environment overrides (experiments only): PLSVO_ALIGN_THREADS, PLSVO_ALIGN_PER_LEVEL, PLSVO_ALIGN_LDS_PAD.
+// Environment overrides (experiments only, read once at plsvo_hip_create): PLSVO_ALIGN_THREADS, PLSVO_ALIGN_PER_LEVEL, PLSVO_ALIGN_LDS_PAD.
 static void pick_align_config(const plsvo_ctx* c, int n_jobs, int cap, int scap, int* threads, size_t* lds) {
   const int cus = c->cu_count > 0 ? c->cu_count : 256;
   int t = 64;                            // >= 64 frames per CU: one wave per frame, no workgroup barrier at all
   if (n_jobs <= cus) t = 512;
   else if (n_jobs <= 4 * cus) t = 256;
   else if (n_jobs < 64 * cus) t = 128;
-  if (const char* s = getenv("PLSVO_ALIGN_THREADS")) { const int v = atoi(s); if (v == 64 || v == 128 || v == 256 || v == 512) t = v; }
+  if (c->env_align_threads) t = c->env_align_threads;
   *threads = t; *lds = align_level_lds_bytes(t, cap, scap);
-  if (const char* s = getenv("PLSVO_ALIGN_LDS_PAD")) *lds += (size_t)std::max(0, atoi(s));   // occupancy experiments: unused LDS bytes per workgroup
+  *lds += (size_t)c->env_align_lds_pad;   // occupancy experiments: unused LDS bytes per workgroup
 }
 
-// roctx range around the host side of an ABI call (rocprofv3 --marker-trace shows it; free when no tool is attached)
-namespace { struct RoctxRange { explicit RoctxRange(const char* name) { roctxRangePush(name); } ~RoctxRange() { roctxRangePop(); } }; }
+// roctx range around the host side of an ABI call (rocprofv3 --marker-trace shows it).  The marker library is looked up at run
+// time, once: the product library neither links against the profiler SDK nor fails to load without it.
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_GLOBAL);
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) { push = nullptr; pop = nullptr; }
+  }
+};
+const Roctx& roctx() { static const Roctx r; return r; }
+struct RoctxRange {
+  explicit RoctxRange(const char* name) { if (roctx().push) roctx().push(name); }
+  ~RoctxRange() { if (roctx().pop) roctx().pop(); }
+};
+}  // namespace
 
 extern "C" int plsvo_align_run(plsvo_ctx* c) {
   CTX_CHECK(c);
@@ -549,8 +591,7 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
   const int scap = (c->a_scap + 3) & ~3;
   pick_align_config(c, c->a_n, cap, scap, &threads, &lds);
   if (lds > c->lds_per_block) return fail(c, PLSVO_E_CAPACITY, "align_run: slot tables do not fit in LDS (too many features in one job)");
-  bool per_level = false;
-  if (const char* s = getenv("PLSVO_ALIGN_PER_LEVEL")) per_level = atoi(s) != 0;
+  const bool per_level = c->env_align_per_level;
   if (!per_level || !have_levels) {
     EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
     HIP_TRY(c, launch_align_levels(c->a_b, cap, scap, have_levels ? c->a_gmax : 0, have_levels ? c->a_gmin : 0, 1, threads, lds, c->stream));
@@ -597,7 +638,7 @@ extern "C" int plsvo_align_fetch(plsvo_ctx* c, int n, plsvo_align_out* out) {
 }
 
 extern "C" int plsvo_sparse_align_batch(plsvo_ctx* c, int n, const plsvo_align_in* in, plsvo_align_out* out) {
-  static const bool host_timing = getenv("PLSVO_HOST_TIMING") != nullptr;   // debug: wall time of the three steps on stderr
+  const bool host_timing = c && c->env_host_timing;   // debug: wall time of the three steps on stderr
   const auto t0 = std::chrono::steady_clock::now();
   int rc = plsvo_align_stage(c, n, in); if (rc) return rc;
   const auto t1 = std::chrono::steady_clock::now();
@@ -688,6 +729,19 @@ extern "C" int plsvo_align_work(plsvo_ctx* c, uint64_t* patch_levels, uint64_t* 
   return PLSVO_OK;
 }
 
+extern "C" int plsvo_align_work_points(plsvo_ctx* c, uint64_t* point_patch_iters) {
+  CTX_CHECK(c);
+  if (!c->a_staged) return fail(c, PLSVO_E_STATE, "align_work_points: no staged batch");
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<AlignStateDev> st((size_t)c->a_n);
+  HIP_TRY(c, hipMemcpyAsync(st.data(), c->a_d_state.p, (size_t)c->a_n * sizeof(AlignStateDev), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  uint64_t n = 0;
+  for (auto& s : st) n += s.patch_iters_pt;
+  if (point_patch_iters) *point_patch_iters = n;
+  return PLSVO_OK;
+}
+
 extern "C" int plsvo_align_chi2_ties(plsvo_ctx* c, uint64_t* iterations, uint64_t* ties) {
   CTX_CHECK(c);
   if (!c->a_staged) return fail(c, PLSVO_E_STATE, "align_chi2_ties: no staged batch");
@@ -718,7 +772,7 @@ extern "C" int plsvo_poseopt_stage(plsvo_ctx* c, int n, const plsvo_poseopt_in* 
       return fail(c, PLSVO_E_INVALID, "poseopt_stage: null feature array");
     PoseJobDev& J = jobs[(size_t)j];
     for (int k = 0; k < 7; ++k) J.T0[k] = a.T_f_w[k];
-    J.fx = a.fx; J.reproj_thresh = a.reproj_thresh; J.n_iter = a.n_iter; J.n_iter_ref = a.n_iter_ref;
+    J.fx = a.fx; J.reproj_thresh = a.reproj_thresh; J.n_iter = a.n_iter; J.n_iter_ref = a.n_iter_ref; J.ldlt_flavour = c->ldlt_flavour; J.reserved0 = 0;
     J.pt_off = (int)plev.size(); J.n_pts = a.n_pts; J.seg_off = (int)slev.size(); J.n_seg = a.n_seg;
     f.insert(f.end(), a.pt_f, a.pt_f + 3 * (size_t)a.n_pts);
     pos.insert(pos.end(), a.pt_pos, a.pt_pos + 3 * (size_t)a.n_pts);
@@ -743,7 +797,6 @@ extern "C" int plsvo_poseopt_stage(plsvo_ctx* c, int n, const plsvo_poseopt_in* 
   HIP_TRY(c, c->p_d_state.ensure((size_t)n * sizeof(PoseStateDev)));
   HIP_TRY(c, c->p_d_poses.ensure((size_t)n * 7 * sizeof(double)));
   if (c->p_trace_cap > 0) HIP_TRY(c, c->p_d_log.ensure((size_t)n * c->p_trace_cap * sizeof(plsvo_poseopt_iterlog)));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
   PoseBatchDev& b = c->p_b;
   uint8_t* const base = c->p_d_blob.as<uint8_t>();
   b.jobs = reinterpret_cast<const PoseJobDev*>(base + o_jobs); b.state = c->p_d_state.as<PoseStateDev>();
@@ -770,7 +823,7 @@ extern "C" int plsvo_poseopt_run(plsvo_ctx* c) {
   // chip (the Gauss-Newton loop of one frame is then ~2x shorter); PLSVO_POSEOPT_THREADS overrides (experiments only)
   const int cus = c->cu_count > 0 ? c->cu_count : 256;
   int threads = c->p_n <= 2 * cus ? 256 : 64;
-  if (const char* s = getenv("PLSVO_POSEOPT_THREADS")) { const int v = atoi(s); if (v == 64 || v == 256 || v == 512) threads = v; }
+  if (c->env_poseopt_threads) threads = c->env_poseopt_threads;
   EventPair ep{}; prof_begin(c, PLSVO_K_POSEOPT, &ep);
   HIP_TRY(c, launch_pose_opt(c->p_b, c->p_d_poses.as<double>(), threads, c->stream));
   prof_end(c, PLSVO_K_POSEOPT, &ep);

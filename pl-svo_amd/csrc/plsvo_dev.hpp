@@ -45,7 +45,7 @@ struct AlignJobDev {
   int patch_off, patch_cap;                 // into the batch patch-cache arrays (slots)
   int n_slots[PLSVO_MAX_LEVELS];            // patch slots of the static layout, per level (host: align_slot_layout)
   int long_mask;                            // bit l: some segment has more than 32 samples at level l (two-pass level)
-  int reserved0;
+  int ldlt_flavour;                         // 320 / 330: zero-pivot rule of Eigen's LDLT (plsvo_wave.hpp::wave_solve6_core)
 };
 
 struct AlignStateDev {
@@ -57,6 +57,7 @@ struct AlignStateDev {
   int log_count;
   int iters[PLSVO_MAX_LEVELS];
   unsigned long long patch_levels, patch_iters;  // work counters
+  unsigned long long patch_iters_pt;             // of patch_iters, those of point features (they also write 64 B of chi2 terms)
   int error;                   // device-side capacity/consistency error
   int chi2_ties;               // Gauss-Newton iterations whose accept / roll-back decision was taken on the exact float chi2 sums
   unsigned long long phase_ticks[8];  // only filled by -DPLSVO_TIMING builds (s_memtime ticks per phase)
@@ -103,6 +104,7 @@ struct PoseJobDev {
   double fx, reproj_thresh;
   int n_iter, n_iter_ref;
   int pt_off, n_pts, seg_off, n_seg;
+  int ldlt_flavour, reserved0;
 };
 
 struct PoseStateDev {

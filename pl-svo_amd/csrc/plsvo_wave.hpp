@@ -166,7 +166,7 @@ __device__ __forceinline__ double fast_sqrt(double x) {   // x >= 0, finite; sqr
 // is written for instruction count: the pivot is a DPP max over the lanes' own |diagonal| keys + one ballot (no per-row
 // readlanes, no compare chain), its reciprocal comes from fast_rcp while the two ds_bpermute round trips (row p, column p)
 // are in flight, and the update is one multiply + one fma per lane.
-__device__ __forceinline__ void wave_solve6_core(double m, double* x);
+__device__ __forceinline__ void wave_solve6_core(double m, double* x, int flavour = 320);
 
 __device__ __forceinline__ void wave_solve6(const double* tot, double* x) {
   const int lane = threadIdx.x & 63;
@@ -178,13 +178,13 @@ __device__ __forceinline__ void wave_solve6(const double* tot, double* x) {
 }
 
 // the same, with the 27 inputs held in registers: lane k (k < 27) passes tot[k] in `tot_lane`
-__device__ __forceinline__ void wave_solve6_reg(double tot_lane, double* x) {
+__device__ __forceinline__ void wave_solve6_reg(double tot_lane, double* x, int flavour = 320) {
   const int lane = threadIdx.x & 63;
   const int i = lane >> 3, j = lane & 7;
   const int src = (i < 6 && j < 6) ? sym6_index(i, j) : ((i < 6 && j == 6) ? 21 + i : 0);
   double m = __shfl(tot_lane, src, 64);
   if (!(i < 6 && j <= 6)) m = 0.0;
-  wave_solve6_core(m, x);
+  wave_solve6_core(m, x, flavour);
 }
 
 __device__ __forceinline__ double bpermute_f64(int byte_addr, double v) {
@@ -204,7 +204,11 @@ __device__ __forceinline__ double wave_max_to_lane63(double v) {
   return v;
 }
 
-__device__ __forceinline__ void wave_solve6_core(double m, double* x) {
+// flavour (wave-uniform): 320 = the rule above; 330 = Eigen 3.2.2 and later (what Ubuntu 16.04's libeigen3-dev 3.3-beta ships): no
+// cutoff -- the factorisation never stops early, only an exactly zero pivot leaves its column unscaled, and solve() drops
+// |d| <= 1/DBL_MAX only.  Identical arithmetic on every full-rank system; on rank-deficient ones 330 divides rounding residue by
+// rounding residue (tests/test_solve_model.py), which no two implementations reproduce alike.
+__device__ __forceinline__ void wave_solve6_core(double m, double* x, int flavour) {
   const int lane = threadIdx.x & 63;
   const int i = lane >> 3, j = lane & 7;
   const int addr_row = 4 * j, addr_col = 4 * 8 * i;      // byte addresses of lanes (p,j) / (i,p) once 32p / 4p is added
@@ -238,7 +242,7 @@ __device__ __forceinline__ void wave_solve6_core(double m, double* x) {
     // Eigen swaps positions `step` and pos[p]: the entry that sat at position `step` moves to where the pivot was
     const int pos_p = __builtin_amdgcn_readlane(pos, plane);
     if (pos == step) pos = pos_p;
-    if (step == 0) cutoff = fabs(2.220446049250313e-16 * kmax);
+    if (step == 0) cutoff = flavour == 330 ? 0.0 : fabs(2.220446049250313e-16 * kmax);
     // Eigen 3.2: stop at "biggest_in_corner < cutoff"; no scaling unless |pivot| > cutoff; D^+ drops |d| <= max|D| eps
     if (!(kmax < cutoff) && fabs(piv) > cutoff) {
       const double mp_j = bpermute_f64(addr_row + 32 * p, m);   // M[p][j]

@@ -173,7 +173,7 @@ __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseS
       const double tot = reduce_rows_finish<PO_T / 16>(s_red);
       if (lane < 30) s_tot[lane] = tot;
       double dT[6];
-      wave_solve6_reg(tot, dT);                                              // A.ldlt().solve(b) :170
+      wave_solve6_reg(tot, dT, job.ldlt_flavour);                            // A.ldlt().solve(b) :170
       const double new_chi2 = readlane_f64(tot, 27), npt = readlane_f64(tot, 28), nls = readlane_f64(tot, 29);
       if (lane == 0) {
         s_pose[27] += npt; s_pose[28] += nls;

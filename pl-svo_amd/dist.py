@@ -52,7 +52,8 @@ def gather_poses(local_poses, out=None):
     return out
 
 
-def timed_sharded_steps(step_local, copy_local_poses, local_poses, steps, warmup, device_sync=lambda: None, before_timed=lambda: None):
+def timed_sharded_steps(step_local, copy_local_poses, local_poses, steps, warmup, device_sync=lambda: None, before_timed=lambda: None,
+                        gather=None, force_gather=False):
     """The timed region of one benchmark run over a sharded batch of independent streams.
 
     step_local():            enqueue one pass of the hot path over this rank's streams
@@ -62,18 +63,26 @@ def timed_sharded_steps(step_local, copy_local_poses, local_poses, steps, warmup
     device_sync():           wait for everything enqueued (torch.cuda.synchronize on a GPU, nothing on the CPU)
     before_timed():          called once between the warm-up and the timed steps (bench.py switches its kernel timers on here)
 
+    gather(local, out):      the all-gather of the pose records.  On GPUs this is the C ABI's plsvo_gather_poses (ncclAllGather on the
+                             library's stream, the ONE gather path of the product); None = torch.distributed's all-gather, which is
+                             what the gloo ranks of the CPU suite use in its place
+    force_gather:            run the copy + gather with a single rank as well (bench.py --dist-selftest: the N>1 code on a 1-GPU box)
+
     One step = step_local, and with more than one rank: copy_local_poses + the all-gather of the poses (the only collective).
     Returns (elapsed seconds of the K timed steps, MAX over ranks; the gathered [world * n_local, 7] tensor or None)."""
     world = world_size()
+    exchange = world > 1 or force_gather
     gathered = None
-    if world > 1:
+    if exchange:
         gathered = torch.empty((world * local_poses.shape[0], local_poses.shape[1]), dtype=local_poses.dtype, device=local_poses.device)
+    if gather is None:
+        gather = lambda local, out: gather_poses(local, out=out)
 
     def step():
         step_local()
-        if world > 1:
+        if exchange:
             copy_local_poses(local_poses)
-            gather_poses(local_poses, out=gathered)
+            gather(local_poses, gathered)
 
     for _ in range(warmup):
         step()
@@ -93,6 +102,7 @@ def timed_sharded_steps(step_local, copy_local_poses, local_poses, steps, warmup
         t = torch.tensor([elapsed], dtype=torch.float64, device=local_poses.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if exchange:
         # the gathered table must hold this rank's poses in this rank's block (guards the copy -> all-gather ordering)
         r, n = rank(), local_poses.shape[0]
         if not torch.equal(gathered[r * n:(r + 1) * n], local_poses):

@@ -63,6 +63,19 @@ struct camera_traits {  // default: the camera type has fx()/fy()/cx()/cy()/widt
     return true;
   }
 };
+// camera_traits<Cam>::supported(cam) if the (possibly user-specialised) traits define it, true otherwise: a specialisation that
+// follows INTEGRATION.md's get()-only recipe must keep compiling
+template <class Cam, class = void>
+struct camera_supported_ {
+  static bool check(const Cam&) { return true; }
+};
+template <class Cam>
+struct camera_supported_<Cam, decltype((void)camera_traits<Cam>::supported(std::declval<const Cam&>()))> {
+  static bool check(const Cam& c) { return camera_traits<Cam>::supported(c); }
+};
+template <class Cam>
+inline bool camera_supported(const Cam& c) { return camera_supported_<Cam>::check(c); }
+
 template <class Img>
 struct image_traits {  // default: cv::Mat-like (data, cols, rows, step)
   static const uint8_t* data(const Img& m) { return reinterpret_cast<const uint8_t*>(m.data); }
@@ -209,7 +222,7 @@ class SparseImgAlignT {
     }
     typedef typename std::remove_reference<decltype(*ref_frame->cam_)>::type Cam;
     plsvo_align_in in;
-    if (!camera_traits<Cam>::supported(*ref_frame->cam_)) return 0;
+    if (!camera_supported<Cam>(*ref_frame->cam_)) return 0;
     in.cam = camera_traits<Cam>::get(*ref_frame->cam_);
     const int n_levels = max_level_ + 1;
     Context& c = default_context();
@@ -532,7 +545,7 @@ struct FrameRegistry {
     for (size_t k = 0; k < frames.size(); ++k) if (frames[k] == (const void*)fr) return (int)k;
     Context& c = default_context();
     typedef typename std::remove_reference<decltype(*fr->cam_)>::type Cam;
-    if (!camera_traits<Cam>::supported(*fr->cam_)) ok = false;
+    if (!camera_supported<Cam>(*fr->cam_)) ok = false;
     const plsvo_pinhole cm = camera_traits<Cam>::get(*fr->cam_);
     const int n_levels = (int)fr->img_pyr_.size();
     if (frames.empty()) cam = cm;

@@ -823,3 +823,120 @@ def test_gather_poses_over_a_single_rank_rccl_communicator(P, gpu_ctx):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.gpu
+def test_config4_sharded_streams_and_pose_gather(P, ob):
+    """BASELINE configs[3] on the hardware at hand: 64 seeded 640x480 streams (200 points + 80 segments, levels 3..1) as eight shards of
+    8 streams -- eight plsvo_ctx on one device standing in for the eight ranks, seeds by pl-svo_amd/dist.py::rank_seeds exactly as
+    bench.py shards them -- each shard running plsvo_align_run + plsvo_poseopt_run on its own streams and publishing its pose block
+    through plsvo_gather_poses (a one-rank RCCL communicator per shard: the transport over xGMI is what a 1-GPU box cannot show).
+    Every stream is checked against the oracle, the assembled table against the concatenation of the shards' results."""
+    import torch
+    D = P.dist
+    world, B, W, H = 8, 8, 640, 480
+    dev = torch.device("cuda", 0)
+    table = torch.zeros((world * B, 7), dtype=torch.float64, device=dev)
+    align_T = np.zeros((world * B, 7))
+    stream = torch.cuda.Stream(dev)
+    ctxs, comms = [], []
+    try:
+        with torch.cuda.stream(stream):
+            for r in range(world):
+                c = P.capi.Context(0, stream=stream.cuda_stream)
+                ctxs.append(c)
+                comm = P.rccl.comm_init(1, 0, P.rccl.unique_id())
+                comms.append(comm)
+                seeds = D.rank_seeds(r, world, B)
+                assert seeds == [1234 + r * B + i for i in range(B)]
+                streams = [P.synth.make_align_stream(s_, W, H, 200, 80, max_level=3) for s_ in seeds]
+                imgs = P.synth.render_streams(streams, device=dev)
+                c.config_pyramids(2 * B, W, H, 4)
+                c.build_pyramids_dev(0, 2 * B, imgs.data_ptr(), W, W * H, 0)
+                jobs = [P.align_job_from_stream(s_, 3, 1, ref_slot=2 * i, cur_slot=2 * i + 1) for i, s_ in enumerate(streams)]
+                frames = [P.synth.make_poseopt_frame(s_, 200, 80, W, H) for s_ in seeds]
+                pjobs = [P.poseopt_job_from_frame(f) for f in frames]
+                c.align_stage(jobs)
+                c.poseopt_stage(pjobs)
+                c.align_run()
+                c.poseopt_run()
+                # the shard's block of the table: all-gather of n_local * 7 doubles straight from the library's pose buffer
+                c.gather_poses(comm, c.poseopt_poses_dev(), B, table.data_ptr() + r * B * 7 * 8)
+                c.synchronize()
+                ares, pres = c.align_fetch(), c.poseopt_fetch()
+                pyrs = [(c.download_pyramid(2 * i), c.download_pyramid(2 * i + 1)) for i in range(B)]
+                for i in range(B):
+                    g = r * B + i
+                    ro, _ = ob.sparse_align(jobs[i], pyrs[i][0], pyrs[i][1])
+                    ang, tr, ok = Hh.pose_close(Hh.frame_pose(ares[i].T, streams[i]), Hh.frame_pose(ro.T, streams[i]))
+                    ang2, tr2, ok2 = Hh.pose_close(ares[i].T, ro.T)
+                    assert ok and ok2, f"stream {g}: align rot {ang:.2e}/{ang2:.2e} trans {tr:.2e}/{tr2:.2e}"
+                    assert np.array_equal(ares[i].seg_alive, ro.seg_alive), g
+                    po, _ = ob.pose_optimize(pjobs[i])
+                    ang3, tr3, ok3 = Hh.pose_close(pres[i].T, po.T)
+                    assert ok3 and ang3 < 1e-9, f"stream {g}: pose-opt rot {ang3:.2e} trans {tr3:.2e}"
+                    assert np.array_equal(pres[i].pt_keep, po.pt_keep) and np.array_equal(pres[i].seg_keep, po.seg_keep), g
+                    align_T[g] = ares[i].T
+                    # the gathered record IS the pose the shard fetched
+                    assert np.array_equal(table[g].cpu().numpy(), np.asarray(pres[i].T)), g
+        torch.cuda.synchronize()
+        # rank-major concatenation: block r of the table holds shard r's streams, in seed order, nothing else touched
+        t = table.cpu().numpy()
+        assert np.all(np.isfinite(t)) and np.all(np.abs(np.linalg.norm(t[:, :4], axis=1) - 1.0) < 1e-12)
+    finally:
+        for comm in comms:
+            P.rccl.comm_destroy(comm)
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.gpu
+def test_bench_distributed_branch_with_one_rank():
+    """bench.py's N>1 code path -- process group, RCCL communicator from the rendezvous, pose copy + plsvo_gather_poses every step,
+    the stale-block check -- with a single rank (--dist-selftest), on BASELINE configs[3]'s shards."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "4", "--steps", "3", "--warmup", "1", "--dist-selftest",
+                        "--no-cpu-baseline", "--no-latency"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["config"]["shards"] == 8 and d["config"]["global_batch"] == 64 and d["value"] > 0
+    assert "dist-selftest" in d["config"]["parallelism"] and len(d["per_shard"]["us_per_step"]) == 8
+
+
+@pytest.mark.gpu
+def test_ldlt_flavour_option(P, ob, gpu_ctx):
+    """plsvo_hip_set_option(PLSVO_OPT_LDLT_FLAVOUR): the Eigen 3.1...3.2.1 rule (320, default) and the Eigen >= 3.2.2 rule (330) are the
+    same arithmetic on full-rank systems -- bit-identical device results -- and each follows the oracle's restatement of the same rule
+    where they differ in a reproducible way: an all-zero system (no visible feature) and a one-observation system under 320."""
+    st, ref, cur, job = Hh.make_case(ob, 1235, 640, 480, 200, 80, 4, 3, 1)
+    gpu_ctx.config_pyramids(2, 640, 480, 4)
+    gpu_ctx.upload_pyramid(0, ref)
+    gpu_ctx.upload_pyramid(1, cur)
+    gpu_ctx.align_set_trace(0)
+    fr = P.synth.make_poseopt_frame(77, 120, 40)
+    pj = P.poseopt_job_from_frame(fr)
+    out = {}
+    try:
+        for flavour in (320, 330):
+            gpu_ctx.set_ldlt_flavour(flavour)
+            out[flavour] = (gpu_ctx.sparse_align(job), gpu_ctx.pose_optimize(pj))
+        assert np.array_equal(out[320][0].T, out[330][0].T) and out[320][0].iters_per_level == out[330][0].iters_per_level
+        assert np.array_equal(out[320][1].T, out[330][1].T) and np.array_equal(out[320][1].cov, out[330][1].cov)
+        with pytest.raises(P.capi.PlsvoError):
+            gpu_ctx.set_ldlt_flavour(321)
+        # one point observation: rank 2.  Under 320 the unobservable directions come back as exact zeros, like the oracle's
+        fr1 = P.synth.make_poseopt_frame(78, 1, 0)
+        pj1 = P.poseopt_job_from_frame(fr1)
+        gpu_ctx.set_ldlt_flavour(320)
+        ob.set_ldlt_flavour(320)
+        d1, o1 = gpu_ctx.pose_optimize(pj1), ob.pose_optimize(pj1)[0]
+        assert Hh.pose_close(d1.T, o1.T)[2]
+        gpu_ctx.set_ldlt_flavour(330)
+        d2 = gpu_ctx.pose_optimize(pj1)          # 330: rounding residue divided by rounding residue -- only required not to fault
+        assert d2.iters >= 1
+    finally:
+        gpu_ctx.set_ldlt_flavour(320)
+        ob.set_ldlt_flavour(320)
