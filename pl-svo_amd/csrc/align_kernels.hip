@@ -42,14 +42,16 @@
 namespace plsvo_hip {
 
 // ------------------------------------------------------------------------------------------------
-// image gather: bytes [off, off+7) of a u8 image as floats, via aligned dword reads + v_alignbyte.
-// The image allocation is padded so the over-read stays inside it.
+// image gather from the TILED mirror of a pyramid level (plsvo_dev.hpp: 16 x 8 pixel tiles of 128 B): pixels [x, x+7) of row y as
+// floats, via aligned dword reads + v_alignbyte.  An aligned dword never straddles a tile row (16 B), so the over-read stays
+// inside the level.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_row7(const uint8_t* img, int off, float* o7) {
-  const int a = off & ~3, sh = off & 3;
-  const uint32_t d0 = *reinterpret_cast<const uint32_t*>(img + a);
-  const uint32_t d1 = *reinterpret_cast<const uint32_t*>(img + a + 4);
-  const uint32_t d2 = *reinterpret_cast<const uint32_t*>(img + a + 8);
+__device__ __forceinline__ void load_row7(const uint8_t* img, int tiles_x, int x, int y, float* o7) {
+  const int a = x & ~3, sh = x & 3;
+  const uint8_t* row = img + tiled_row_offset(tiles_x, y);
+  const uint32_t d0 = *reinterpret_cast<const uint32_t*>(row + tiled_col_offset(a));
+  const uint32_t d1 = *reinterpret_cast<const uint32_t*>(row + tiled_col_offset(a + 4));
+  const uint32_t d2 = *reinterpret_cast<const uint32_t*>(row + tiled_col_offset(a + 8));
   const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);  // bytes off..off+3
   const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);  // bytes off+4..off+7
   o7[0] = (float)(w0 & 0xffu); o7[1] = (float)((w0 >> 8) & 0xffu);
@@ -286,9 +288,10 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     // (level geometry is recomputed instead of indexing the kernel-argument arrays with a run-time level,
     //  which would force the whole argument struct into scratch memory)
     const int W = job.width >> level, Hh = job.height >> level;
-    const unsigned int lvl_off = pyr_level_offset(job.width, job.height, level);
-    const uint8_t* ref_img = b.pyr.base + (size_t)job.ref_slot * b.pyr.slot_bytes + lvl_off;
-    const uint8_t* cur_img = b.pyr.base + (size_t)job.cur_slot * b.pyr.slot_bytes + lvl_off;
+    const unsigned int lvl_off = pyr_tiled_level_offset(job.width, job.height, level);   // the alignment reads the tiled mirror
+    const uint8_t* ref_img = b.pyr.tbase + (size_t)job.ref_slot * b.pyr.tslot_bytes + lvl_off;
+    const uint8_t* cur_img = b.pyr.tbase + (size_t)job.cur_slot * b.pyr.tslot_bytes + lvl_off;
+    const int tiles_x = (W + 15) >> 4;
     int n_slots = 0; bool long_lines = false;
 #pragma unroll
     for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) if (l == level) { n_slots = job.n_slots[l]; long_lines = ((job.long_mask >> l) & 1) != 0; }
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         const int c0 = pw.ui - 2 - 1;
         float I[4][7];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) load_row7(ref_img, (r0 + rr) * W + c0, I[rr]);
+        for (int rr = 0; rr < 4; ++rr) load_row7(ref_img, tiles_x, c0, r0 + rr, I[rr]);
         float4 vr, vx, vy;
         float* pr = reinterpret_cast<float*>(&vr); float* pxp = reinterpret_cast<float*>(&vx); float* pyp = reinterpret_cast<float*>(&vy);
 #pragma unroll
@@ -424,7 +427,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         // depth 2: round r+1 is also projected and its image window requested before r's arithmetic (measured: 11 spilled
         //   VGPRs, no gain over depth 1); depth 0: no pipelining.
         struct SlotA { int2 meta; bool cand; double X, Y, Z; };
-        struct SlotB { bool live; float u, v; int off; uint32_t r0a, r0b, r1a, r1b, r2a, r2b; };
+        struct SlotB { bool live; float u, v; int sh; uint32_t r0a, r0b, r1a, r1b, r2a, r2b; };
         struct SlotC { float4 vr0, vx0, vy0, vr1, vx1, vy1; };
         auto stage_a = [&](int pb_) -> SlotA {
           SlotA f;
@@ -447,14 +450,19 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           g.u = half ? w_other : w_mine; g.v = half ? w_mine : w_other;
           // Patch::isInFrame(halfsize=2) on floorf(u), floorf(v); NaN -> out of frame
           g.live = sa.cand && (g.u >= 2.0f) && (g.v >= 2.0f) && (g.u < colmax) && (g.v < rowmax);
-          g.off = 0; g.r0a = g.r0b = g.r1a = g.r1b = g.r2a = g.r2b = 0u;
+          g.sh = 0; g.r0a = g.r0b = g.r1a = g.r1b = g.r2a = g.r2b = 0u;
           if (g.live) {
+            // rows y0 .. y0+2 of the window, columns x0 .. x0+4: two aligned dwords per row from the tiled level
             const int ui = (int)floorf(g.u), vi = (int)floorf(g.v);
-            g.off = (vi - 2 + 2 * half) * W + (ui - 2);
-            const int a0 = g.off & ~3, a1 = (g.off + W) & ~3, a2 = (g.off + 2 * W) & ~3;
-            g.r0a = *reinterpret_cast<const uint32_t*>(cur_img + a0); g.r0b = *reinterpret_cast<const uint32_t*>(cur_img + a0 + 4);
-            g.r1a = *reinterpret_cast<const uint32_t*>(cur_img + a1); g.r1b = *reinterpret_cast<const uint32_t*>(cur_img + a1 + 4);
-            g.r2a = *reinterpret_cast<const uint32_t*>(cur_img + a2); g.r2b = *reinterpret_cast<const uint32_t*>(cur_img + a2 + 4);
+            const int x0 = ui - 2, y0 = vi - 2 + 2 * half;
+            g.sh = x0 & 3;
+            const int ca = tiled_col_offset(x0 & ~3), cb = tiled_col_offset((x0 & ~3) + 4);
+            const uint8_t* q0 = cur_img + tiled_row_offset(tiles_x, y0);
+            const uint8_t* q1 = cur_img + tiled_row_offset(tiles_x, y0 + 1);
+            const uint8_t* q2 = cur_img + tiled_row_offset(tiles_x, y0 + 2);
+            g.r0a = *reinterpret_cast<const uint32_t*>(q0 + ca); g.r0b = *reinterpret_cast<const uint32_t*>(q0 + cb);
+            g.r1a = *reinterpret_cast<const uint32_t*>(q1 + ca); g.r1b = *reinterpret_cast<const uint32_t*>(q1 + cb);
+            g.r2a = *reinterpret_cast<const uint32_t*>(q2 + ca); g.r2b = *reinterpret_cast<const uint32_t*>(q2 + cb);
           }
           return g;
         };
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           float4 chi_t0 = make_float4(0.f, 0.f, 0.f, 0.f), chi_t1 = chi_t0;   // a patch outside the current image contributes nothing (:432-433): +0
           if (live) {
             const PatchW pw = patch_weights(u, v);
-            const int off = sb.off;
+            const int sh = sb.sh;
             const uint32_t r0a = sb.r0a, r0b = sb.r0b, r1a = sb.r1a, r1b = sb.r1b, r2a = sb.r2a, r2b = sb.r2b;
             auto unpack5 = [](uint32_t lo, uint32_t hi, int sh, float* o) {
               const uint32_t w0 = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh);
@@ -521,9 +529,9 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
               o[4] = (float)((hi >> (8 * sh)) & 0xffu);
             };
             float r0[5], r1[5], r2[5];
-            unpack5(r0a, r0b, off & 3, r0);
-            unpack5(r1a, r1b, (off + W) & 3, r1);
-            unpack5(r2a, r2b, (off + 2 * W) & 3, r2);
+            unpack5(r0a, r0b, sh, r0);
+            unpack5(r1a, r1b, sh, r1);
+            unpack5(r2a, r2b, sh, r2);
             const bool is_point = !is_line;
             // WEIGHTED is decided per wave: the slot table lists points first, then line samples, so most rounds are
             // homogeneous and the line-only ones skip the robust weight (11 instructions per pixel) and the chi2 term.

@@ -33,6 +33,7 @@ hipError_t launch_halfsample(const uint8_t* src, size_t src_pitch, int in_w, int
                              size_t dst_pitch, int n_slots, int rounding, hipStream_t stream);
 hipError_t launch_copy_level0(const uint8_t* src, size_t src_pitch, int w, int h, int stride, uint8_t* dst, size_t dst_pitch,
                               int n_slots, hipStream_t stream);
+hipError_t launch_tile_level(const uint8_t* src, size_t src_pitch, int w, int h, uint8_t* dst, size_t dst_pitch, int n_slots, hipStream_t stream);
 }  // namespace plsvo_hip
 
 using namespace plsvo_hip;
@@ -84,7 +85,8 @@ struct plsvo_ctx {
   bool env_align_per_level = false, env_align_no_lpt = false, env_host_timing = false;
   int ldlt_flavour = 320;   // plsvo_hip_set_option(PLSVO_OPT_LDLT_FLAVOUR)
 
-  // pyramids
+  // pyramids (row-major slab: half-sampler, matcher, depth filter, download) and their tiled mirror (alignment kernel)
+  DevBuf pyr_tiled;
   DevBuf pyr_slab;
   PyrDesc pyr{};
   DevBuf pyr_upload;  // staging for level-0 uploads
@@ -219,7 +221,7 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-  DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_upload, &c->a_d_blob, &c->a_d_state, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv, &c->a_d_cref, &c->a_d_cdx,
+  DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_tiled, &c->pyr_upload, &c->a_d_blob, &c->a_d_state, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv, &c->a_d_cref, &c->a_d_cdx,
                      &c->a_d_cdy, &c->a_d_chi, &c->a_d_log, &c->a_d_poses, &c->p_d_blob, &c->p_d_state, &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64,
                      &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out };
   for (DevBuf* b : bufs) b->release();
@@ -267,10 +269,14 @@ extern "C" int plsvo_hip_config_pyramids(plsvo_ctx* c, int n_slots, int width, i
     off = (size_t)pyr_level_offset(width, height, l + 1);           // >= 64 bytes of slack after every level (gather over-read)
   }
   d.slot_bytes = off; d.n_slots = n_slots; d.n_levels = n_levels;
+  d.tslot_bytes = pyr_tiled_level_offset(width, height, n_levels);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, c->pyr_slab.ensure((size_t)n_slots * off + 256));
   HIP_TRY(c, hipMemsetAsync(c->pyr_slab.p, 0, (size_t)n_slots * off + 256, c->stream));
+  HIP_TRY(c, c->pyr_tiled.ensure((size_t)n_slots * d.tslot_bytes + 256));
+  HIP_TRY(c, hipMemsetAsync(c->pyr_tiled.p, 0, (size_t)n_slots * d.tslot_bytes + 256, c->stream));
   d.base = c->pyr_slab.as<uint8_t>();
+  d.tbase = c->pyr_tiled.as<uint8_t>();
   c->pyr = d;
   c->a_staged = false;
   return PLSVO_OK;
@@ -279,6 +285,16 @@ extern "C" int plsvo_hip_config_pyramids(plsvo_ctx* c, int n_slots, int width, i
 static int check_slot(plsvo_ctx* c, int slot) {
   if (!c->pyr.base) return fail(c, PLSVO_E_STATE, "pyramids not configured");
   if (slot < 0 || slot >= c->pyr.n_slots) return fail(c, PLSVO_E_CAPACITY, "pyramid slot out of range");
+  return PLSVO_OK;
+}
+
+// refresh the tiled mirror of slots [first_slot, first_slot + n), levels [0, n_levels): enqueued after whatever wrote the slab
+static int retile(plsvo_ctx* c, int first_slot, int n, int n_levels) {
+  const uint8_t* src = c->pyr_slab.as<uint8_t>() + (size_t)first_slot * c->pyr.slot_bytes;
+  uint8_t* dst = c->pyr_tiled.as<uint8_t>() + (size_t)first_slot * c->pyr.tslot_bytes;
+  for (int l = 0; l < n_levels; ++l)
+    HIP_TRY(c, launch_tile_level(src + c->pyr.off[l], c->pyr.slot_bytes, c->pyr.w[l], c->pyr.h[l],
+                                 dst + pyr_tiled_level_offset(c->pyr.w[0], c->pyr.h[0], l), c->pyr.tslot_bytes, n, c->stream));
   return PLSVO_OK;
 }
 
@@ -294,6 +310,7 @@ extern "C" int plsvo_hip_upload_pyramid(plsvo_ctx* c, int slot, int n_levels, co
     HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)width[l], level_ptr[l], (size_t)stride_bytes[l], (size_t)width[l], (size_t)height[l],
                                 hipMemcpyHostToDevice, c->stream));
   }
+  rc = retile(c, slot, 1, n_levels); if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // the host buffers may be released by the caller
   return PLSVO_OK;
 }
@@ -306,7 +323,7 @@ static int build_levels(plsvo_ctx* c, int first_slot, int n, int rounding) {
                                  base + c->pyr.off[l], c->pyr.slot_bytes, n, rounding, c->stream));
     prof_end(c, PLSVO_K_HALFSAMPLE, &ep);
   }
-  return PLSVO_OK;
+  return retile(c, first_slot, n, c->pyr.n_levels);
 }
 
 extern "C" int plsvo_hip_build_pyramid(plsvo_ctx* c, int slot, const uint8_t* level0, int stride_bytes, int rounding) {

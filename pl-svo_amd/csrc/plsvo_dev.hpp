@@ -27,9 +27,32 @@ inline unsigned int pyr_level_offset(int width, int height, int level) {
   return (unsigned int)off;
 }
 
+// TILED MIRROR of the pyramids, read by the alignment kernel (written by tile_level_kernel whenever a slot changes).  A level is
+// cut into tiles of 16 x 8 pixels = 128 B = one L2 line, tiles row-major, pixel (x, y) at
+//     ((y >> 3) * tiles_x + (x >> 4)) * 128 + (y & 7) * 16 + (x & 15),        tiles_x = ceil(w / 16)
+// A 5x5 window of a row-major level touches five lines (one per image row: 640 B fetched for 25 B used); in tiles it touches
+// (1 + 4/16)(1 + 4/8) = 1.9 lines on average.  The launch runs within a few per cent of the achievable HBM rate, so lines are time.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline unsigned int pyr_tiled_level_offset(int width, int height, int level) {
+  unsigned long long off = 0;
+  for (int l = 0; l < level; ++l) {
+    const unsigned long long tiles = (unsigned long long)(((width >> l) + 15) >> 4) * (unsigned long long)(((height >> l) + 7) >> 3);
+    off += (tiles * 128 + 255) & ~255ull;
+  }
+  return (unsigned int)off;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ int tiled_row_offset(int tiles_x, int y) { return (((y >> 3) * tiles_x) << 7) + ((y & 7) << 4); }
+__device__ __forceinline__ int tiled_col_offset(int x) { return ((x >> 4) << 7) + (x & 15); }
+#endif
+
 struct PyrDesc {
   const uint8_t* base;
   unsigned long long slot_bytes;
+  const uint8_t* tbase;               // tiled mirror: slot s at tbase + s * tslot_bytes, level l at + pyr_tiled_level_offset(w, h, l)
+  unsigned long long tslot_bytes;
   int n_slots, n_levels;
   int w[PLSVO_MAX_LEVELS], h[PLSVO_MAX_LEVELS];
   unsigned int off[PLSVO_MAX_LEVELS];

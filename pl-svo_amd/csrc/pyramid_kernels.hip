@@ -70,6 +70,35 @@ __global__ __launch_bounds__(256) void copy_level0_kernel(const uint8_t* src, si
   else for (int k = 0; k < 16 && 16 * q + k < w; ++k) d[k] = s[k];
 }
 
+// row-major level -> 16 x 8 tiles (plsvo_dev.hpp): one thread per 16-byte tile row; pixels beyond the image edge are written as 0
+__global__ __launch_bounds__(256) void tile_level_kernel(const uint8_t* src, size_t src_pitch, int w, int h, uint8_t* dst, size_t dst_pitch) {
+  const int tiles_x = (w + 15) >> 4, tiles_y = (h + 7) >> 3;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // tile-row index: (tile, row inside the tile)
+  if (idx >= tiles_x * tiles_y * 8) return;
+  const int tile = idx >> 3, r = idx & 7;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int y = ty * 8 + r, x0 = tx * 16;
+  const uint8_t* s = src + (size_t)blockIdx.y * src_pitch + (size_t)y * w + x0;
+  uint8_t* d = dst + (size_t)blockIdx.y * dst_pitch + ((size_t)tile << 7) + (r << 4);
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (y < h) {
+    if (x0 + 16 <= w && (reinterpret_cast<uintptr_t>(s) & 15) == 0) v = *reinterpret_cast<const uint4*>(s);
+    else {
+      uint32_t q[4] = { 0u, 0u, 0u, 0u };
+      for (int k = 0; k < 16 && x0 + k < w; ++k) q[k >> 2] |= (uint32_t)s[k] << (8 * (k & 3));
+      v = make_uint4(q[0], q[1], q[2], q[3]);
+    }
+  }
+  *reinterpret_cast<uint4*>(d) = v;
+}
+
+hipError_t launch_tile_level(const uint8_t* src, size_t src_pitch, int w, int h, uint8_t* dst, size_t dst_pitch, int n_slots, hipStream_t stream) {
+  const int work = ((w + 15) >> 4) * ((h + 7) >> 3) * 8;
+  if (work <= 0 || n_slots <= 0) return hipSuccess;
+  hipLaunchKernelGGL(tile_level_kernel, dim3((work + 255) / 256, n_slots), dim3(256), 0, stream, src, src_pitch, w, h, dst, dst_pitch);
+  return hipGetLastError();
+}
+
 hipError_t launch_halfsample(const uint8_t* src, size_t src_pitch, int in_w, int in_h, int in_stride, uint8_t* dst,
                              size_t dst_pitch, int n_slots, int rounding, hipStream_t stream) {
   const int ow = in_w >> 1, oh = in_h >> 1;
