@@ -98,6 +98,9 @@ int plsvo_hip_build_pyramid(plsvo_ctx* ctx, int slot, const uint8_t* level0, int
  * first_slot; image i is at d_level0 + i*image_pitch_bytes. */
 int plsvo_hip_build_pyramids_dev(plsvo_ctx* ctx, int first_slot, int n, const void* d_level0,
                                  int stride_bytes, size_t image_pitch_bytes, int rounding);
+/* Device-to-device copy of n whole pyramid slots (src_first.. -> dst_first.., ranges must not overlap), enqueued on the ctx stream:
+ * "the current frame becomes the reference frame" (src/frame_handler_mono.cpp:272-274) for a resident batch without crossing PCIe. */
+int plsvo_hip_copy_slots(plsvo_ctx* ctx, int dst_first, int src_first, int n);
 /* Read one level of a slot back to the host (tight rows); for tests. */
 int plsvo_hip_download_level(plsvo_ctx* ctx, int slot, int level, uint8_t* out);
 

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("PLSVO_HIP_LIB", os.path.join(_HERE, "libplsvo_hip.so"
 SYMBOLS = [
     "plsvo_hip_create", "plsvo_hip_create_on_stream", "plsvo_hip_set_option", "plsvo_align_slot_layout", "plsvo_hip_destroy", "plsvo_hip_last_error", "plsvo_hip_stream", "plsvo_hip_synchronize",
     "plsvo_hip_config_pyramids", "plsvo_hip_upload_pyramid", "plsvo_hip_build_pyramid", "plsvo_hip_build_pyramids_dev",
-    "plsvo_hip_download_level",
+    "plsvo_hip_download_level", "plsvo_hip_copy_slots",
     "plsvo_sparse_align", "plsvo_sparse_align_batch", "plsvo_align_stage", "plsvo_align_run", "plsvo_align_fetch",
     "plsvo_align_set_trace", "plsvo_align_fetch_trace", "plsvo_align_poses_dev", "plsvo_align_copy_poses", "plsvo_align_work", "plsvo_align_work_points", "plsvo_align_chi2_ties",
     "plsvo_pose_optimize", "plsvo_pose_optimize_batch", "plsvo_poseopt_stage", "plsvo_poseopt_run", "plsvo_poseopt_fetch",
@@ -62,6 +62,7 @@ def lib():
         "plsvo_hip_build_pyramid": (C.c_int, [ctxp, C.c_int, abi.c_u8_p, C.c_int, C.c_int]),
         "plsvo_hip_build_pyramids_dev": (C.c_int, [ctxp, C.c_int, C.c_int, vp, C.c_int, C.c_size_t, C.c_int]),
         "plsvo_hip_download_level": (C.c_int, [ctxp, C.c_int, C.c_int, abi.c_u8_p]),
+        "plsvo_hip_copy_slots": (C.c_int, [ctxp, C.c_int, C.c_int, C.c_int]),
         "plsvo_sparse_align": (C.c_int, [ctxp, C.POINTER(abi.AlignIn), C.POINTER(abi.AlignOut)]),
         "plsvo_sparse_align_batch": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.AlignIn), C.POINTER(abi.AlignOut)]),
         "plsvo_align_stage": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.AlignIn)]),
@@ -198,6 +199,9 @@ class Context:
         out = np.empty((h, w), dtype=np.uint8)
         self._chk(self.L.plsvo_hip_download_level(self.h, slot, level, out.ctypes.data_as(abi.c_u8_p)))
         return out
+
+    def copy_slots(self, dst_first, src_first, n):
+        self._chk(self.L.plsvo_hip_copy_slots(self.h, int(dst_first), int(src_first), int(n)))
 
     def download_pyramid(self, slot):
         return [self.download_level(slot, l) for l in range(self.n_levels)]

@@ -353,6 +353,24 @@ extern "C" int plsvo_hip_build_pyramids_dev(plsvo_ctx* c, int first_slot, int n,
   return build_levels(c, first_slot, n, rounding);
 }
 
+// "cur becomes ref" for a block of streams without crossing PCIe: device-to-device copy of whole slots, row-major slab and tiled
+// mirror alike (src/frame_handler_mono.cpp:272-274: the frame aligned against in the next call is the one just tracked)
+extern "C" int plsvo_hip_copy_slots(plsvo_ctx* c, int dst_first, int src_first, int n) {
+  CTX_CHECK(c);
+  if (n <= 0) return fail(c, PLSVO_E_INVALID, "copy_slots: bad arguments");
+  int rc = check_slot(c, dst_first); if (rc) return rc;
+  rc = check_slot(c, dst_first + n - 1); if (rc) return rc;
+  rc = check_slot(c, src_first); if (rc) return rc;
+  rc = check_slot(c, src_first + n - 1); if (rc) return rc;
+  if (dst_first < src_first + n && src_first < dst_first + n) return fail(c, PLSVO_E_INVALID, "copy_slots: the two slot ranges overlap");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(c->pyr_slab.as<uint8_t>() + (size_t)dst_first * c->pyr.slot_bytes, c->pyr_slab.as<uint8_t>() + (size_t)src_first * c->pyr.slot_bytes,
+                            (size_t)n * c->pyr.slot_bytes, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->pyr_tiled.as<uint8_t>() + (size_t)dst_first * c->pyr.tslot_bytes, c->pyr_tiled.as<uint8_t>() + (size_t)src_first * c->pyr.tslot_bytes,
+                            (size_t)n * c->pyr.tslot_bytes, hipMemcpyDeviceToDevice, c->stream));
+  return PLSVO_OK;
+}
+
 extern "C" int plsvo_hip_download_level(plsvo_ctx* c, int slot, int level, uint8_t* out) {
   CTX_CHECK(c);
   int rc = check_slot(c, slot); if (rc) return rc;

@@ -57,9 +57,45 @@ __device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t b, uint32_t c) { r
 
 // Matcher::findEpipolarMatchDirect (seg == 0) / findEpipolarMatchDirectSegmentEndpoint (seg == 1).
 // Kept out of line: a line seed calls it twice and a point seed once from the same kernel.
-__device__ __noinline__ bool epipolar_search(const SeedsBatchDev& b, uint32_t* my, int rf, int cf, double rpx0, double rpx1, const double* f_ref,
-                                             int level, int type, double g0, double g1, double d_estimate, double d_min, double d_max, int seg,
-                                             double* depth, double* px_cur) {
+// Everything travels by value -- the handful of batch fields it reads (EpiCtx), the bearing, the result (EpiOut): handing the
+// kernel's 500-byte argument struct and three stack arrays over by address cost the kernel a 576-byte scratch frame per lane.
+struct EpiCtx {
+  const uint8_t* pyr_base; unsigned long long slot_bytes; const double* frame_T; const int* frame_slot;
+  double fx, fy, cx, cy, edgelet_max_angle;
+  int width, height, cam_width, cam_height, n_pyr_levels, align_max_iter, max_epi_search_steps, edgelet_filtering;
+};
+struct EpiOut { int ok; double depth, px0, px1; };
+__device__ __forceinline__ EpiCtx epi_ctx(const SeedsBatchDev& s) {
+  EpiCtx e;
+  e.pyr_base = s.pyr_base; e.slot_bytes = s.slot_bytes; e.frame_T = s.frame_T; e.frame_slot = s.frame_slot;
+  e.fx = s.fx; e.fy = s.fy; e.cx = s.cx; e.cy = s.cy; e.edgelet_max_angle = s.edgelet_max_angle;
+  e.width = s.width; e.height = s.height; e.cam_width = s.cam_width; e.cam_height = s.cam_height; e.n_pyr_levels = s.n_pyr_levels;
+  e.align_max_iter = s.align_max_iter; e.max_epi_search_steps = s.max_epi_search_steps; e.edgelet_filtering = s.edgelet_filtering;
+  return e;
+}
+__device__ __forceinline__ bool epipolar_search_body(const EpiCtx& b, uint32_t* my, int rf, int cf, double rpx0, double rpx1, const double* f_ref,
+                                                     int level, int type, double g0, double g1, double d_estimate, double d_min, double d_max, int seg,
+                                                     double* depth, double* px_cur);
+// (an aggregate passed by value travels through the stack as well: the context sits in LDS, written once per workgroup, and the
+//  out-of-line function receives its address)
+typedef const __attribute__((address_space(3))) EpiCtx* EpiCtxLds;
+__device__ __noinline__ EpiOut epipolar_search(EpiCtxLds c, uint32_t* my, int rf, int cf, double rpx0, double rpx1, double f0, double f1, double f2,
+                                               int level, int type, double g0, double g1, double d_estimate, double d_min, double d_max, int seg) {
+  EpiCtx b;
+  b.pyr_base = c->pyr_base; b.slot_bytes = c->slot_bytes; b.frame_T = c->frame_T; b.frame_slot = c->frame_slot;
+  b.fx = c->fx; b.fy = c->fy; b.cx = c->cx; b.cy = c->cy; b.edgelet_max_angle = c->edgelet_max_angle;
+  b.width = c->width; b.height = c->height; b.cam_width = c->cam_width; b.cam_height = c->cam_height; b.n_pyr_levels = c->n_pyr_levels;
+  b.align_max_iter = c->align_max_iter; b.max_epi_search_steps = c->max_epi_search_steps; b.edgelet_filtering = c->edgelet_filtering;
+  const double f_ref[3] = { f0, f1, f2 };
+  double depth = 0.0, px_cur[2] = { 0.0, 0.0 };
+  EpiOut o;
+  o.ok = epipolar_search_body(b, my, rf, cf, rpx0, rpx1, f_ref, level, type, g0, g1, d_estimate, d_min, d_max, seg, &depth, px_cur) ? 1 : 0;
+  o.depth = depth; o.px0 = px_cur[0]; o.px1 = px_cur[1];
+  return o;
+}
+__device__ __forceinline__ bool epipolar_search_body(const EpiCtx& b, uint32_t* my, int rf, int cf, double rpx0, double rpx1, const double* f_ref,
+                                                     int level, int type, double g0, double g1, double d_estimate, double d_min, double d_max, int seg,
+                                                     double* depth, double* px_cur) {
   const CamDev cam{b.fx, b.fy, b.cx, b.cy, b.cam_width, b.cam_height};
   px_cur[0] = 0.0; px_cur[1] = 0.0;
   const SE3d T_ref = se3_load(b.frame_T + 7 * rf), T_cur = se3_load(b.frame_T + 7 * cf);
@@ -203,7 +239,11 @@ __device__ __forceinline__ bool px_in_image(const CamDev& cam, const double* px)
 
 __global__ void __launch_bounds__(MT) update_seeds_kernel(const SeedsBatchDev b) {
   __shared__ uint32_t s_patch[PB_ROWS * PB_WORDS * MT];
+  __shared__ EpiCtx s_epi;
   const int lane = threadIdx.x;
+  if (lane == 0) s_epi = epi_ctx(b);
+  __syncthreads();
+  const EpiCtxLds epi = (EpiCtxLds)&s_epi;
   const int gi = blockIdx.x * MT + lane;
   if (gi >= b.n_pt + b.n_seg) return;
   uint32_t* my = s_patch + lane;
@@ -231,8 +271,10 @@ __global__ void __launch_bounds__(MT) update_seeds_kernel(const SeedsBatchDev b)
       const float t_ = mu - sqrtf(sigma2);
       const float z_inv_max = t_ > 0.00000001f ? t_ : 0.00000001f;
       const double g0 = b.pt_grad ? b.pt_grad[2 * i] : 0.0, g1 = b.pt_grad ? b.pt_grad[2 * i + 1] : 0.0;
-      if (!epipolar_search(b, my, rf, cf, b.pt_px[2 * i], b.pt_px[2 * i + 1], f, b.pt_level[i], b.pt_type[i], g0, g1, 1.0 / mu,
-                           1.0 / z_inv_min, 1.0 / z_inv_max, 0, &z, px_cur)) {
+      const EpiOut eo = epipolar_search(epi, my, rf, cf, b.pt_px[2 * i], b.pt_px[2 * i + 1], f[0], f[1], f[2], b.pt_level[i], b.pt_type[i], g0, g1,
+                                        1.0 / mu, 1.0 / z_inv_min, 1.0 / z_inv_max, 0);
+      z = eo.depth; px_cur[0] = eo.px0; px_cur[1] = eo.px1;
+      if (!eo.ok) {
         bb += 1.0f;
         status = PLSVO_SEED_NO_MATCH;
       } else {
@@ -290,8 +332,12 @@ __global__ void __launch_bounds__(MT) update_seeds_kernel(const SeedsBatchDev b)
       const float z_inv_max_e = te_ > 0.00000001f ? te_ : 0.00000001f;
       const double px0 = b.seg_px[2 * i], px1 = b.seg_px[2 * i + 1];
       const int level = b.seg_level[i];
-      if (!epipolar_search(b, my, rf, cf, px0, px1, fc, level, PLSVO_FTR_CORNER, 0.0, 0.0, 1.0 / mu_s, 1.0 / z_inv_min_s, 1.0 / z_inv_max_s, 1, &z_s, px_cur) ||
-          !epipolar_search(b, my, rf, cf, px0, px1, fc, level, PLSVO_FTR_CORNER, 0.0, 0.0, 1.0 / mu_e, 1.0 / z_inv_min_e, 1.0 / z_inv_max_e, 1, &z_e, px_cur)) {
+      // (the second search runs only when the first one succeeds, like the reference's `||`)
+      const EpiOut es = epipolar_search(epi, my, rf, cf, px0, px1, fc[0], fc[1], fc[2], level, PLSVO_FTR_CORNER, 0.0, 0.0, 1.0 / mu_s, 1.0 / z_inv_min_s, 1.0 / z_inv_max_s, 1);
+      z_s = es.depth;
+      EpiOut ee; ee.ok = 0; ee.depth = 0.0; ee.px0 = 0.0; ee.px1 = 0.0;
+      if (es.ok) { ee = epipolar_search(epi, my, rf, cf, px0, px1, fc[0], fc[1], fc[2], level, PLSVO_FTR_CORNER, 0.0, 0.0, 1.0 / mu_e, 1.0 / z_inv_min_e, 1.0 / z_inv_max_e, 1); z_e = ee.depth; }
+      if (!es.ok || !ee.ok) {
         bb += 1.0f;
         status = PLSVO_SEED_NO_MATCH;
       } else {
