@@ -201,9 +201,13 @@ def host_fed_leg(P, torch, dev, stream, streams, cfg, n_streams=1024, steps=12):
             ref0 = imgs[:, 0].contiguous()
             ctx.build_pyramids_dev(c0, ref0.shape[0], ref0.data_ptr(), W, W * H, 0)
             ctx.synchronize()
-            host.append(imgs[:, 1].contiguous().cpu())
+            host.append(imgs.cpu())
             del imgs, ref0
-        host_cur = torch.cat(host).pin_memory()                    # [n, H, W]: the frames the "camera" delivers
+        both = torch.cat(host)
+        # the frames the "camera" delivers: each stream's two images alternately (B, A, B, A, ..), so that every step aligns a
+        # genuinely different image pair (forward motion on even steps, the reverse motion on odd ones)
+        host_img = [both[:, 1].contiguous().pin_memory(), both[:, 0].contiguous().pin_memory()]
+        del both
         jobs = [P.align_job_from_stream(s_, cfg["maxl"], cfg["minl"], ref_slot=i, cur_slot=n + i) for i, s_ in enumerate(sub)]
         frames = [synth.make_poseopt_frame(1234 + i, cfg["pose_pts"], cfg["pose_seg"], W, H) for i in range(n)]
         pjobs = [P.poseopt_job_from_frame(f) for f in frames]
@@ -214,10 +218,10 @@ def host_fed_leg(P, torch, dev, stream, streams, cfg, n_streams=1024, steps=12):
         uploaded = [torch.cuda.Event() for _ in range(2)]
         consumed = [torch.cuda.Event() for _ in range(2)]
 
-        def upload(k):
+        def upload(k):                                             # k = step parity = which of the two images is due
             with torch.cuda.stream(copy_stream):
                 copy_stream.wait_event(consumed[k])                # the staging buffer is free again
-                staging[k].copy_(host_cur, non_blocking=True)
+                staging[k].copy_(host_img[k], non_blocking=True)
                 uploaded[k].record(copy_stream)
 
         def step(t):
@@ -233,12 +237,12 @@ def host_fed_leg(P, torch, dev, stream, streams, cfg, n_streams=1024, steps=12):
         for k in range(2):
             consumed[k].record(stream)
         upload(0)
-        for t in range(3):                                         # warm-up
+        for t in range(2):                                         # warm-up
             upload((t + 1) & 1)
             step(t)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for t in range(3, 3 + steps):
+        for t in range(2, 2 + steps):                              # `steps` even: the last step is a forward (A -> B) one
             upload((t + 1) & 1)
             step(t)
         torch.cuda.synchronize(dev)
@@ -251,6 +255,90 @@ def host_fed_leg(P, torch, dev, stream, streams, cfg, n_streams=1024, steps=12):
                 "what": "host-fed pipeline, NOT the headline value: every step uploads one new level-0 image per stream from pinned host memory "
                         "(second stream, double-buffered), copies cur->ref on the device, builds the new pyramids with the device half-sampler, then "
                         "plsvo_align_run + plsvo_poseopt_run; steady state over the timed steps"}
+    finally:
+        ctx.close()
+
+
+def chain_leg(P, torch, dev, stream, streams, cfg, n_streams=4096, steps=10, cpu_frames=6):
+    """Resident frame step (never `value`): alignment -> pose composition -> reprojection of the stream's landmarks -> direct matching ->
+    selection -> pose optimisation as ONE enqueue per step for n_streams streams (plsvo_chain_run), everything staying in HBM; beside
+    it the same chain on the CPU oracle, one stream at a time on one thread (Python between the four calls included)."""
+    capi, synth, abi = P.capi, P.synth, P.abi
+    n = min(n_streams, len(streams))
+    W, H = cfg["W"], cfg["H"]
+    sub = streams[:n]
+    ctx = capi.Context(dev.index, stream=stream.cuda_stream)
+    try:
+        ctx.config_pyramids(2 * n, W, H, cfg["pyr"])
+        for c0 in range(0, n, 256):
+            imgs = synth.render_streams(sub[c0:c0 + 256], device=dev)
+            ctx.build_pyramids_dev(2 * c0, 2 * imgs.shape[0], imgs.data_ptr(), W, W * H, 0)
+            ctx.synchronize()
+            del imgs
+
+        def chain_job(i, s_):
+            aj = P.align_job_from_stream(s_, cfg["maxl"], cfg["minl"], ref_slot=2 * i, cur_slot=2 * i + 1)
+            pos = np.concatenate([s_.pt_pos_w, s_.seg_spos_w, s_.seg_epos_w])
+            return abi.ChainJob(aj, s_.T_ref_w, s_.T_ref_w, 2 * i, len(s_.pt_pos_w), len(s_.seg_spos_w), pos,
+                                np.concatenate([s_.pt_px, s_.seg_spx, s_.seg_epx]), np.concatenate([s_.pt_f, s_.seg_sf, s_.seg_ef]))
+        jobs = [chain_job(i, s_) for i, s_ in enumerate(sub)]
+        ctx.chain_stage(jobs, sub[0].cam, n_pyr_levels=cfg["pyr"] - 1)
+        for _ in range(2):
+            ctx.chain_run()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.chain_run()
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res = ctx.chain_fetch()
+        errs = np.array([synth.se3_log_angle_dist(r.pose.T, synth.se3_mul(s_.T_true, s_.T_ref_w)) for r, s_ in zip(res[:32], sub[:32])])
+        out = {"frames_per_s": round(n / dt, 1), "streams": n, "ms_per_step": round(1e3 * dt, 3),
+               "candidates_per_frame": jobs[0].n_cand, "matched_points_median": int(np.median([len(r.sel_pt) for r in res[:64]])),
+               "median_rot_err_vs_truth_rad": float(np.median(errs[:, 0])),
+               "what": "resident frame step, NOT the headline value: plsvo_chain_run = alignment, pose composition, reprojection of the stream's "
+                       "landmarks, direct matching, selection, pose optimisation, one enqueue per step, nothing leaves HBM"}
+        try:   # the same chain on the CPU oracle (checker only; one thread, Python between the calls)
+            from oracle import binding as ob
+            ob.build()
+            t_cpu, ang_max = 0.0, 0.0
+            for i in range(min(cpu_frames, n)):
+                s_, cj = sub[i], jobs[i]
+                ref, cur = ctx.download_pyramid(2 * i), ctx.download_pyramid(2 * i + 1)
+                t1 = time.perf_counter()
+                ar, _ = ob.sparse_align(cj.align_job, ref, cur)
+                T_k = synth.se3_mul(ar.T, s_.T_ref_w)
+                rp = ob.reproject(abi.ReprojectJob(s_.cam, np.stack([s_.T_ref_w, T_k]), np.ones(cj.n_cand, np.int32), cj.pos, cell_size=30))
+                vis = rp["cell"] >= 0
+                npt, nsg = cj.n_cand_pt, cj.n_cand_seg
+                sv = vis[npt:npt + nsg] & vis[npt + nsg:]
+                vis[npt:npt + nsg] = sv; vis[npt + nsg:] = sv
+                idx = np.nonzero(vis)[0]
+                m = len(idx)
+                mr = ob.match_direct(abi.MatchJob(s_.cam, np.stack([s_.T_ref_w, T_k]), np.array([0, 1], np.int32), np.ones(m, np.int32), np.zeros(m, np.int32),
+                                                  cj.ref_px[idx], cj.ref_f[idx], np.zeros(m, np.int32), np.zeros(m, np.uint8), np.zeros((m, 2)), cj.pos[idx],
+                                                  rp["px"][idx], cfg["pyr"] - 1, 10), [ref, cur])
+                found = np.zeros(cj.n_cand, bool); found[idx] = mr["found"].astype(bool)
+                px_new = rp["px"].copy(); px_new[idx] = mr["px_cur"]
+                level = np.zeros(cj.n_cand, np.int32); level[idx] = np.maximum(mr["search_level"], 0)
+                pt_i = np.nonzero(found[:npt])[0]
+                seg_i = np.nonzero(found[npt:npt + nsg] & found[npt + nsg:])[0]
+                brg = lambda px: (lambda r: r / np.linalg.norm(r, axis=1, keepdims=True))(np.stack([(px[:, 0] - s_.cam[2]) / s_.cam[0], (px[:, 1] - s_.cam[3]) / s_.cam[1], np.ones(len(px))], axis=1))
+                sf, ef = brg(px_new[npt + seg_i]), brg(px_new[npt + nsg + seg_i])
+                line = np.cross(sf, ef)
+                line = line / np.sqrt(line[:, 0:1] ** 2 + line[:, 1:2] ** 2) if len(seg_i) else np.zeros((0, 3))
+                po, _ = ob.pose_optimize(abi.PoseOptJob(T_k, abs(s_.cam[0]), 2.0, 10, brg(px_new[pt_i]), cj.pos[pt_i], level[pt_i], line,
+                                                        cj.pos[npt + seg_i], cj.pos[npt + nsg + seg_i], level[npt + seg_i]))
+                t_cpu += time.perf_counter() - t1
+                ang_max = max(ang_max, synth.se3_log_angle_dist(po.T, res[i].pose.T)[0])
+            k = min(cpu_frames, n)
+            out["cpu_oracle_chain"] = {"frames_per_s": round(k / t_cpu, 2), "frames": k, "threads": 1,
+                                       "max_rot_diff_vs_device_rad": ang_max,
+                                       "note": "oracle/libplsvo_oracle.so through its Python binding, one stream at a time"}
+            out["speedup_vs_cpu_oracle_chain_1thread"] = round(out["frames_per_s"] / (k / t_cpu), 1)
+        except Exception as e:
+            out["cpu_oracle_chain"] = {"error": str(e)[:200]}
+        return out
     finally:
         ctx.close()
 
@@ -497,6 +585,10 @@ def main():
                     result["host_fed"] = host_fed_leg(P, torch, dev, stream, streams, cfg)
                 except Exception as e:   # never take the headline line down
                     result["host_fed"] = {"error": str(e)[:300]}
+                try:
+                    result["frame_chain"] = chain_leg(P, torch, dev, stream, streams, cfg)
+                except Exception as e:
+                    result["frame_chain"] = {"error": str(e)[:300]}
             print(json.dumps(result), flush=True)
         for sh in shard:
             sh["ctx"].close()

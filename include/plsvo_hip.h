@@ -402,6 +402,69 @@ typedef struct plsvo_reproject_out { /* caller buffers; either may be NULL */
 
 int plsvo_reproject(plsvo_ctx* ctx, const plsvo_reproject_in* in, plsvo_reproject_out* out);
 
+/* ------------------------------------------------------------------------------------------ */
+/* resident frame step (hot-path contract row (f) "next": the callers either side of the path) */
+/* FrameHandlerMono::processFrame runs alignment -> Reprojector::reprojectMap -> pose          */
+/* optimisation back to back (src/frame_handler_mono.cpp:263-345).  plsvo_chain_* runs the     */
+/* same sequence for a batch of streams in ONE call: the alignment result is composed into the */
+/* new frame's pose (:92), the map candidates are projected with it, matched                   */
+/* (Matcher::findMatchDirect), selected, turned into bearings / line equations                 */
+/* (src/feature.cpp:103-104) and handed to the pose optimiser without leaving the device.      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* One stream.  Candidates are the landmarks of ONE keyframe (pose T_kf_w, pyramid slot kf_slot) with their observation in it, in
+ * the caller's order of preference (the reference sorts a cell's candidates by landmark quality, reprojector.cpp:225):
+ * n_cand_pt points, then the start points of n_cand_seg segments, then their end points -- every array below has
+ * n_cand_pt + 2 * n_cand_seg entries in that order (ref_type / ref_grad are read for points only). */
+typedef struct plsvo_chain_in {
+  plsvo_align_in align;             /* previous frame -> new frame; ref_slot / cur_slot are the two frames' pyramid slots */
+  double T_prev_w[7];               /* previous frame's T_f_w_ */
+  double T_kf_w[7];                 /* keyframe's T_f_w_ */
+  int32_t kf_slot;
+  int32_t n_cand_pt, n_cand_seg;
+  int32_t reserved0;
+  const double* pos;                /* 3 per candidate: Point::pos_ / LineSeg::spos_ / LineSeg::epos_ */
+  const double* ref_px;             /* 2: the keyframe observation (as plsvo_match_in) */
+  const double* ref_f;              /* 3 */
+  const int32_t* ref_level;
+  const uint8_t* ref_type;          /* PLSVO_FTR_*; may be NULL (all corners) */
+  const double* ref_grad;           /* 2; may be NULL without edgelets */
+  const uint8_t* active;            /* may be NULL: 0 = leave this candidate out (e.g. a landmark not yet in the map) */
+} plsvo_chain_in;
+
+typedef struct plsvo_chain_params {
+  plsvo_pinhole cam;                /* one camera for the batch */
+  int32_t n_pyr_levels;             /* Config::nPyrLevels() (matcher) */
+  int32_t align_max_iter;           /* Matcher::Options::align_max_iter (10) */
+  int32_t cell_size;                /* Config::gridSize(): the reprojection grid of the points (reprojector.cpp:57-66) */
+  int32_t cell_rule;                /* 0: every matched candidate becomes a feature; 1: the reference's rule -- per cell the first
+                                       candidate that matches, cells in cell_order, stop after the match that makes the count exceed
+                                       max_fts (reprojector.cpp:188-199, :222-243).  Points only: every segment whose two end points
+                                       match becomes a feature (the reference files a segment under both end-point cells, :405-421) */
+  int32_t max_fts;                  /* Config::maxFts() */
+  int32_t poseopt_n_iter;           /* 10 (src/config.cpp:103) */
+  const int32_t* cell_order;        /* grid_n_cols * grid_n_rows cell indices (Grid::cell_order, shuffled once, :63-66); NULL = 0,1,2,.. */
+  double reproj_thresh;             /* 2.0 (src/config.cpp:102) */
+} plsvo_chain_params;
+
+typedef struct plsvo_chain_out {
+  plsvo_align_out align;            /* as plsvo_align_fetch */
+  plsvo_poseopt_out pose;           /* as plsvo_poseopt_fetch; pt_keep / seg_keep index the SELECTED features (sel_pt / sel_seg order) */
+  int32_t n_sel_pt, n_sel_seg;      /* features the new frame received */
+  /* caller buffers, any may be NULL */
+  uint8_t* found;                   /* per candidate: findMatchDirect's result (0 for candidates left out) */
+  double* px;                       /* 2 per candidate: refined pixel (the projection for candidates left out / not found) */
+  int32_t* search_level;            /* per candidate */
+  int32_t* sel_pt;                  /* n_cand_pt: candidate index of selected point feature k, k < n_sel_pt */
+  int32_t* sel_seg;                 /* n_cand_seg: segment index of selected segment feature k, k < n_sel_seg */
+} plsvo_chain_out;
+
+int plsvo_chain_stage(plsvo_ctx* ctx, int n, const plsvo_chain_in* in, const plsvo_chain_params* params);
+int plsvo_chain_run(plsvo_ctx* ctx);     /* enqueue only: alignment, pose composition, reprojection, matching, selection, pose optimisation */
+int plsvo_chain_fetch(plsvo_ctx* ctx, int n, plsvo_chain_out* out);
+int plsvo_frame_step_batch(plsvo_ctx* ctx, int n, const plsvo_chain_in* in, const plsvo_chain_params* params, plsvo_chain_out* out);
+const double* plsvo_chain_poses_dev(plsvo_ctx* ctx);   /* n*7 doubles: the optimised T_f_w of the staged streams, on the device */
+
 /* TUM-style trajectory record of a frame (app/run_pipeline.cpp:425-451): the camera pose in the world,
  * T_f_w^-1, as tx ty tz qx qy qz qw.  Returns 1 and fills out7 when the reference would write the line, 0 when
  * it skips the frame (a covariance entry outside (1e-16, 1e16), or an exactly-identity pose).  Host-only helper:

@@ -104,6 +104,24 @@ class ReprojectOut(C.Structure):
     _fields_ = [("px", c_double_p), ("cell", c_i32_p)]
 
 
+class ChainIn(C.Structure):
+    _fields_ = [("align", AlignIn), ("T_prev_w", C.c_double * 7), ("T_kf_w", C.c_double * 7), ("kf_slot", C.c_int32),
+                ("n_cand_pt", C.c_int32), ("n_cand_seg", C.c_int32), ("reserved0", C.c_int32),
+                ("pos", c_double_p), ("ref_px", c_double_p), ("ref_f", c_double_p), ("ref_level", c_i32_p), ("ref_type", c_u8_p),
+                ("ref_grad", c_double_p), ("active", c_u8_p)]
+
+
+class ChainParams(C.Structure):
+    _fields_ = [("cam", Pinhole), ("n_pyr_levels", C.c_int32), ("align_max_iter", C.c_int32), ("cell_size", C.c_int32),
+                ("cell_rule", C.c_int32), ("max_fts", C.c_int32), ("poseopt_n_iter", C.c_int32), ("cell_order", c_i32_p),
+                ("reproj_thresh", C.c_double)]
+
+
+class ChainOut(C.Structure):
+    _fields_ = [("align", AlignOut), ("pose", PoseOptOut), ("n_sel_pt", C.c_int32), ("n_sel_seg", C.c_int32),
+                ("found", c_u8_p), ("px", c_double_p), ("search_level", c_i32_p), ("sel_pt", c_i32_p), ("sel_seg", c_i32_p)]
+
+
 c_float_p = C.POINTER(C.c_float)
 
 
@@ -415,3 +433,40 @@ class SeedsJob:
             for name, _, _ in spec:
                 out[name] = bufs[name][:n].copy()
         return out
+
+
+class ChainJob:
+    """One stream of a resident frame step (plsvo_chain_in): an AlignJob plus the map candidates of one keyframe, ordered
+    [points | segment start points | segment end points]."""
+
+    def __init__(self, align_job, T_prev_w, T_kf_w, kf_slot, n_cand_pt, n_cand_seg, pos, ref_px, ref_f, ref_level=None, ref_type=None,
+                 ref_grad=None, active=None):
+        nc = int(n_cand_pt) + 2 * int(n_cand_seg)
+        self.align_job = align_job
+        self.pos = _f64(pos, 3 * nc).reshape(-1, 3)
+        self.ref_px = _f64(ref_px, 2 * nc).reshape(-1, 2)
+        self.ref_f = _f64(ref_f, 3 * nc).reshape(-1, 3)
+        self.ref_level = np.ascontiguousarray(np.zeros(nc, np.int32) if ref_level is None else ref_level, dtype=np.int32)
+        self.ref_type = None if ref_type is None else np.ascontiguousarray(ref_type, dtype=np.uint8)
+        self.ref_grad = None if ref_grad is None else _f64(ref_grad, 2 * nc)
+        self.active = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        self.n_cand_pt, self.n_cand_seg, self.n_cand = int(n_cand_pt), int(n_cand_seg), nc
+        c = ChainIn()
+        c.align = align_job.c
+        c.T_prev_w[:] = list(_f64(T_prev_w, 7))
+        c.T_kf_w[:] = list(_f64(T_kf_w, 7))
+        c.kf_slot, c.n_cand_pt, c.n_cand_seg = int(kf_slot), int(n_cand_pt), int(n_cand_seg)
+        c.pos, c.ref_px, c.ref_f = _ptr(self.pos, c_double_p), _ptr(self.ref_px, c_double_p), _ptr(self.ref_f, c_double_p)
+        c.ref_level = _ptr(self.ref_level, c_i32_p)
+        c.ref_type = C.cast(None, c_u8_p) if self.ref_type is None else self.ref_type.ctypes.data_as(c_u8_p)
+        c.ref_grad = C.cast(None, c_double_p) if self.ref_grad is None else self.ref_grad.ctypes.data_as(c_double_p)
+        c.active = C.cast(None, c_u8_p) if self.active is None else self.active.ctypes.data_as(c_u8_p)
+        self.c = c
+
+
+class ChainResult:
+    def __init__(self, out, job, seg_alive, pt_keep, seg_keep, found, px, level, sel_pt, sel_seg):
+        self.align = AlignResult(out.align, seg_alive)
+        self.pose = PoseOptResult(out.pose, pt_keep[:out.n_sel_pt].copy(), seg_keep[:out.n_sel_seg].copy())
+        self.found, self.px, self.search_level = found[:job.n_cand].astype(bool), px[:job.n_cand].copy(), level[:job.n_cand].copy()
+        self.sel_pt, self.sel_seg = sel_pt[:out.n_sel_pt].copy(), sel_seg[:out.n_sel_seg].copy()

@@ -23,6 +23,7 @@ SYMBOLS = [
     "plsvo_pose_optimize", "plsvo_pose_optimize_batch", "plsvo_poseopt_stage", "plsvo_poseopt_run", "plsvo_poseopt_fetch",
     "plsvo_poseopt_set_trace", "plsvo_poseopt_fetch_trace", "plsvo_poseopt_poses_dev", "plsvo_poseopt_copy_poses", "plsvo_poseopt_work",
     "plsvo_structure_optimize", "plsvo_match_direct", "plsvo_reproject", "plsvo_trajectory_record", "plsvo_update_seeds",
+    "plsvo_chain_stage", "plsvo_chain_run", "plsvo_chain_fetch", "plsvo_frame_step_batch", "plsvo_chain_poses_dev",
     "plsvo_gather_poses",
     "plsvo_hip_set_profiling", "plsvo_hip_kernel_time", "plsvo_hip_reset_profiling",
     "plsvo_hip_version", "plsvo_hip_device_info",
@@ -90,6 +91,11 @@ def lib():
         "plsvo_reproject": (C.c_int, [ctxp, C.POINTER(abi.ReprojectIn), C.POINTER(abi.ReprojectOut)]),
         "plsvo_update_seeds": (C.c_int, [ctxp, C.POINTER(abi.SeedsIn), C.POINTER(abi.SeedsOut)]),
         "plsvo_trajectory_record": (C.c_int, [abi.c_double_p, abi.c_double_p, abi.c_double_p]),
+        "plsvo_chain_stage": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.ChainIn), C.POINTER(abi.ChainParams)]),
+        "plsvo_chain_run": (C.c_int, [ctxp]),
+        "plsvo_chain_fetch": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.ChainOut)]),
+        "plsvo_frame_step_batch": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.ChainIn), C.POINTER(abi.ChainParams), C.POINTER(abi.ChainOut)]),
+        "plsvo_chain_poses_dev": (vp, [ctxp]),
         "plsvo_align_slot_layout": (C.c_int, [C.POINTER(abi.AlignIn), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                               C.POINTER(C.c_longlong)]),
         "plsvo_gather_poses": (C.c_int, [ctxp, vp, vp, C.c_int, vp]),
@@ -319,6 +325,54 @@ class Context:
 
     def poseopt_poses_dev(self):
         return self.L.plsvo_poseopt_poses_dev(self.h)
+
+    # ---- resident frame step ----
+    def chain_stage(self, jobs, cam, n_pyr_levels=3, align_max_iter=10, cell_size=30, cell_rule=False, max_fts=120, cell_order=None,
+                    reproj_thresh=2.0, poseopt_n_iter=10):
+        n = len(jobs)
+        arr = (abi.ChainIn * n)(*[j.c for j in jobs])
+        pr = abi.ChainParams()
+        pr.cam = cam if isinstance(cam, abi.Pinhole) else abi.Pinhole(*cam)
+        pr.n_pyr_levels, pr.align_max_iter, pr.cell_size, pr.cell_rule = int(n_pyr_levels), int(align_max_iter), int(cell_size), int(bool(cell_rule))
+        pr.max_fts, pr.poseopt_n_iter, pr.reproj_thresh = int(max_fts), int(poseopt_n_iter), float(reproj_thresh)
+        self._chain_order = None if cell_order is None else np.ascontiguousarray(cell_order, dtype=np.int32)
+        pr.cell_order = C.cast(None, abi.c_i32_p) if self._chain_order is None else self._chain_order.ctypes.data_as(abi.c_i32_p)
+        self._chk(self.L.plsvo_chain_stage(self.h, n, arr, C.byref(pr)))
+        self._chain_jobs = list(jobs)
+        self._align_jobs = [j.align_job for j in jobs]
+
+    def chain_run(self):
+        self._chk(self.L.plsvo_chain_run(self.h))
+
+    def chain_fetch(self):
+        jobs = self._chain_jobs
+        n = len(jobs)
+        outs = (abi.ChainOut * n)()
+        bufs = []
+        for o, j in zip(outs, jobs):
+            b = dict(alive=np.ones(max(j.align_job.n_seg, 1), np.uint8), pk=np.zeros(max(j.n_cand_pt, 1), np.uint8), sk=np.zeros(max(j.n_cand_seg, 1), np.uint8),
+                     found=np.zeros(max(j.n_cand, 1), np.uint8), px=np.zeros((max(j.n_cand, 1), 2)), level=np.zeros(max(j.n_cand, 1), np.int32),
+                     sel_pt=np.zeros(max(j.n_cand_pt, 1), np.int32), sel_seg=np.zeros(max(j.n_cand_seg, 1), np.int32))
+            o.align.seg_alive_out = b["alive"].ctypes.data_as(abi.c_u8_p)
+            o.pose.pt_keep = b["pk"].ctypes.data_as(abi.c_u8_p)
+            o.pose.seg_keep = b["sk"].ctypes.data_as(abi.c_u8_p)
+            o.found = b["found"].ctypes.data_as(abi.c_u8_p)
+            o.px = b["px"].ctypes.data_as(abi.c_double_p)
+            o.search_level = b["level"].ctypes.data_as(abi.c_i32_p)
+            o.sel_pt = b["sel_pt"].ctypes.data_as(abi.c_i32_p)
+            o.sel_seg = b["sel_seg"].ctypes.data_as(abi.c_i32_p)
+            bufs.append(b)
+        self._chk(self.L.plsvo_chain_fetch(self.h, n, outs))
+        return [abi.ChainResult(o, j, b["alive"][:j.align_job.n_seg].copy(), b["pk"], b["sk"], b["found"], b["px"], b["level"], b["sel_pt"], b["sel_seg"])
+                for o, j, b in zip(outs, jobs, bufs)]
+
+    def frame_step_batch(self, jobs, cam, **params):
+        self.chain_stage(jobs, cam, **params)
+        self.chain_run()
+        return self.chain_fetch()
+
+    def chain_poses_dev(self):
+        return self.L.plsvo_chain_poses_dev(self.h)
 
     # ---- structure optimisation ----
     def structure_optimize(self, job):

@@ -222,6 +222,33 @@ __device__ __noinline__ void exact_chi2_pair(const PLSVO_GLOBAL float* bufA, con
   wave_lds_fence();
 }
 
+// the same with the two planes in LDS (small batches): no staging, lane 0 / lane 1 walk plane A / B directly
+__device__ __noinline__ void exact_chi2_pair_lds(const PLSVO_LDS float* planeA, const PLSVO_LDS float* planeB, int n_pts, int n_seg, int iter,
+                                                 const PLSVO_LDS int* s_dead, const PLSVO_LDS float* s_lterm, int scap, PLSVO_LDS float* s_out) {
+  const int lane = threadIdx.x & 63;
+  if (lane < 2) {
+    const plsvo_v4f z4 = { 0.f, 0.f, 0.f, 0.f };
+    const PLSVO_LDS plsvo_v4f* w = reinterpret_cast<const PLSVO_LDS plsvo_v4f*>(lane ? planeB : planeA);
+    float sum = 0.0f;
+    plsvo_v4f a0 = z4, a1 = z4, a2 = z4, a3 = z4;
+    if (n_pts > 0) { a0 = w[0]; a1 = w[1]; a2 = w[2]; a3 = w[3]; }
+    for (int n = 0; n < n_pts; ++n) {
+      plsvo_v4f b0 = z4, b1 = z4, b2 = z4, b3 = z4;
+      if (n + 1 < n_pts) { b0 = w[4 * n + 4]; b1 = w[4 * n + 5]; b2 = w[4 * n + 6]; b3 = w[4 * n + 7]; }
+      sum = chain4(sum, a0); sum = chain4(sum, a1); sum = chain4(sum, a2); sum = chain4(sum, a3);
+      a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+    }
+    float seg_sum = 0.0f;
+    for (int sg = 0; sg < n_seg; ++sg) {
+      const int dead = s_dead[sg];
+      const float t = s_lterm[((iter - lane) & 1) * scap + sg];
+      seg_sum = __fadd_rn(seg_sum, (dead == 0 || dead > iter - lane + 1) ? t : 0.0f);
+    }
+    s_out[lane] = __fadd_rn(sum, seg_sum);
+  }
+  wave_lds_fence();
+}
+
 // ------------------------------------------------------------------------------------------------
 // SparseImgAlign::run for every job of the batch: levels [level_hi .. level_lo] of each job's range
 // ------------------------------------------------------------------------------------------------
@@ -249,7 +276,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   float* s_abs = reinterpret_cast<float*>(s_meta + cap);                 // cap: sum |res| of the slot's 16 pixels, -1 = sample not in the image
   int* s_dead = reinterpret_cast<int*>(s_abs + cap);                     // scap: per segment, 0 = alive, k + 1 = culled at iteration k of this level
   float* s_lterm = reinterpret_cast<float*>(s_dead + scap);              // 2 * scap + 2: exact chi2 term of every line, two iterations; the two sums
-  float* s_win = reinterpret_cast<float*>(smem + align_chi_window_offset(T, cap, scap));   // 1024: two 32-slot windows of chi_terms
+  float* s_win = reinterpret_cast<float*>(smem + align_chi_window_offset(T, cap, scap));   // 1024: two 32-slot windows of chi_terms, or the two planes themselves (chi_lds_pts)
 
 #ifdef PLSVO_TIMING
   __shared__ unsigned long long s_time[8];
@@ -593,8 +620,13 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           // pixel arithmetic pins every later load behind it (measured +31 % launch time there, and the launch is within a few
           // per cent of the achievable HBM rate: every byte written costs its time, which is why line pixels are not stored).
           if (accumulate && p < job.n_pts) {
-            float4* const chi_dst = reinterpret_cast<float4*>(chi_it + (unsigned)(p * 16 + 8 * half));   // wave-uniform base + 32-bit lane offset
-            PLSVO_CHI_STORE(chi_dst, chi_t0); PLSVO_CHI_STORE(chi_dst + 1, chi_t1);
+            if (b.chi_lds_pts > 0) {   // small batches: the planes are in LDS (kernel-uniform)
+              float4* const chi_dst = reinterpret_cast<float4*>(s_win + (iter & 1) * b.chi_lds_pts * 16 + p * 16 + 8 * half);
+              chi_dst[0] = chi_t0; chi_dst[1] = chi_t1;
+            } else {
+              float4* const chi_dst = reinterpret_cast<float4*>(chi_it + (unsigned)(p * 16 + 8 * half));   // wave-uniform base + 32-bit lane offset
+              PLSVO_CHI_STORE(chi_dst, chi_t0); PLSVO_CHI_STORE(chi_dst + 1, chi_t1);
+            }
           }
 
           // -- weights: points 1; a line's samples share w / mean|res| (H) and w (Jres), :640-688
@@ -683,9 +715,13 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         const float band = PLSVO_CHI_BAND * __fsqrt_rn((float)nm_d) * 5.9604644775390625e-8f;
         const bool tie = iter > 0 && !s_ctl[1] && !isnan(x[0]) && fabs(new_chi2 - old_chi2) <= (double)band * old_chi2;
         if (tie) {   // wave-uniform
-          exact_chi2_pair((const PLSVO_GLOBAL float*)chi_it, (const PLSVO_GLOBAL float*)(b.chi_terms + (size_t)((iter & 1) ^ 1) * b.chi_plane + (size_t)job.pt_off * 16),
-                          job.n_pts, job.n_seg, iter, (const PLSVO_LDS int*)s_dead, (PLSVO_LDS float*)s_win, (const PLSVO_LDS float*)s_lterm, scap,
-                          (PLSVO_LDS float*)s_lterm + 2 * scap);
+          if (b.chi_lds_pts > 0)
+            exact_chi2_pair_lds((const PLSVO_LDS float*)(s_win + (iter & 1) * b.chi_lds_pts * 16), (const PLSVO_LDS float*)(s_win + ((iter & 1) ^ 1) * b.chi_lds_pts * 16),
+                                job.n_pts, job.n_seg, iter, (const PLSVO_LDS int*)s_dead, (const PLSVO_LDS float*)s_lterm, scap, (PLSVO_LDS float*)s_lterm + 2 * scap);
+          else
+            exact_chi2_pair((const PLSVO_GLOBAL float*)chi_it, (const PLSVO_GLOBAL float*)(b.chi_terms + (size_t)((iter & 1) ^ 1) * b.chi_plane + (size_t)job.pt_off * 16),
+                            job.n_pts, job.n_seg, iter, (const PLSVO_LDS int*)s_dead, (PLSVO_LDS float*)s_win, (const PLSVO_LDS float*)s_lterm, scap,
+                            (PLSVO_LDS float*)s_lterm + 2 * scap);
           const float FA = s_lterm[2 * scap], FB = s_lterm[2 * scap + 1];   // chi2 of this / of the previous iteration, before the division
           new_chi2 = (double)(FA / (float)nm);
           old_chi2 = (double)(FB / (float)(unsigned long long)(s_pose[30] + 0.5));
@@ -768,8 +804,9 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 }
 
 // LDS bytes the kernel needs for slot capacity `cap` and segment capacity `scap` (host side helper)
-size_t align_level_lds_bytes(int threads, int cap, int scap) {
-  return align_chi_window_offset(threads, cap, scap) + 1024 * sizeof(float) + 16;
+size_t align_level_lds_bytes(int threads, int cap, int scap, int chi_lds_pts) {
+  const size_t window = 1024 * sizeof(float), planes = (size_t)2 * chi_lds_pts * 16 * sizeof(float);
+  return align_chi_window_offset(threads, cap, scap) + (planes > window ? planes : window) + 16;
 }
 
 template <int T>

@@ -1,0 +1,146 @@
+// chain_kernels.hip -- the glue that keeps one frame step resident on the device.
+//
+// FrameHandlerMono::processFrame (src/frame_handler_mono.cpp:263-345) runs, back to back on one thread,
+//     sparse image alignment  ->  Reprojector::reprojectMap (project the map, file candidates in grid cells, refine one per cell with
+//     Matcher::findMatchDirect)  ->  pose_optimizer::optimizeGaussNewton
+// and every arrow is a few host-side lines: compose the pose (:92), test visibility, pick the cell winners, turn refined pixels into
+// bearings / line equations (src/feature.cpp:103-104).  Called one ABI entry point at a time those lines sit on the host between four
+// synchronous calls with PCIe copies either side.  The kernels here do them on the device, between the alignment, reprojection,
+// matching and pose-optimisation kernels of the same stream (plsvo_capi.hip::plsvo_chain_run):
+//   chain_pose_kernel     T_f_w(new) = T_cur_from_ref * T_f_w(prev)  -> frame table [keyframe, new frame] of every stream
+//   chain_active_kernel   candidate is worth matching: caller's mask, in frame (8-px border), a segment needs both end points
+//   chain_select_kernel   which matches become features of the new frame -- all of them, or the reference's rule: per grid cell the first
+//                         candidate (caller's order = its quality order) that matched, cells visited in the caller's (random) order until
+//                         more than max_fts have matched (src/reprojector.cpp:188-199, refineBestCandidate :222-243).  Matching every
+//                         candidate and selecting afterwards equals the reference's early exits because a match has no side effect on
+//                         other matches.  Then the selected features are written as pose-optimiser input, in selection order.
+#include <hip/hip_runtime.h>
+
+#include "plsvo_dev.hpp"
+#include "plsvo_math.hpp"
+
+namespace plsvo_hip {
+
+__global__ void __launch_bounds__(64) chain_pose_kernel(const ChainBatchDev b) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= b.n_jobs) return;
+  const ChainJobDev& J = b.jobs[j];
+  const SE3d T_k = se3_mul(se3_load(b.align_poses + 7 * j), se3_load(J.T_prev));   // cur_frame->T_f_w_ = T_cur_from_ref * ref_frame->T_f_w_
+  se3_store(se3_load(J.T_kf), b.frame_T + 14 * j);
+  se3_store(T_k, b.frame_T + 14 * j + 7);
+  b.frame_slot[2 * j] = J.kf_slot;
+  b.frame_slot[2 * j + 1] = J.cur_slot;
+}
+
+__global__ void __launch_bounds__(256) chain_active_kernel(const ChainBatchDev b) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= b.n_cand) return;
+  const ChainJobDev& J = b.jobs[b.cand_job[i]];
+  const int k = i - J.cand_off;
+  bool a = (b.active_in ? b.active_in[i] != 0 : true) && b.cell[i] >= 0;
+  if (k >= J.n_pt) {   // a segment end point: the other end must be in frame (and wanted) too (src/reprojector.cpp:405-421)
+    const int other = k < J.n_pt + J.n_seg ? i + J.n_seg : i - J.n_seg;
+    a = a && (b.active_in ? b.active_in[other] != 0 : true) && b.cell[other] >= 0;
+  }
+  b.active[i] = a ? 1 : 0;
+}
+
+// in-order compaction by ONE wave: flag[i] for i in [0, n) -> dst[rank] = value(i); returns the count (wave-uniform).  limit < 0: no limit
+template <class Flag, class Emit>
+__device__ __forceinline__ int wave_compact(int n, int limit, Flag flag, Emit emit) {
+  const int lane = threadIdx.x & 63;
+  int total = 0;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const bool f = i < n && flag(i);
+    const unsigned long long m = __ballot(f);
+    const int rank = total + __popcll(m & ((1ull << lane) - 1ull));
+    if (f && (limit < 0 || rank < limit)) emit(i, rank);
+    total += __popcll(m);
+    if (limit >= 0 && total >= limit) { total = limit; break; }
+  }
+  return total;
+}
+
+__global__ void __launch_bounds__(256) chain_select_kernel(const ChainBatchDev b) {
+  extern __shared__ int s_winner[];   // n_cells (cell rule only)
+  __shared__ int s_n[2];
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const ChainJobDev J = b.jobs[j];
+  const int c0 = J.cand_off;
+  int* const sel_pt = b.sel_pt + J.po_pt_off;
+  int* const sel_seg = b.sel_seg + J.po_seg_off;
+  auto matched = [&](int k) { return b.active[c0 + k] && b.found[c0 + k]; };
+
+  if (b.cell_rule) {
+    for (int c = tid; c < b.n_cells; c += 256) s_winner[c] = 0x7fffffff;
+    __syncthreads();
+    for (int k = tid; k < J.n_pt; k += 256)
+      if (matched(k)) atomicMin(&s_winner[b.cell[c0 + k]], k);        // first candidate of the cell, in the caller's order, that matched
+    __syncthreads();
+  }
+  if (tid < 64) {
+    int n_pt_sel;
+    if (b.cell_rule)    // cells in visit order; the reference stops AFTER the match that makes n_matches_ exceed max_fts
+      n_pt_sel = wave_compact(b.n_cells, b.max_fts + 1,
+                              [&](int r) { return s_winner[b.cell_order ? b.cell_order[r] : r] != 0x7fffffff; },
+                              [&](int r, int rank) { sel_pt[rank] = s_winner[b.cell_order ? b.cell_order[r] : r]; });
+    else
+      n_pt_sel = wave_compact(J.n_pt, -1, matched, [&](int k, int rank) { sel_pt[rank] = k; });
+    const int n_seg_sel = wave_compact(J.n_seg, -1, [&](int s) { return matched(J.n_pt + s) && matched(J.n_pt + J.n_seg + s); },
+                                       [&](int s, int rank) { sel_seg[rank] = s; });
+    if (tid == 0) { s_n[0] = n_pt_sel; s_n[1] = n_seg_sel; }
+  }
+  __syncthreads();
+  const int n_pt_sel = s_n[0], n_seg_sel = s_n[1];
+  // unit bearing of a pixel ([ext] vk::PinholeCamera::cam2world, normalised as Feature's constructor does)
+  auto bearing = [&](const double* px, double* f) {
+    const double x = (px[0] - b.cx) / b.fx, y = (px[1] - b.cy) / b.fy;
+    const double n = sqrt(x * x + y * y + 1.0);
+    f[0] = x / n; f[1] = y / n; f[2] = 1.0 / n;
+  };
+  for (int k = tid; k < n_pt_sel; k += 256) {
+    const int c = c0 + sel_pt[k], o = J.po_pt_off + k;
+    double f[3];
+    bearing(b.m_px + 2 * c, f);
+    for (int d = 0; d < 3; ++d) { b.pt_f[3 * o + d] = f[d]; b.pt_pos[3 * o + d] = b.pos[3 * c + d]; }
+    b.pt_level[o] = max(b.search_level[c], 0);
+  }
+  for (int k = tid; k < n_seg_sel; k += 256) {
+    const int cs = c0 + J.n_pt + sel_seg[k], ce = cs + J.n_seg, o = J.po_seg_off + k;
+    double sf[3], ef[3];
+    bearing(b.m_px + 2 * cs, sf); bearing(b.m_px + 2 * ce, ef);
+    // LineFeat: line = sf x ef, scaled to a unit normal in the image plane (src/feature.cpp:103-104)
+    double l[3] = { sf[1] * ef[2] - sf[2] * ef[1], sf[2] * ef[0] - sf[0] * ef[2], sf[0] * ef[1] - sf[1] * ef[0] };
+    const double n = sqrt(l[0] * l[0] + l[1] * l[1]);
+    for (int d = 0; d < 3; ++d) { b.seg_line[3 * o + d] = l[d] / n; b.seg_spos[3 * o + d] = b.pos[3 * cs + d]; b.seg_epos[3 * o + d] = b.pos[3 * ce + d]; }
+    b.seg_level[o] = max(b.search_level[cs], 0);
+  }
+  if (tid == 0) {
+    PoseJobDev& P = b.po_jobs[j];
+    for (int d = 0; d < 7; ++d) P.T0[d] = b.frame_T[14 * j + 7 + d];
+    P.fx = fabs(b.fx); P.reproj_thresh = b.reproj_thresh; P.n_iter = b.po_n_iter; P.n_iter_ref = -1;
+    P.pt_off = J.po_pt_off; P.n_pts = n_pt_sel; P.seg_off = J.po_seg_off; P.n_seg = n_seg_sel;
+    P.ldlt_flavour = b.ldlt_flavour; P.reserved0 = 0;
+    b.n_sel[2 * j] = n_pt_sel; b.n_sel[2 * j + 1] = n_seg_sel;
+  }
+}
+
+hipError_t launch_chain_pose(const ChainBatchDev& b, hipStream_t stream) {
+  if (b.n_jobs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(chain_pose_kernel, dim3((b.n_jobs + 63) / 64), dim3(64), 0, stream, b);
+  return hipGetLastError();
+}
+hipError_t launch_chain_active(const ChainBatchDev& b, hipStream_t stream) {
+  if (b.n_cand <= 0) return hipSuccess;
+  hipLaunchKernelGGL(chain_active_kernel, dim3((b.n_cand + 255) / 256), dim3(256), 0, stream, b);
+  return hipGetLastError();
+}
+hipError_t launch_chain_select(const ChainBatchDev& b, hipStream_t stream) {
+  if (b.n_jobs <= 0) return hipSuccess;
+  const size_t lds = b.cell_rule ? (size_t)b.n_cells * sizeof(int) : 0;
+  hipLaunchKernelGGL(chain_select_kernel, dim3(b.n_jobs), dim3(256), lds, stream, b);
+  return hipGetLastError();
+}
+
+}  // namespace plsvo_hip

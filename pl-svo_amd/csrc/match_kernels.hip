@@ -44,9 +44,10 @@ __global__ void __launch_bounds__(MT) match_direct_kernel(const MatchBatchDev b)
   double px_cur[2] = { b.px_cur[2 * i], b.px_cur[2 * i + 1] };
   const double rpx0 = b.ref_px[2 * i], rpx1 = b.ref_px[2 * i + 1];
   int found = 0, search_level = -1, iters = 0;
+  const bool wanted = !b.active || b.active[i];   // resident frame step: the candidate was not visible / not selected for matching
 
   // matcher.cpp:168-170  isInFrame(px.cast<int>()/(1<<level), halfpatch_size_+2, level)
-  if (cam_is_in_frame(cam, (int)rpx0 / (1 << level), (int)rpx1 / (1 << level), 6, level)) {
+  if (wanted && cam_is_in_frame(cam, (int)rpx0 / (1 << level), (int)rpx1 / (1 << level), 6, level)) {
     const SE3d T_ref = se3_load(b.frame_T + 7 * rf), T_cur = se3_load(b.frame_T + 7 * cf);
     const SE3d T_ref_inv = se3_inv(T_ref);
     const SE3d T_cur_ref = se3_mul(T_cur, T_ref_inv);

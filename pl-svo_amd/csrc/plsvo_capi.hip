@@ -21,7 +21,7 @@
 
 namespace plsvo_hip {
 // kernels (align_kernels.hip, poseopt_kernels.hip, pyramid_kernels.hip)
-size_t align_level_lds_bytes(int threads, int cap, int scap);
+size_t align_level_lds_bytes(int threads, int cap, int scap, int chi_lds_pts);
 hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int scap, int level_hi, int level_lo, int do_init, int threads, size_t lds,
                                hipStream_t stream);
 hipError_t launch_pose_opt(const PoseBatchDev& b, double* d_poses, int threads, hipStream_t stream);
@@ -33,6 +33,9 @@ hipError_t launch_halfsample(const uint8_t* src, size_t src_pitch, int in_w, int
                              size_t dst_pitch, int n_slots, int rounding, hipStream_t stream);
 hipError_t launch_copy_level0(const uint8_t* src, size_t src_pitch, int w, int h, int stride, uint8_t* dst, size_t dst_pitch,
                               int n_slots, hipStream_t stream);
+hipError_t launch_chain_pose(const ChainBatchDev& b, hipStream_t stream);
+hipError_t launch_chain_active(const ChainBatchDev& b, hipStream_t stream);
+hipError_t launch_chain_select(const ChainBatchDev& b, hipStream_t stream);
 hipError_t launch_tile_level(const uint8_t* src, size_t src_pitch, int w, int h, uint8_t* dst, size_t dst_pitch, int n_slots, hipStream_t stream);
 }  // namespace plsvo_hip
 
@@ -114,6 +117,17 @@ struct plsvo_ctx {
   DevBuf p_d_state, p_d_ptkeep, p_d_segkeep;   // (inputs: p_d_blob)
   DevBuf p_d_s32, p_d_s64, p_d_log, p_d_poses;
   PoseBatchDev p_b{};
+
+  // resident frame step (plsvo_chain_*): candidates, glue state, pose-optimiser input written on the device
+  bool ch_staged = false;
+  int ch_n = 0, ch_ncand = 0, ch_npt_cap = 0, ch_nseg_cap = 0;
+  std::vector<ChainJobDev> ch_jobs;
+  DevBuf ch_d_blob, ch_d_work, ch_d_po;
+  ChainBatchDev ch_b{};
+  MatchBatchDev ch_match{};
+  ReprojBatchDev ch_reproj{};
+  PoseBatchDev ch_pose{};
+  DevBuf ch_d_state, ch_d_ptkeep, ch_d_segkeep, ch_d_s32, ch_d_s64, ch_d_poses;
 
   // structure optimisation (one-shot batches)
   DevBuf s_d_in, s_d_out;
@@ -223,7 +237,8 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
   for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_tiled, &c->pyr_upload, &c->a_d_blob, &c->a_d_state, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv, &c->a_d_cref, &c->a_d_cdx,
                      &c->a_d_cdy, &c->a_d_chi, &c->a_d_log, &c->a_d_poses, &c->p_d_blob, &c->p_d_state, &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64,
-                     &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out };
+                     &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out, &c->ch_d_blob, &c->ch_d_work, &c->ch_d_po, &c->ch_d_state,
+                     &c->ch_d_ptkeep, &c->ch_d_segkeep, &c->ch_d_s32, &c->ch_d_s64, &c->ch_d_poses };
   for (DevBuf* b : bufs) b->release();
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -579,14 +594,19 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
 //   large batches (throughput): 128 threads, several workgroups per CU hide each other's serial solve/update tails;
 //   small batches (latency):    512 threads, the whole CU works on one frame and a Gauss-Newton iteration is one or two rounds.
 // Environment overrides (experiments only, read once at plsvo_hip_create): PLSVO_ALIGN_THREADS, PLSVO_ALIGN_PER_LEVEL, PLSVO_ALIGN_LDS_PAD.
-static void pick_align_config(const plsvo_ctx* c, int n_jobs, int cap, int scap, int* threads, size_t* lds) {
+static void pick_align_config(const plsvo_ctx* c, int n_jobs, int cap, int scap, int max_pts, int* threads, size_t* lds, int* chi_lds_pts) {
   const int cus = c->cu_count > 0 ? c->cu_count : 256;
   int t = 64;                            // >= 64 frames per CU: one wave per frame, no workgroup barrier at all
   if (n_jobs <= cus) t = 512;
   else if (n_jobs <= 4 * cus) t = 256;
   else if (n_jobs < 64 * cus) t = 128;
   if (c->env_align_threads) t = c->env_align_threads;
-  *threads = t; *lds = align_level_lds_bytes(t, cap, scap);
+  // chi2 terms: in LDS when a workgroup owns (most of) a CU -- a global store is acknowledged from the memory side (~1 us) and a
+  // lone frame has no other wave to hide that behind -- in HBM planes when eight frames share the CU's LDS
+  int pts = t >= 256 ? ((max_pts + 3) & ~3) : 0;
+  if (pts > 0 && align_level_lds_bytes(t, cap, scap, pts) > c->lds_per_block) pts = 0;
+  *chi_lds_pts = pts;
+  *threads = t; *lds = align_level_lds_bytes(t, cap, scap, pts);
   *lds += (size_t)c->env_align_lds_pad;   // occupancy experiments: unused LDS bytes per workgroup
 }
 
@@ -624,7 +644,10 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
   if (have_levels) for (int l = c->a_gmin; l <= c->a_gmax; ++l) cap = std::max(cap, c->a_cap[l]);
   int threads; size_t lds;
   const int scap = (c->a_scap + 3) & ~3;
-  pick_align_config(c, c->a_n, cap, scap, &threads, &lds);
+  int max_pts = 0, chi_lds_pts = 0;
+  for (const AlignJobDev& J : c->a_jobs) max_pts = std::max(max_pts, J.n_pts);
+  pick_align_config(c, c->a_n, cap, scap, max_pts, &threads, &lds, &chi_lds_pts);
+  c->a_b.chi_lds_pts = chi_lds_pts; c->a_b.reserved1 = 0;
   if (lds > c->lds_per_block) return fail(c, PLSVO_E_CAPACITY, "align_run: slot tables do not fit in LDS (too many features in one job)");
   const bool per_level = c->env_align_per_level;
   if (!per_level || !have_levels) {
@@ -1117,6 +1140,228 @@ extern "C" int plsvo_reproject(plsvo_ctx* c, const plsvo_reproject_in* in, plsvo
   if (out->px) memcpy(out->px, h.data(), out_d);
   if (out->cell) memcpy(out->cell, h.data() + out_d, out_i);
   return PLSVO_OK;
+}
+
+// ---- resident frame step ------------------------------------------------------------------------------
+namespace {
+// carve typed arrays out of one device allocation (256-byte aligned sections)
+struct Carver {
+  size_t off = 0;
+  template <typename T> size_t take(size_t n) { const size_t o = (off + 255) & ~(size_t)255; off = o + std::max(n, (size_t)1) * sizeof(T); return o; }
+};
+}  // namespace
+
+extern "C" int plsvo_chain_stage(plsvo_ctx* c, int n, const plsvo_chain_in* in, const plsvo_chain_params* pr) {
+  CTX_CHECK(c);
+  if (n <= 0 || !in || !pr) return fail(c, PLSVO_E_INVALID, "chain_stage: bad arguments");
+  if (pr->cell_size <= 0 || pr->n_pyr_levels < 1 || pr->align_max_iter < 0 || pr->poseopt_n_iter < 0 || pr->max_fts < 0)
+    return fail(c, PLSVO_E_INVALID, "chain_stage: bad parameters");
+  if (!c->pyr.base) return fail(c, PLSVO_E_STATE, "chain_stage: pyramids not configured");
+  if (pr->n_pyr_levels > c->pyr.n_levels) return fail(c, PLSVO_E_INVALID, "chain_stage: n_pyr_levels exceeds the configured pyramid");
+  if (pr->cam.width != c->pyr.w[0] || pr->cam.height != c->pyr.h[0]) return fail(c, PLSVO_E_INVALID, "chain_stage: camera size does not match the configured pyramid");
+  c->ch_staged = false;
+  // the alignment part is an ordinary staged alignment batch
+  std::vector<plsvo_align_in> ain((size_t)n);
+  for (int j = 0; j < n; ++j) ain[(size_t)j] = in[j].align;
+  int rc = plsvo_align_stage(c, n, ain.data()); if (rc) return rc;
+  const int grid_n_cols = (pr->cam.width + pr->cell_size - 1) / pr->cell_size, grid_n_rows = (pr->cam.height + pr->cell_size - 1) / pr->cell_size;
+  const int n_cells = grid_n_cols * grid_n_rows;
+  if (pr->cell_rule && (size_t)n_cells * sizeof(int) > 60000) return fail(c, PLSVO_E_CAPACITY, "chain_stage: reprojection grid too fine for the selection kernel");
+  if (pr->cell_rule && pr->cell_order)
+    for (int k = 0; k < n_cells; ++k) if (pr->cell_order[k] < 0 || pr->cell_order[k] >= n_cells) return fail(c, PLSVO_E_INVALID, "chain_stage: cell_order entry out of range");
+  std::vector<ChainJobDev> jobs((size_t)n);
+  std::vector<double> pos, rpx, rf, rgrad;
+  std::vector<int> rlevel, cand_job, frame_cur, frame_ref, order;
+  std::vector<uint8_t> rtype, active;
+  bool any_active = false, any_edgelet = false;
+  int npt_total = 0, nseg_total = 0;
+  for (int j = 0; j < n; ++j) {
+    const plsvo_chain_in& a = in[j];
+    const int nc = a.n_cand_pt + 2 * a.n_cand_seg;
+    if (a.n_cand_pt < 0 || a.n_cand_seg < 0) return fail(c, PLSVO_E_INVALID, "chain_stage: negative candidate count");
+    if (nc > 0 && (!a.pos || !a.ref_px || !a.ref_f || !a.ref_level)) return fail(c, PLSVO_E_INVALID, "chain_stage: null candidate array");
+    if (a.kf_slot < 0 || a.kf_slot >= c->pyr.n_slots) return fail(c, PLSVO_E_CAPACITY, "chain_stage: keyframe slot out of range");
+    ChainJobDev& J = jobs[(size_t)j];
+    for (int k = 0; k < 7; ++k) { J.T_prev[k] = a.T_prev_w[k]; J.T_kf[k] = a.T_kf_w[k]; }
+    J.kf_slot = a.kf_slot; J.cur_slot = a.align.cur_slot;
+    J.cand_off = (int)cand_job.size(); J.n_pt = a.n_cand_pt; J.n_seg = a.n_cand_seg;
+    J.po_pt_off = npt_total; J.po_seg_off = nseg_total; J.reserved0 = 0;
+    npt_total += a.n_cand_pt; nseg_total += a.n_cand_seg;
+    pos.insert(pos.end(), a.pos, a.pos + 3 * (size_t)nc);
+    rpx.insert(rpx.end(), a.ref_px, a.ref_px + 2 * (size_t)nc);
+    rf.insert(rf.end(), a.ref_f, a.ref_f + 3 * (size_t)nc);
+    for (int k = 0; k < nc; ++k) {
+      if (a.ref_level[k] < 0 || a.ref_level[k] >= c->pyr.n_levels) return fail(c, PLSVO_E_INVALID, "chain_stage: ref_level outside the configured pyramid");
+      const uint8_t ty = (a.ref_type && k < a.n_cand_pt) ? a.ref_type[k] : (uint8_t)PLSVO_FTR_CORNER;
+      if (ty == PLSVO_FTR_EDGELET) any_edgelet = true; else if (ty != PLSVO_FTR_CORNER) return fail(c, PLSVO_E_INVALID, "chain_stage: unknown feature type");
+      if (ty == PLSVO_FTR_EDGELET && !a.ref_grad) return fail(c, PLSVO_E_INVALID, "chain_stage: edgelets without ref_grad");
+      rtype.push_back(ty);
+      rgrad.push_back(a.ref_grad ? a.ref_grad[2 * k] : 0.0); rgrad.push_back(a.ref_grad ? a.ref_grad[2 * k + 1] : 0.0);
+      rlevel.push_back(a.ref_level[k]);
+      active.push_back(a.active ? (a.active[k] ? 1 : 0) : 1);
+      if (a.active) any_active = true;
+      cand_job.push_back(j); frame_ref.push_back(2 * j); frame_cur.push_back(2 * j + 1);
+    }
+  }
+  (void)any_edgelet;
+  const size_t NC = cand_job.size();
+  if (pr->cell_rule) { order.resize((size_t)n_cells); for (int k = 0; k < n_cells; ++k) order[(size_t)k] = pr->cell_order ? pr->cell_order[k] : k; }
+  Blob blob;
+  const size_t o_jobs = blob.add(jobs), o_pos = blob.add(pos), o_rpx = blob.add(rpx), o_rf = blob.add(rf), o_rgrad = blob.add(rgrad), o_rlevel = blob.add(rlevel),
+               o_cjob = blob.add(cand_job), o_fcur = blob.add(frame_cur), o_fref = blob.add(frame_ref), o_rtype = blob.add(rtype), o_active = blob.add(active),
+               o_order = blob.add(order);
+  if ((rc = upload_blob(c, c->ch_d_blob, blob))) return rc;
+  // work arrays
+  Carver w;
+  const size_t w_frameT = w.take<double>((size_t)n * 14), w_fslot = w.take<int>((size_t)n * 2), w_px = w.take<double>(NC * 2), w_cell = w.take<int>(NC),
+               w_act = w.take<uint8_t>(NC), w_mpx = w.take<double>(NC * 2), w_found = w.take<uint8_t>(NC), w_slevel = w.take<int>(NC), w_niter = w.take<int>(NC),
+               w_selpt = w.take<int>((size_t)npt_total), w_selseg = w.take<int>((size_t)nseg_total), w_nsel = w.take<int>((size_t)n * 2);
+  HIP_TRY(c, c->ch_d_work.ensure(w.off + 256));
+  Carver p;
+  const size_t p_jobs = p.take<PoseJobDev>((size_t)n), p_ptf = p.take<double>((size_t)npt_total * 3), p_ptpos = p.take<double>((size_t)npt_total * 3),
+               p_ptlev = p.take<int>((size_t)npt_total), p_line = p.take<double>((size_t)nseg_total * 3), p_spos = p.take<double>((size_t)nseg_total * 3),
+               p_epos = p.take<double>((size_t)nseg_total * 3), p_slev = p.take<int>((size_t)nseg_total);
+  HIP_TRY(c, c->ch_d_po.ensure(p.off + 256));
+  const size_t nft = std::max((size_t)npt_total + (size_t)nseg_total, (size_t)1);
+  HIP_TRY(c, c->ch_d_ptkeep.ensure(std::max((size_t)npt_total, (size_t)1)));
+  HIP_TRY(c, c->ch_d_segkeep.ensure(std::max((size_t)nseg_total, (size_t)1)));
+  HIP_TRY(c, c->ch_d_s32.ensure(nft * sizeof(float)));
+  HIP_TRY(c, c->ch_d_s64.ensure(nft * 3 * sizeof(double)));
+  HIP_TRY(c, c->ch_d_state.ensure((size_t)n * sizeof(PoseStateDev)));
+  HIP_TRY(c, c->ch_d_poses.ensure((size_t)n * 7 * sizeof(double)));
+  uint8_t* const B = c->ch_d_blob.as<uint8_t>();
+  uint8_t* const Wk = c->ch_d_work.as<uint8_t>();
+  uint8_t* const Po = c->ch_d_po.as<uint8_t>();
+  ChainBatchDev& b = c->ch_b;
+  b = ChainBatchDev{};
+  b.jobs = reinterpret_cast<const ChainJobDev*>(B + o_jobs); b.n_jobs = n; b.n_cand = (int)NC;
+  b.align_poses = c->a_d_poses.as<double>();
+  b.frame_T = reinterpret_cast<double*>(Wk + w_frameT); b.frame_slot = reinterpret_cast<int*>(Wk + w_fslot);
+  b.cand_job = reinterpret_cast<const int*>(B + o_cjob); b.pos = reinterpret_cast<const double*>(B + o_pos);
+  b.active_in = any_active ? B + o_active : nullptr;
+  b.cell = reinterpret_cast<const int*>(Wk + w_cell); b.active = Wk + w_act;
+  b.m_px = reinterpret_cast<const double*>(Wk + w_mpx); b.found = Wk + w_found; b.search_level = reinterpret_cast<const int*>(Wk + w_slevel);
+  b.fx = pr->cam.fx; b.fy = pr->cam.fy; b.cx = pr->cam.cx; b.cy = pr->cam.cy;
+  b.n_cells = n_cells; b.cell_rule = pr->cell_rule ? 1 : 0; b.max_fts = pr->max_fts;
+  b.cell_order = pr->cell_rule ? reinterpret_cast<const int*>(B + o_order) : nullptr;
+  b.po_jobs = reinterpret_cast<PoseJobDev*>(Po + p_jobs);
+  b.pt_f = reinterpret_cast<double*>(Po + p_ptf); b.pt_pos = reinterpret_cast<double*>(Po + p_ptpos); b.pt_level = reinterpret_cast<int*>(Po + p_ptlev);
+  b.seg_line = reinterpret_cast<double*>(Po + p_line); b.seg_spos = reinterpret_cast<double*>(Po + p_spos); b.seg_epos = reinterpret_cast<double*>(Po + p_epos);
+  b.seg_level = reinterpret_cast<int*>(Po + p_slev);
+  b.sel_pt = reinterpret_cast<int*>(Wk + w_selpt); b.sel_seg = reinterpret_cast<int*>(Wk + w_selseg); b.n_sel = reinterpret_cast<int*>(Wk + w_nsel);
+  b.reproj_thresh = pr->reproj_thresh; b.po_n_iter = pr->poseopt_n_iter; b.ldlt_flavour = c->ldlt_flavour;
+  ReprojBatchDev& r = c->ch_reproj;
+  r = ReprojBatchDev{};
+  r.fx = pr->cam.fx; r.fy = pr->cam.fy; r.cx = pr->cam.cx; r.cy = pr->cam.cy; r.cam_width = pr->cam.width; r.cam_height = pr->cam.height;
+  r.n = (int)NC; r.cell_size = pr->cell_size; r.grid_n_cols = grid_n_cols; r.boundary = 8;
+  r.frame_T = b.frame_T; r.frame = reinterpret_cast<const int*>(B + o_fcur); r.pos = b.pos;
+  r.px = reinterpret_cast<double*>(Wk + w_px); r.cell = reinterpret_cast<int*>(Wk + w_cell);
+  MatchBatchDev& m = c->ch_match;
+  m = MatchBatchDev{};
+  m.pyr_base = c->pyr.base; m.slot_bytes = c->pyr.slot_bytes; m.width = c->pyr.w[0]; m.height = c->pyr.h[0];
+  m.fx = pr->cam.fx; m.fy = pr->cam.fy; m.cx = pr->cam.cx; m.cy = pr->cam.cy; m.cam_width = pr->cam.width; m.cam_height = pr->cam.height;
+  m.n = (int)NC; m.n_pyr_levels = pr->n_pyr_levels; m.align_max_iter = pr->align_max_iter;
+  m.frame_T = b.frame_T; m.frame_slot = b.frame_slot; m.cur_frame = r.frame; m.ref_frame = reinterpret_cast<const int*>(B + o_fref);
+  m.ref_px = reinterpret_cast<const double*>(B + o_rpx); m.ref_f = reinterpret_cast<const double*>(B + o_rf); m.ref_level = reinterpret_cast<const int*>(B + o_rlevel);
+  m.ref_type = B + o_rtype; m.ref_grad = reinterpret_cast<const double*>(B + o_rgrad); m.pos = b.pos; m.px_cur = r.px;
+  m.px_out = reinterpret_cast<double*>(Wk + w_mpx); m.found = Wk + w_found; m.search_level = reinterpret_cast<int*>(Wk + w_slevel); m.n_iter = reinterpret_cast<int*>(Wk + w_niter);
+  m.active = b.active;
+  PoseBatchDev& q = c->ch_pose;
+  q = PoseBatchDev{};
+  q.jobs = b.po_jobs; q.state = c->ch_d_state.as<PoseStateDev>();
+  q.pt_f = b.pt_f; q.pt_pos = b.pt_pos; q.pt_level = b.pt_level; q.seg_line = b.seg_line; q.seg_spos = b.seg_spos; q.seg_epos = b.seg_epos; q.seg_level = b.seg_level;
+  q.pt_keep = c->ch_d_ptkeep.as<uint8_t>(); q.seg_keep = c->ch_d_segkeep.as<uint8_t>();
+  q.scratch_f32 = c->ch_d_s32.as<float>(); q.scratch_f64 = c->ch_d_s64.as<double>();
+  q.log = nullptr; q.log_cap = 0; q.n_jobs = n;
+  c->ch_jobs.swap(jobs);
+  c->ch_n = n; c->ch_ncand = (int)NC; c->ch_npt_cap = npt_total; c->ch_nseg_cap = nseg_total;
+  c->ch_staged = true;
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_chain_run(plsvo_ctx* c) {
+  CTX_CHECK(c);
+  RoctxRange range("frame_step");
+  if (!c->ch_staged || !c->a_staged || c->a_n != c->ch_n) return fail(c, PLSVO_E_STATE, "chain_run: no staged frame step (or the alignment batch was re-staged since)");
+  int rc = plsvo_align_run(c); if (rc) return rc;
+  HIP_TRY(c, launch_chain_pose(c->ch_b, c->stream));
+  { EventPair ep{}; prof_begin(c, PLSVO_K_MATCH, &ep);
+    HIP_TRY(c, launch_reproject(c->ch_reproj, c->stream));
+    HIP_TRY(c, launch_chain_active(c->ch_b, c->stream));
+    HIP_TRY(c, launch_match_direct(c->ch_match, c->stream));
+    HIP_TRY(c, launch_chain_select(c->ch_b, c->stream));
+    prof_end(c, PLSVO_K_MATCH, &ep); }
+  const int cus = c->cu_count > 0 ? c->cu_count : 256;
+  int threads = c->ch_n <= 2 * cus ? 256 : 64;
+  if (c->env_poseopt_threads) threads = c->env_poseopt_threads;
+  EventPair ep{}; prof_begin(c, PLSVO_K_POSEOPT, &ep);
+  HIP_TRY(c, launch_pose_opt(c->ch_pose, c->ch_d_poses.as<double>(), threads, c->stream));
+  prof_end(c, PLSVO_K_POSEOPT, &ep);
+  return PLSVO_OK;
+}
+
+extern "C" const double* plsvo_chain_poses_dev(plsvo_ctx* c) { return (c && c->ch_staged) ? c->ch_d_poses.as<double>() : nullptr; }
+
+extern "C" int plsvo_chain_fetch(plsvo_ctx* c, int n, plsvo_chain_out* out) {
+  CTX_CHECK(c);
+  if (!c->ch_staged) return fail(c, PLSVO_E_STATE, "chain_fetch: no staged frame step");
+  if (n != c->ch_n || !out) return fail(c, PLSVO_E_INVALID, "chain_fetch: n does not match the staged batch");
+  // the alignment results through the ordinary fetch (the caller's seg_alive_out buffers are honoured)
+  std::vector<plsvo_align_out> ao((size_t)n);
+  for (int j = 0; j < n; ++j) ao[(size_t)j].seg_alive_out = out[j].align.seg_alive_out;
+  int rc = plsvo_align_fetch(c, n, ao.data()); if (rc) return rc;
+  const size_t NC = (size_t)c->ch_ncand, NP = (size_t)c->ch_npt_cap, NS = (size_t)c->ch_nseg_cap;
+  std::vector<PoseStateDev> st((size_t)n);
+  std::vector<uint8_t> found(std::max(NC, (size_t)1)), pk(std::max(NP, (size_t)1)), sk(std::max(NS, (size_t)1));
+  std::vector<double> mpx(std::max(NC * 2, (size_t)1));
+  std::vector<int> slev(std::max(NC, (size_t)1)), selp(std::max(NP, (size_t)1)), sels(std::max(NS, (size_t)1)), nsel((size_t)n * 2);
+  const ChainBatchDev& b = c->ch_b;
+  HIP_TRY(c, hipMemcpyAsync(st.data(), c->ch_d_state.p, (size_t)n * sizeof(PoseStateDev), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(nsel.data(), b.n_sel, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  if (NC) {
+    HIP_TRY(c, hipMemcpyAsync(found.data(), b.found, NC, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(mpx.data(), b.m_px, NC * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(slev.data(), b.search_level, NC * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  }
+  if (NP) {
+    HIP_TRY(c, hipMemcpyAsync(pk.data(), c->ch_d_ptkeep.p, NP, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(selp.data(), b.sel_pt, NP * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  }
+  if (NS) {
+    HIP_TRY(c, hipMemcpyAsync(sk.data(), c->ch_d_segkeep.p, NS, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(sels.data(), b.sel_seg, NS * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int j = 0; j < n; ++j) {
+    const ChainJobDev& J = c->ch_jobs[(size_t)j];
+    const PoseStateDev& s = st[(size_t)j];
+    plsvo_chain_out& o = out[j];
+    o.align = ao[(size_t)j];
+    uint8_t* pko = o.pose.pt_keep; uint8_t* sko = o.pose.seg_keep;
+    memset(&o.pose, 0, sizeof(o.pose));
+    o.pose.pt_keep = pko; o.pose.seg_keep = sko;
+    for (int k = 0; k < 7; ++k) o.pose.T_f_w[k] = s.T[k];
+    for (int k = 0; k < 36; ++k) o.pose.cov[k] = s.cov[k];
+    o.pose.estimated_scale = s.estimated_scale; o.pose.error_init = s.error_init; o.pose.error_final = s.error_final;
+    o.pose.num_obs_pt = s.num_obs_pt; o.pose.num_obs_ls = s.num_obs_ls;
+    o.pose.iters = s.iters; o.pose.iters_ref = s.iters_ref; o.pose.status = s.status;
+    o.n_sel_pt = nsel[(size_t)j * 2]; o.n_sel_seg = nsel[(size_t)j * 2 + 1];
+    const int nc = J.n_pt + 2 * J.n_seg;
+    if (pko && o.n_sel_pt > 0) memcpy(pko, pk.data() + J.po_pt_off, (size_t)o.n_sel_pt);
+    if (sko && o.n_sel_seg > 0) memcpy(sko, sk.data() + J.po_seg_off, (size_t)o.n_sel_seg);
+    if (o.found && nc) memcpy(o.found, found.data() + J.cand_off, (size_t)nc);
+    if (o.px && nc) memcpy(o.px, mpx.data() + 2 * (size_t)J.cand_off, (size_t)nc * 2 * sizeof(double));
+    if (o.search_level && nc) memcpy(o.search_level, slev.data() + J.cand_off, (size_t)nc * sizeof(int));
+    if (o.sel_pt && o.n_sel_pt > 0) memcpy(o.sel_pt, selp.data() + J.po_pt_off, (size_t)o.n_sel_pt * sizeof(int));
+    if (o.sel_seg && o.n_sel_seg > 0) memcpy(o.sel_seg, sels.data() + J.po_seg_off, (size_t)o.n_sel_seg * sizeof(int));
+  }
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_frame_step_batch(plsvo_ctx* c, int n, const plsvo_chain_in* in, const plsvo_chain_params* params, plsvo_chain_out* out) {
+  int rc = plsvo_chain_stage(c, n, in, params); if (rc) return rc;
+  rc = plsvo_chain_run(c); if (rc) return rc;
+  return plsvo_chain_fetch(c, n, out);
 }
 
 // ---- trajectory record (host only; app/run_pipeline.cpp:425-451) ---------------------------------------

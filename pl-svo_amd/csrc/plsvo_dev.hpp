@@ -114,6 +114,8 @@ struct AlignBatchDev {
   // float sums do (align_kernels.hip::exact_chi2_pair).
   float* chi_terms;
   unsigned long long chi_plane;
+  int chi_lds_pts;             // > 0: the two planes live in LDS instead (capacity in points per plane): small batches, where a
+  int reserved1;               //      workgroup has LDS to spare and nothing to hide a global store's acknowledge behind
   double* poses;               // 7 per job: final model, contiguous (what a device-side consumer / the RCCL gather reads)
   PyrDesc pyr;
   plsvo_align_iterlog* log;    // log_cap per job, or null
@@ -178,6 +180,7 @@ struct MatchBatchDev {
   const double* ref_px; const double* ref_f; const int* ref_level; const uint8_t* ref_type; const double* ref_grad;
   const double* pos; const double* px_cur;
   double* px_out; uint8_t* found; int* search_level; int* n_iter;
+  const uint8_t* active;            // optional (resident frame step): candidates with 0 are reported "not found" without any work
 };
 
 // depth-filter seeds (include/plsvo_hip.h plsvo_seeds_in / plsvo_seeds_out), one lane per seed
@@ -198,6 +201,28 @@ struct SeedsBatchDev {
   int* o_pt_status; float* o_pt_a; float* o_pt_b; float* o_pt_mu; float* o_pt_sigma2; double* o_pt_xyz; double* o_pt_px; double* o_pt_depth;
   int* o_seg_status; float* o_seg_a; float* o_seg_b; float* o_seg_mu_s; float* o_seg_mu_e; float* o_seg_sigma2_s; float* o_seg_sigma2_e;
   double* o_seg_xyz_s; double* o_seg_xyz_e; double* o_seg_depth_s; double* o_seg_depth_e;
+};
+
+// resident frame step (chain_kernels.hip): one job = one stream's new frame
+struct ChainJobDev {
+  double T_prev[7], T_kf[7];        // previous frame's and keyframe's T_f_w
+  int kf_slot, cur_slot;            // pyramid slots
+  int cand_off, n_pt, n_seg;        // candidates of the job: [points | segment start points | segment end points] from cand_off
+  int po_pt_off, po_seg_off;        // where its selected features go in the pose optimiser's input arrays
+  int reserved0;
+};
+struct ChainBatchDev {
+  const ChainJobDev* jobs; int n_jobs, n_cand;
+  const double* align_poses;        // 7 per job: T_cur_from_ref of the alignment launch
+  double* frame_T; int* frame_slot; // 2 per job: [keyframe, new frame]
+  const int* cand_job; const double* pos; const uint8_t* active_in;
+  const int* cell; uint8_t* active;                                  // reprojection result / worth matching
+  const double* m_px; const uint8_t* found; const int* search_level; // matcher result
+  double fx, fy, cx, cy;
+  int n_cells, cell_rule, max_fts; const int* cell_order;
+  PoseJobDev* po_jobs; double* pt_f; double* pt_pos; int* pt_level; double* seg_line; double* seg_spos; double* seg_epos; int* seg_level;
+  int* sel_pt; int* sel_seg; int* n_sel;
+  double reproj_thresh; int po_n_iter, ldlt_flavour;
 };
 
 struct ReprojBatchDev {

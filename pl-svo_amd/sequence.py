@@ -59,6 +59,15 @@ class HipBackend:
         return self.ctx.update_seeds(job)
 
 
+class HipChainBackend(HipBackend):
+    """The same product backend with steps 1-4 of a frame -- alignment, reprojection, matching, pose optimisation -- as ONE resident
+    call (plsvo_frame_step_batch): poses, candidates, matches and keep masks stay in HBM between the kernels."""
+
+    def frame_step(self, job, T_prev, kf_T, kf_slot, n_pt, n_seg, pos_all, ref_px, ref_f, active, cam, n_pyr_levels, reproj_thresh):
+        cj = abi.ChainJob(job, T_prev, kf_T, kf_slot, n_pt, n_seg, pos_all, ref_px, ref_f, active=active)
+        return self.ctx.frame_step_batch([cj], cam, n_pyr_levels=n_pyr_levels, reproj_thresh=reproj_thresh)[0]
+
+
 def make_sequence(seed, n_frames=6, W=320, H=240, n_pts=120, n_seg=30, step_scale=0.5, total=None):
     """Camera moving smoothly over the textured plane of synth.make_align_stream.  Returns a dict with the level-0
     images, the camera, the true poses T_f_w of every frame and the map: landmark positions with their keyframe-0
@@ -136,40 +145,52 @@ def run_sequence(backend, seq, max_level=3, min_level=1, n_pyr_levels=3, reproj_
                            scaled(prev["pt_px"], P3[pi]), prev["seg_spx"], prev["seg_epx"],
                            np.linalg.norm(prev["seg_epx"] - prev["seg_spx"], axis=1), scaled(prev["seg_spx"], seq["seg_spos"][si]),
                            scaled(prev["seg_epx"], seq["seg_epos"][si]), ref_slot=k - 1, cur_slot=k)
-        ar = backend.sparse_align(job)
-        T_k = synth.se3_mul(ar.T, T_prev)                                                    # :92
-        # ---- 2. reprojection of the whole map (Reprojector::reprojectMap) ----
         pos_all = np.concatenate([P3, seq["seg_spos"], seq["seg_epos"]])
-        rp = backend.reproject(abi.ReprojectJob(cam, np.stack([kf_T, T_k]), np.ones(len(pos_all), np.int32), pos_all, cell_size=30))
-        vis = rp["cell"] >= 0
-        vis[:n_pts] &= known                     # seeds are not in the map yet
-        seg_vis = vis[n_pts:n_pts + n_seg] & vis[n_pts + n_seg:]
-        vis[n_pts:n_pts + n_seg] = seg_vis
-        vis[n_pts + n_seg:] = seg_vis
-        idx = np.nonzero(vis)[0]
-        # ---- 3. direct matching against the keyframe-0 observations (Matcher::findMatchDirect) ----
-        ref_px = np.concatenate([seq["pt_px0"], seq["seg_spx0"], seq["seg_epx0"]])[idx]
-        ref_f = np.concatenate([seq["pt_f0"], seq["seg_sf0"], seq["seg_ef0"]])[idx]
-        m = len(idx)
-        mj = abi.MatchJob(cam, np.stack([kf_T, T_k]), np.array([0, k], np.int32), np.ones(m, np.int32), np.zeros(m, np.int32), ref_px, ref_f,
-                          np.zeros(m, np.int32), np.zeros(m, np.uint8), np.zeros((m, 2)), pos_all[idx], rp["px"][idx], n_pyr_levels, 10)
-        mr = backend.match_direct(mj)
-        found = np.zeros(len(pos_all), bool)
-        found[idx] = mr["found"].astype(bool)
-        px_new = rp["px"].copy()
-        px_new[idx] = mr["px_cur"]
-        level = np.zeros(len(pos_all), np.int32)
-        level[idx] = np.maximum(mr["search_level"], 0)
-        pt_ok = found[:n_pts]
-        seg_ok = found[n_pts:n_pts + n_seg] & found[n_pts + n_seg:]
-        # ---- 4. motion-only pose optimisation on the matches (processFrame :327-329) ----
-        pt_i, seg_i = np.nonzero(pt_ok)[0], np.nonzero(seg_ok)[0]
-        sf, ef = _bearing(cam, px_new[n_pts + seg_i]), _bearing(cam, px_new[n_pts + n_seg + seg_i])
-        line = np.cross(sf, ef)
-        line = line / np.sqrt(line[:, 0:1] ** 2 + line[:, 1:2] ** 2) if len(seg_i) else np.zeros((0, 3))    # feature.cpp:103-104
-        pj = abi.PoseOptJob(T_k, abs(cam[0]), reproj_thresh, 10, _bearing(cam, px_new[pt_i]), P3[pt_i], level[pt_i], line,
-                            seq["seg_spos"][seg_i], seq["seg_epos"][seg_i], level[n_pts + seg_i])
-        pr = backend.pose_optimize(pj)
+        if hasattr(backend, "frame_step"):
+            # ---- 1-4 as one resident call: nothing but the final results comes back ----
+            act = np.concatenate([known, np.ones(2 * n_seg, bool)]).astype(np.uint8)
+            ref_px_all = np.concatenate([seq["pt_px0"], seq["seg_spx0"], seq["seg_epx0"]])
+            ref_f_all = np.concatenate([seq["pt_f0"], seq["seg_sf0"], seq["seg_ef0"]])
+            cr = backend.frame_step(job, T_prev, kf_T, 0, n_pts, n_seg, pos_all, ref_px_all, ref_f_all, act, cam, n_pyr_levels, reproj_thresh)
+            ar, pr = cr.align, cr.pose
+            px_new = cr.px
+            pt_i, seg_i = cr.sel_pt.astype(np.int64), cr.sel_seg.astype(np.int64)
+            pt_ok = np.zeros(n_pts, bool); pt_ok[pt_i] = True
+            seg_ok = np.zeros(n_seg, bool); seg_ok[seg_i] = True
+        else:
+            ar = backend.sparse_align(job)
+            T_k = synth.se3_mul(ar.T, T_prev)                                                    # :92
+            # ---- 2. reprojection of the whole map (Reprojector::reprojectMap) ----
+            rp = backend.reproject(abi.ReprojectJob(cam, np.stack([kf_T, T_k]), np.ones(len(pos_all), np.int32), pos_all, cell_size=30))
+            vis = rp["cell"] >= 0
+            vis[:n_pts] &= known                     # seeds are not in the map yet
+            seg_vis = vis[n_pts:n_pts + n_seg] & vis[n_pts + n_seg:]
+            vis[n_pts:n_pts + n_seg] = seg_vis
+            vis[n_pts + n_seg:] = seg_vis
+            idx = np.nonzero(vis)[0]
+            # ---- 3. direct matching against the keyframe-0 observations (Matcher::findMatchDirect) ----
+            ref_px = np.concatenate([seq["pt_px0"], seq["seg_spx0"], seq["seg_epx0"]])[idx]
+            ref_f = np.concatenate([seq["pt_f0"], seq["seg_sf0"], seq["seg_ef0"]])[idx]
+            m = len(idx)
+            mj = abi.MatchJob(cam, np.stack([kf_T, T_k]), np.array([0, k], np.int32), np.ones(m, np.int32), np.zeros(m, np.int32), ref_px, ref_f,
+                              np.zeros(m, np.int32), np.zeros(m, np.uint8), np.zeros((m, 2)), pos_all[idx], rp["px"][idx], n_pyr_levels, 10)
+            mr = backend.match_direct(mj)
+            found = np.zeros(len(pos_all), bool)
+            found[idx] = mr["found"].astype(bool)
+            px_new = rp["px"].copy()
+            px_new[idx] = mr["px_cur"]
+            level = np.zeros(len(pos_all), np.int32)
+            level[idx] = np.maximum(mr["search_level"], 0)
+            pt_ok = found[:n_pts]
+            seg_ok = found[n_pts:n_pts + n_seg] & found[n_pts + n_seg:]
+            # ---- 4. motion-only pose optimisation on the matches (processFrame :327-329) ----
+            pt_i, seg_i = np.nonzero(pt_ok)[0], np.nonzero(seg_ok)[0]
+            sf, ef = _bearing(cam, px_new[n_pts + seg_i]), _bearing(cam, px_new[n_pts + n_seg + seg_i])
+            line = np.cross(sf, ef)
+            line = line / np.sqrt(line[:, 0:1] ** 2 + line[:, 1:2] ** 2) if len(seg_i) else np.zeros((0, 3))    # feature.cpp:103-104
+            pj = abi.PoseOptJob(T_k, abs(cam[0]), reproj_thresh, 10, _bearing(cam, px_new[pt_i]), P3[pt_i], level[pt_i], line,
+                                seq["seg_spos"][seg_i], seq["seg_epos"][seg_i], level[n_pts + seg_i])
+            pr = backend.pose_optimize(pj)
         T_k = pr.T.copy()
         pt_keep, seg_keep = pr.pt_keep.astype(bool), pr.seg_keep.astype(bool)
         prev = dict(pt_idx=pt_i[pt_keep], pt_px=px_new[pt_i[pt_keep]], seg_idx=seg_i[seg_keep],

@@ -98,3 +98,78 @@ def test_hip_chain_matches_the_oracle_chain(P, ob, gpu_ctx, seqm, tmp_path):
     assert n == len(lines) == len(rd) and all(len(l.split()) == 8 for l in lines)
     q = np.array([[float(x) for x in l.split()[4:]] for l in lines])
     assert np.allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_resident_chain_equals_the_per_call_chain(P, ob, gpu_ctx, seqm):
+    """plsvo_frame_step_batch (alignment -> pose composition -> reprojection -> matching -> selection -> pose optimisation without
+    leaving the device) against the same steps called one ABI entry point at a time, and against the oracle's chain."""
+    seq = seqm.make_sequence(4, n_frames=6, W=320, H=240, n_pts=100, n_seg=24)
+    ro = seqm.run_sequence(OracleBackend(ob), seq)
+    rc = seqm.run_sequence(seqm.HipBackend(gpu_ctx), seq)
+    rd = seqm.run_sequence(seqm.HipChainBackend(gpu_ctx), seq)
+    for k, (a, b, o) in enumerate(zip(rd, rc, ro)):
+        ang, dist = P.synth.se3_log_angle_dist(a["T"], b["T"])
+        assert ang < 1e-11 and dist < 1e-11, (k, ang, dist)      # same kernels, same inputs: only the bearing normalisation is done elsewhere
+        assert (a["n_matched_pt"], a["n_matched_seg"], a.get("n_kept_pt"), a.get("n_kept_seg")) == \
+               (b["n_matched_pt"], b["n_matched_seg"], b.get("n_kept_pt"), b.get("n_kept_seg")), k
+        assert Hh.pose_close(a["T"], o["T"])[2], k
+    # mapping mode (seeds not yet in the map are left out through the `active` mask)
+    seq2 = seqm.make_sequence(6, n_frames=12, W=320, H=240, n_pts=100, n_seg=20, step_scale=1.0)
+    rc2 = seqm.run_sequence(seqm.HipBackend(gpu_ctx), seq2, mapping=True)
+    rd2 = seqm.run_sequence(seqm.HipChainBackend(gpu_ctx), seq2, mapping=True)
+    for k, (a, b) in enumerate(zip(rd2, rc2)):
+        ang, dist = P.synth.se3_log_angle_dist(a["T"], b["T"])
+        assert ang < 1e-9 and dist < 1e-9 and a.get("n_known") == b.get("n_known"), (k, ang, dist)
+
+
+@pytest.mark.gpu
+def test_resident_chain_applies_the_reprojection_grid_rule(P, ob, gpu_ctx, seqm):
+    """cell_rule = 1: per grid cell the first candidate (caller's order) that matched becomes the feature, cells visited in the caller's
+    order, stop after the match that makes the count exceed max_fts (src/reprojector.cpp:188-199, :222-243) -- checked against a NumPy
+    statement of the rule applied to the device's own match results, for a batch of two streams."""
+    abi, synth = P.abi, P.synth
+    seqs = [seqm.make_sequence(8 + s, n_frames=2, W=320, H=240, n_pts=150, n_seg=10) for s in range(2)]
+    cam = seqs[0]["cam"]
+    gpu_ctx.config_pyramids(4, 320, 240, 4)
+    jobs = []
+    for s, seq in enumerate(seqs):
+        gpu_ctx.build_pyramid(2 * s, seq["images"][0], 0)
+        gpu_ctx.build_pyramid(2 * s + 1, seq["images"][1], 0)
+        T0 = seq["poses_true"][0]
+        ref_pos = synth.se3_inv(T0)[4:]
+        scaled = lambda px, pos: seqm._bearing(cam, px) * np.linalg.norm(pos - ref_pos, axis=1)[:, None]
+        aj = abi.AlignJob(cam, 3, 1, 30, 1e-6, [0, 0, 0, 1, 0, 0, 0], seq["pt_px0"], scaled(seq["pt_px0"], seq["pt_pos"]), seq["seg_spx0"], seq["seg_epx0"],
+                          np.linalg.norm(seq["seg_epx0"] - seq["seg_spx0"], axis=1), scaled(seq["seg_spx0"], seq["seg_spos"]),
+                          scaled(seq["seg_epx0"], seq["seg_epos"]), ref_slot=2 * s, cur_slot=2 * s + 1)
+        n_pts, n_seg = len(seq["pt_pos"]), len(seq["seg_spos"])
+        pos_all = np.concatenate([seq["pt_pos"], seq["seg_spos"], seq["seg_epos"]])
+        jobs.append(abi.ChainJob(aj, T0, T0, 2 * s, n_pts, n_seg, pos_all, np.concatenate([seq["pt_px0"], seq["seg_spx0"], seq["seg_epx0"]]),
+                                 np.concatenate([seq["pt_f0"], seq["seg_sf0"], seq["seg_ef0"]])))
+    cell_size, max_fts = 40, 25
+    n_cols, n_rows = -(-320 // cell_size), -(-240 // cell_size)
+    order = np.random.default_rng(5).permutation(n_cols * n_rows).astype(np.int32)
+    res = gpu_ctx.frame_step_batch(jobs, cam, n_pyr_levels=3, cell_size=cell_size, cell_rule=True, max_fts=max_fts, cell_order=order)
+    free = gpu_ctx.frame_step_batch(jobs, cam, n_pyr_levels=3, cell_size=cell_size, cell_rule=False)
+    for s, (r, f, seq, cj) in enumerate(zip(res, free, seqs, jobs)):
+        n_pts = cj.n_cand_pt
+        assert np.array_equal(r.found, f.found) and np.array_equal(r.px, f.px)        # the rule selects, it does not change the matching
+        assert np.array_equal(f.sel_pt, np.nonzero(f.found[:n_pts])[0])               # no rule: every matched point, in candidate order
+        # projection of the candidates with the pose the alignment produced (what filed them in their cells)
+        T_k = synth.se3_mul(r.align.T, seq["poses_true"][0])
+        R, t = synth.quat_to_R(T_k[:4]), T_k[4:]
+        pc = seq["pt_pos"] @ R.T + t
+        px = np.stack([cam[0] * pc[:, 0] / pc[:, 2] + cam[2], cam[1] * pc[:, 1] / pc[:, 2] + cam[3]], axis=1)
+        ix, iy = px[:, 0].astype(int), px[:, 1].astype(int)
+        inframe = (ix >= 8) & (ix < 320 - 8) & (iy >= 8) & (iy < 240 - 8)
+        cell = (px[:, 1] / cell_size).astype(int) * n_cols + (px[:, 0] / cell_size).astype(int)
+        expect = []
+        for c in order:
+            cand = [k for k in range(n_pts) if inframe[k] and cell[k] == c and r.found[k]]
+            if cand:
+                expect.append(cand[0])
+            if len(expect) > max_fts:
+                break
+        assert list(r.sel_pt) == expect, (s, list(r.sel_pt)[:10], expect[:10])
+        assert len(expect) == max_fts + 1                                              # the scene is dense enough to hit the limit
+        assert r.pose.pt_keep.shape[0] == len(expect) and Hh.pose_close(r.pose.T, f.pose.T, rot_tol=2e-3, trans_tol=2e-2)[2]
