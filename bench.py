@@ -237,12 +237,12 @@ def host_fed_leg(P, torch, dev, stream, streams, cfg, n_streams=1024, steps=12):
         for k in range(2):
             consumed[k].record(stream)
         upload(0)
-        for t in range(2):                                         # warm-up
+        for t in range(3):                                         # warm-up
             upload((t + 1) & 1)
             step(t)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for t in range(2, 2 + steps):                              # `steps` even: the last step is a forward (A -> B) one
+        for t in range(3, 3 + steps):                              # `steps` even: the last step (t = steps + 2) is a forward (A -> B) one
             upload((t + 1) & 1)
             step(t)
         torch.cuda.synchronize(dev)

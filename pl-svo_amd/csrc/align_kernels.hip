@@ -42,18 +42,33 @@
 namespace plsvo_hip {
 
 // ------------------------------------------------------------------------------------------------
-// image gather from the TILED mirror of a pyramid level (plsvo_dev.hpp: 16 x 8 pixel tiles of 128 B): pixels [x, x+7) of row y as
-// floats, via aligned dword reads + v_alignbyte.  An aligned dword never straddles a tile row (16 B), so the over-read stays
-// inside the level.
+// image gather: pixels [x, x+7) of row y of a u8 pyramid level as floats, via aligned dword reads + v_alignbyte.
+//   TILED   the tiled mirror (plsvo_dev.hpp: 16 x 8 pixel tiles of 128 B, `pitch` = tiles per row): what the throughput launch shapes
+//           read -- they run within a few per cent of the achievable HBM rate and a window touches 1.9 lines instead of 5 (-7 % launch
+//           time at 32768 frames).  An aligned dword never straddles a tile row, so the over-read stays inside the level.
+//   !TILED  the row-major slab (`pitch` = level width; the allocation is padded for the over-read): what a frame that has a CU to
+//           itself reads -- it is bound by latency and issue, and there the tile arithmetic and the three separate dword requests
+//           per row (instead of one 12-byte request) cost 12 % of a pass and 25-45 % of a level's set-up.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_row7(const uint8_t* img, int tiles_x, int x, int y, float* o7) {
-  const int a = x & ~3, sh = x & 3;
-  const uint8_t* row = img + tiled_row_offset(tiles_x, y);
-  const uint32_t d0 = *reinterpret_cast<const uint32_t*>(row + tiled_col_offset(a));
-  const uint32_t d1 = *reinterpret_cast<const uint32_t*>(row + tiled_col_offset(a + 4));
-  const uint32_t d2 = *reinterpret_cast<const uint32_t*>(row + tiled_col_offset(a + 8));
-  const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);  // bytes off..off+3
-  const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);  // bytes off+4..off+7
+template <bool TILED>
+__device__ __forceinline__ void load_row7(const uint8_t* img, int pitch, int x, int y, float* o7) {
+  uint32_t d0, d1, d2, sh;
+  if constexpr (TILED) {
+    const int a = x & ~3;
+    sh = (uint32_t)(x & 3);
+    const int row = tiled_row_offset(pitch, y);
+    d0 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a)));
+    d1 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a + 4)));
+    d2 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a + 8)));
+  } else {
+    const int off = y * pitch + x, a = off & ~3;
+    sh = (uint32_t)(off & 3);
+    d0 = *reinterpret_cast<const uint32_t*>(img + a);
+    d1 = *reinterpret_cast<const uint32_t*>(img + a + 4);
+    d2 = *reinterpret_cast<const uint32_t*>(img + a + 8);
+  }
+  const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);  // bytes x..x+3
+  const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);  // bytes x+4..x+7
   o7[0] = (float)(w0 & 0xffu); o7[1] = (float)((w0 >> 8) & 0xffu);
   o7[2] = (float)((w0 >> 16) & 0xffu); o7[3] = (float)(w0 >> 24);
   o7[4] = (float)(w1 & 0xffu); o7[5] = (float)((w1 >> 8) & 0xffu);
@@ -171,6 +186,29 @@ typedef float plsvo_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float chain4(float s, plsvo_v4f v) {   // four sequential float additions, never re-associated
   s = __fadd_rn(s, v.x); s = __fadd_rn(s, v.y); s = __fadd_rn(s, v.z); return __fadd_rn(s, v.w);
 }
+// Sequential float sum over `slots4` slots (a multiple of 4; 16 floats each, slots beyond the last point hold +0) starting at w: four
+// register sets, each reloaded with the slot four ahead as soon as it has been added, so that a slot's LDS reads have 48 dependent
+// additions to complete under and nothing is copied between registers.  (The first version rotated two sets through v_mov and
+// waited for every read right after issuing it: 260 cycles per slot, 21 us per near tie for a frame alone on a CU.)
+__device__ __forceinline__ float chain_slots4(float sum, const PLSVO_LDS plsvo_v4f* w, int slots4) {
+  plsvo_v4f r[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[u][q] = w[4 * u + q];
+  const int last = slots4 - 4;
+  for (int g = 0; g < slots4; g += 4) {
+    const PLSVO_LDS plsvo_v4f* nx = w + 4 * (g + 4 <= last ? g + 4 : last);   // the last group is read twice rather than branching
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      sum = chain4(sum, r[u][0]); sum = chain4(sum, r[u][1]); sum = chain4(sum, r[u][2]); sum = chain4(sum, r[u][3]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[u][q] = nx[4 * u + q];
+    }
+  }
+  return sum;
+}
+
 __device__ __noinline__ void exact_chi2_pair(const PLSVO_GLOBAL float* bufA, const PLSVO_GLOBAL float* bufB, int n_pts, int n_seg, int iter,
                                              const PLSVO_LDS int* s_dead, PLSVO_LDS float* s_win, const PLSVO_LDS float* s_lterm, int scap,
                                              PLSVO_LDS float* s_out) {
@@ -197,17 +235,8 @@ __device__ __noinline__ void exact_chi2_pair(const PLSVO_GLOBAL float* bufA, con
     PLSVO_LDS plsvo_v4f* const w4 = reinterpret_cast<PLSVO_LDS plsvo_v4f*>(s_win);
     w4[lane] = c0; w4[lane + 64] = c1; w4[128 + lane] = c2; w4[128 + lane + 64] = c3;
     wave_lds_fence();
-    const int cnt = min(32, n_pts - 32 * r);
-    if (lane < 2) {
-      const PLSVO_LDS plsvo_v4f* w = w4 + 128 * lane;
-      plsvo_v4f a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3];
-      for (int n = 0; n < cnt; ++n) {
-        plsvo_v4f b0 = z4, b1 = z4, b2 = z4, b3 = z4;
-        if (n + 1 < cnt) { b0 = w[4 * n + 4]; b1 = w[4 * n + 5]; b2 = w[4 * n + 6]; b3 = w[4 * n + 7]; }
-        sum = chain4(sum, a0); sum = chain4(sum, a1); sum = chain4(sum, a2); sum = chain4(sum, a3);
-        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-      }
-    }
+    const int cnt4 = (min(32, n_pts - 32 * r) + 3) & ~3;   // the window holds +0 beyond the last point
+    if (lane < 2) sum = chain_slots4(sum, w4 + 128 * lane, cnt4);
   }
   if (lane < 2) {
     float seg_sum = 0.0f;                                                // :683, segments in feature order
@@ -227,17 +256,9 @@ __device__ __noinline__ void exact_chi2_pair_lds(const PLSVO_LDS float* planeA, 
                                                  const PLSVO_LDS int* s_dead, const PLSVO_LDS float* s_lterm, int scap, PLSVO_LDS float* s_out) {
   const int lane = threadIdx.x & 63;
   if (lane < 2) {
-    const plsvo_v4f z4 = { 0.f, 0.f, 0.f, 0.f };
     const PLSVO_LDS plsvo_v4f* w = reinterpret_cast<const PLSVO_LDS plsvo_v4f*>(lane ? planeB : planeA);
     float sum = 0.0f;
-    plsvo_v4f a0 = z4, a1 = z4, a2 = z4, a3 = z4;
-    if (n_pts > 0) { a0 = w[0]; a1 = w[1]; a2 = w[2]; a3 = w[3]; }
-    for (int n = 0; n < n_pts; ++n) {
-      plsvo_v4f b0 = z4, b1 = z4, b2 = z4, b3 = z4;
-      if (n + 1 < n_pts) { b0 = w[4 * n + 4]; b1 = w[4 * n + 5]; b2 = w[4 * n + 6]; b3 = w[4 * n + 7]; }
-      sum = chain4(sum, a0); sum = chain4(sum, a1); sum = chain4(sum, a2); sum = chain4(sum, a3);
-      a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-    }
+    if (n_pts > 0) sum = chain_slots4(sum, w, (n_pts + 3) & ~3);   // the planes hold +0 between the last point and the next multiple of 4
     float seg_sum = 0.0f;
     for (int sg = 0; sg < n_seg; ++sg) {
       const int dead = s_dead[sg];
@@ -307,6 +328,10 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     for (int k = 0; k < 32; ++k) s_tot[k] = 0.0;
     s_ctl[1] = st->stop; s_ctl[3] = 0; s_ctl[6] = 0;
   }
+  if (b.chi_lds_pts > 0) {   // LDS planes: the slots between the last point and the next multiple of 4 are read by the exact sums: +0
+    const int tail0 = job.n_pts * 16, tail1 = ((job.n_pts + 3) & ~3) * 16;
+    for (int k = tail0 + tid; k < tail1; k += T) { s_win[k] = 0.0f; s_win[b.chi_lds_pts * 16 + k] = 0.0f; }
+  }
   const size_t pbase = (size_t)job.patch_off;
   const int nfeat = job.n_pts + job.n_seg;
   double* const pxyz = b.patch_xyz + 3 * pbase;      // 3-D point of every slot (ref frame)
@@ -315,10 +340,14 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     // (level geometry is recomputed instead of indexing the kernel-argument arrays with a run-time level,
     //  which would force the whole argument struct into scratch memory)
     const int W = job.width >> level, Hh = job.height >> level;
-    const unsigned int lvl_off = pyr_tiled_level_offset(job.width, job.height, level);   // the alignment reads the tiled mirror
-    const uint8_t* ref_img = b.pyr.tbase + (size_t)job.ref_slot * b.pyr.tslot_bytes + lvl_off;
-    const uint8_t* cur_img = b.pyr.tbase + (size_t)job.cur_slot * b.pyr.tslot_bytes + lvl_off;
-    const int tiles_x = (W + 15) >> 4;
+    // throughput shapes read the tiled mirror of the pyramids, latency shapes the row-major slab (load_row7)
+    constexpr bool kTiled = T <= 128;
+    const unsigned int lvl_off = kTiled ? pyr_tiled_level_offset(job.width, job.height, level) : pyr_level_offset(job.width, job.height, level);
+    const uint8_t* const pyr_base = kTiled ? b.pyr.tbase : b.pyr.base;
+    const unsigned long long pyr_slot = kTiled ? b.pyr.tslot_bytes : b.pyr.slot_bytes;
+    const uint8_t* ref_img = pyr_base + (size_t)job.ref_slot * pyr_slot + lvl_off;
+    const uint8_t* cur_img = pyr_base + (size_t)job.cur_slot * pyr_slot + lvl_off;
+    const int pitch = kTiled ? (W + 15) >> 4 : W;   // tiles per row / bytes per row
     int n_slots = 0; bool long_lines = false;
 #pragma unroll
     for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) if (l == level) { n_slots = job.n_slots[l]; long_lines = ((job.long_mask >> l) & 1) != 0; }
@@ -398,7 +427,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         const int c0 = pw.ui - 2 - 1;
         float I[4][7];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) load_row7(ref_img, tiles_x, c0, r0 + rr, I[rr]);
+        for (int rr = 0; rr < 4; ++rr) load_row7<kTiled>(ref_img, pitch, c0, r0 + rr, I[rr]);
         float4 vr, vx, vy;
         float* pr = reinterpret_cast<float*>(&vr); float* pxp = reinterpret_cast<float*>(&vx); float* pyp = reinterpret_cast<float*>(&vy);
 #pragma unroll
@@ -454,7 +483,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         // depth 2: round r+1 is also projected and its image window requested before r's arithmetic (measured: 11 spilled
         //   VGPRs, no gain over depth 1); depth 0: no pipelining.
         struct SlotA { int2 meta; bool cand; double X, Y, Z; };
-        struct SlotB { bool live; float u, v; int sh; uint32_t r0a, r0b, r1a, r1b, r2a, r2b; };
+        struct SlotB { bool live; float u, v; int sh0, sh1, sh2; uint32_t r0a, r0b, r1a, r1b, r2a, r2b; };
         struct SlotC { float4 vr0, vx0, vy0, vr1, vx1, vy1; };
         auto stage_a = [&](int pb_) -> SlotA {
           SlotA f;
@@ -477,19 +506,26 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           g.u = half ? w_other : w_mine; g.v = half ? w_mine : w_other;
           // Patch::isInFrame(halfsize=2) on floorf(u), floorf(v); NaN -> out of frame
           g.live = sa.cand && (g.u >= 2.0f) && (g.v >= 2.0f) && (g.u < colmax) && (g.v < rowmax);
-          g.sh = 0; g.r0a = g.r0b = g.r1a = g.r1b = g.r2a = g.r2b = 0u;
+          g.sh0 = g.sh1 = g.sh2 = 0; g.r0a = g.r0b = g.r1a = g.r1b = g.r2a = g.r2b = 0u;
           if (g.live) {
-            // rows y0 .. y0+2 of the window, columns x0 .. x0+4: two aligned dwords per row from the tiled level
+            // rows y0 .. y0+2 of the window, columns x0 .. x0+4: two aligned dwords per row (32-bit offsets from the wave-uniform level base)
             const int ui = (int)floorf(g.u), vi = (int)floorf(g.v);
             const int x0 = ui - 2, y0 = vi - 2 + 2 * half;
-            g.sh = x0 & 3;
-            const int ca = tiled_col_offset(x0 & ~3), cb = tiled_col_offset((x0 & ~3) + 4);
-            const uint8_t* q0 = cur_img + tiled_row_offset(tiles_x, y0);
-            const uint8_t* q1 = cur_img + tiled_row_offset(tiles_x, y0 + 1);
-            const uint8_t* q2 = cur_img + tiled_row_offset(tiles_x, y0 + 2);
-            g.r0a = *reinterpret_cast<const uint32_t*>(q0 + ca); g.r0b = *reinterpret_cast<const uint32_t*>(q0 + cb);
-            g.r1a = *reinterpret_cast<const uint32_t*>(q1 + ca); g.r1b = *reinterpret_cast<const uint32_t*>(q1 + cb);
-            g.r2a = *reinterpret_cast<const uint32_t*>(q2 + ca); g.r2b = *reinterpret_cast<const uint32_t*>(q2 + cb);
+            int a0, a1, a2, b0, b1, b2;
+            if constexpr (kTiled) {
+              g.sh0 = g.sh1 = g.sh2 = x0 & 3;
+              const int ca = tiled_col_offset(x0 & ~3), cb = tiled_col_offset((x0 & ~3) + 4);
+              const int q0 = tiled_row_offset(pitch, y0), q1 = tiled_row_offset(pitch, y0 + 1), q2 = tiled_row_offset(pitch, y0 + 2);
+              a0 = q0 + ca; b0 = q0 + cb; a1 = q1 + ca; b1 = q1 + cb; a2 = q2 + ca; b2 = q2 + cb;
+            } else {
+              const int off = y0 * pitch + x0;
+              g.sh0 = off & 3; g.sh1 = (off + pitch) & 3; g.sh2 = (off + 2 * pitch) & 3;
+              a0 = off & ~3; a1 = (off + pitch) & ~3; a2 = (off + 2 * pitch) & ~3;
+              b0 = a0 + 4; b1 = a1 + 4; b2 = a2 + 4;
+            }
+            g.r0a = *reinterpret_cast<const uint32_t*>(cur_img + a0); g.r0b = *reinterpret_cast<const uint32_t*>(cur_img + b0);
+            g.r1a = *reinterpret_cast<const uint32_t*>(cur_img + a1); g.r1b = *reinterpret_cast<const uint32_t*>(cur_img + b1);
+            g.r2a = *reinterpret_cast<const uint32_t*>(cur_img + a2); g.r2b = *reinterpret_cast<const uint32_t*>(cur_img + b2);
           }
           return g;
         };
@@ -548,7 +584,6 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           float4 chi_t0 = make_float4(0.f, 0.f, 0.f, 0.f), chi_t1 = chi_t0;   // a patch outside the current image contributes nothing (:432-433): +0
           if (live) {
             const PatchW pw = patch_weights(u, v);
-            const int sh = sb.sh;
             const uint32_t r0a = sb.r0a, r0b = sb.r0b, r1a = sb.r1a, r1b = sb.r1b, r2a = sb.r2a, r2b = sb.r2b;
             auto unpack5 = [](uint32_t lo, uint32_t hi, int sh, float* o) {
               const uint32_t w0 = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh);
@@ -556,9 +591,9 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
               o[4] = (float)((hi >> (8 * sh)) & 0xffu);
             };
             float r0[5], r1[5], r2[5];
-            unpack5(r0a, r0b, sh, r0);
-            unpack5(r1a, r1b, sh, r1);
-            unpack5(r2a, r2b, sh, r2);
+            unpack5(r0a, r0b, sb.sh0, r0);
+            unpack5(r1a, r1b, sb.sh1, r1);
+            unpack5(r2a, r2b, sb.sh2, r2);
             const bool is_point = !is_line;
             // WEIGHTED is decided per wave: the slot table lists points first, then line samples, so most rounds are
             // homogeneous and the line-only ones skip the robust weight (11 instructions per pixel) and the chi2 term.
@@ -619,6 +654,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           // have been issued: the compiler cannot prove that these stores do not alias the cache arrays, and a store inside the
           // pixel arithmetic pins every later load behind it (measured +31 % launch time there, and the launch is within a few
           // per cent of the achievable HBM rate: every byte written costs its time, which is why line pixels are not stored).
+#ifndef PLSVO_CHI_NOSTORE   // (experiment switch: cost of keeping the terms)
           if (accumulate && p < job.n_pts) {
             if (b.chi_lds_pts > 0) {   // small batches: the planes are in LDS (kernel-uniform)
               float4* const chi_dst = reinterpret_cast<float4*>(s_win + (iter & 1) * b.chi_lds_pts * 16 + p * 16 + 8 * half);
@@ -628,6 +664,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
               PLSVO_CHI_STORE(chi_dst, chi_t0); PLSVO_CHI_STORE(chi_dst + 1, chi_t1);
             }
           }
+#endif
 
           // -- weights: points 1; a line's samples share w / mean|res| (H) and w (Jres), :640-688
           double wh = 0.0, wj = 0.0;

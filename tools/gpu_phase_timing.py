@@ -10,6 +10,8 @@ B = int(os.environ.get("TIMING_BATCH", "256"))
 ctx = P.capi.Context(0)
 streams = [P.synth.make_align_stream(1234 + i, 640, 480, 200, 80, max_level=3) for i in range(B)]
 imgs = P.synth.render_streams(streams, device="cuda")
+import torch
+torch.cuda.synchronize()   # the library enqueues on its own stream
 ctx.config_pyramids(2 * B, 640, 480, 4)
 ctx.build_pyramids_dev(0, 2 * B, imgs.data_ptr(), 640, 640 * 480, 0)
 ctx.synchronize()
@@ -17,8 +19,7 @@ names = ["setup+precompute", "fused pass", "reduce", "rows finish", "solve6", "u
 L = ctx.L
 L.plsvo_align_phase_ticks.restype = C.c_int
 L.plsvo_align_phase_ticks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-for threads in os.environ.get("TIMING_THREADS", "256,512,1024").split(","):
-    os.environ["PLSVO_ALIGN_THREADS"] = threads
+for threads in [os.environ.get("PLSVO_ALIGN_THREADS", "default")]:   # (the library reads the override once, at context creation)
     for level in (3, 2, 1):
         jobs = [P.align_job_from_stream(s, level, level, ref_slot=2 * i, cur_slot=2 * i + 1) for i, s in enumerate(streams)]
         ctx.align_stage(jobs)
