@@ -529,11 +529,11 @@ def main():
                                        "note": f"{local_shards} shards of {B} streams run back to back on this GPU; with one shard per GPU the step "
                                                "time of the job is the slowest shard's (plus the pose all-gather): that run is the driver's --gpus 8"}
             if not pose_only and hasattr(ctx.L, "plsvo_align_chi2_ties"):
-                gn_it = gn_ties = 0
+                gn_it = gn_ties = gn_un = 0
                 for sh in shard:
-                    a_, b_ = sh["ctx"].align_chi2_ties()
-                    gn_it += a_; gn_ties += b_
-                result["chi2_ties"] = {"gn_iterations_per_step": int(gn_it), "decided_on_exact_float_sums": int(gn_ties),
+                    a_, b_, c_ = sh["ctx"].align_chi2_ties()
+                    gn_it += a_; gn_ties += b_; gn_un += c_
+                result["chi2_ties"] = {"gn_iterations_per_step": int(gn_it), "decided_on_exact_float_sums": int(gn_ties), "near_ties_without_terms": int(gn_un),
                                        "what": "iterations whose `new_chi2 > chi2_` decision was taken on the reference's sequential float sums "
                                                "(the two values closer than the sums' own rounding noise)"}
             if not pose_only:

@@ -203,13 +203,15 @@ int plsvo_align_copy_poses(plsvo_ctx* ctx, double* d_dst);
  *   patch_levels = sum over jobs and levels of patches precomputed (497 B each)
  *   patch_iters  = sum over jobs, levels and GN iterations of patches evaluated (485 B each) */
 int plsvo_align_work(plsvo_ctx* ctx, uint64_t* patch_levels, uint64_t* patch_iters);
-/* of patch_iters, the evaluations of POINT patches (those also write 64 B of per-pixel chi2 terms, see plsvo_align_chi2_ties) */
+/* of patch_iters, the evaluations of POINT patches that also wrote their 64 B of per-pixel chi2 terms to HBM (see plsvo_align_chi2_ties) */
 int plsvo_align_work_points(plsvo_ctx* ctx, uint64_t* point_patch_iters);
 
 /* parity accounting of the last plsvo_align_run: Gauss-Newton iterations in total, and how many of them had their
  * `new_chi2 > chi2_` decision ([ext] vk::NLLSSolver::optimizeGaussNewton) taken on the reference's own sequential float sums
- * (src/sparse_img_align.cpp:484, 683, 171, 192) because the two chi2 values were closer than the rounding noise of those sums */
-int plsvo_align_chi2_ties(plsvo_ctx* ctx, uint64_t* iterations, uint64_t* ties);
+ * (src/sparse_img_align.cpp:484, 683, 171, 192) because the two chi2 values were closer than the rounding noise of those sums;
+ * near_ties_without_terms: such iterations whose per-pixel terms had not been kept (large batches keep them only once the solver's
+ * steps are small) -- decided on the exactly-rounded sums instead.  Any output may be NULL. */
+int plsvo_align_chi2_ties(plsvo_ctx* ctx, uint64_t* iterations, uint64_t* ties, uint64_t* near_ties_without_terms);
 
 /* ------------------------------------------------------------------------------------------ */
 /* pose optimisation                                                                           */

@@ -75,7 +75,7 @@ def lib():
         "plsvo_align_copy_poses": (C.c_int, [ctxp, vp]),
         "plsvo_poseopt_copy_poses": (C.c_int, [ctxp, vp]),
         "plsvo_align_work": (C.c_int, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-        "plsvo_align_chi2_ties": (C.c_int, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "plsvo_align_chi2_ties": (C.c_int, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "plsvo_align_work_points": (C.c_int, [ctxp, C.POINTER(C.c_uint64)]),
         "plsvo_pose_optimize": (C.c_int, [ctxp, C.POINTER(abi.PoseOptIn), C.POINTER(abi.PoseOptOut)]),
         "plsvo_pose_optimize_batch": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.PoseOptIn), C.POINTER(abi.PoseOptOut)]),
@@ -262,11 +262,12 @@ class Context:
         return a.value
 
     def align_chi2_ties(self):
-        """(Gauss-Newton iterations, iterations decided on the exact float chi2 sums) of the last align_run"""
+        """(Gauss-Newton iterations, iterations decided on the exact float chi2 sums, near ties whose terms had not been kept) of the last align_run"""
         a = C.c_uint64(0)
         b = C.c_uint64(0)
-        self._chk(self.L.plsvo_align_chi2_ties(self.h, C.byref(a), C.byref(b)))
-        return a.value, b.value
+        c = C.c_uint64(0)
+        self._chk(self.L.plsvo_align_chi2_ties(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def align_poses_dev(self):
         return self.L.plsvo_align_poses_dev(self.h)

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       st->chi2 = 1e10; st->n_meas = 0; st->stop = 0; st->log_count = 0; st->error = 0;
       for (int k = 0; k < 36; ++k) st->H[k] = 0.0;
       for (int k = 0; k < PLSVO_MAX_LEVELS; ++k) st->iters[k] = 0;
-      st->patch_levels = 0; st->patch_iters = 0; st->patch_iters_pt = 0; st->chi2_ties = 0;
+      st->patch_levels = 0; st->patch_iters = 0; st->patch_iters_pt = 0; st->chi2_ties = 0; st->chi2_unarmed = 0;
       for (int k = 0; k < 8; ++k) st->phase_ticks[k] = 0;
       if (nothing && b.poses) for (int k = 0; k < 7; ++k) b.poses[7 * job_id + k] = b.T0[7 * job_id + k];
     }
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     for (int k = 0; k < 7; ++k) { s_pose[12 + k] = st->T[k]; s_pose[19 + k] = st->T[k]; }
     s_pose[26] = st->chi2; s_pose[28] = 0.0; s_pose[29] = 0.0; s_pose[31] = 0.0;
     for (int k = 0; k < 32; ++k) s_tot[k] = 0.0;
-    s_ctl[1] = st->stop; s_ctl[3] = 0; s_ctl[6] = 0;
+    s_ctl[1] = st->stop; s_ctl[3] = 0; s_ctl[6] = 0; s_ctl[9] = 0;
   }
   if (b.chi_lds_pts > 0) {   // LDS planes: the slots between the last point and the next multiple of 4 are read by the exact sums: +0
     const int tail0 = job.n_pts * 16, tail1 = ((job.n_pts + 3) & ~3) * 16;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     }
     block_sync<T>();  // previous level done with every LDS table
 
-    if (tid == 0) { s_ctl[0] = 0; s_ctl[2] = 0; s_ctl[5] = 0; s_pose[27] = 0.0; }
+    if (tid == 0) { s_ctl[0] = 0; s_ctl[2] = 0; s_ctl[5] = 0; s_ctl[7] = 0; s_ctl[8] = 0; s_pose[27] = 0.0; }
     for (int p = tid; p < n_slots; p += T) s_meta[p] = make_int2(SLOT_HOLE, 0);
     block_sync<T>();
 
@@ -463,9 +463,13 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       const double Ra = s_pose[3 * half], Rb = s_pose[3 * half + 1], Rc = s_pose[3 * half + 2], ta = s_pose[9 + half];
       const double Rz0 = s_pose[6], Rz1 = s_pose[7], Rz2 = s_pose[8], tz = s_pose[11];
 
+      // HBM planes are written only while the solver is ARMED: the step that led to this iteration was small (||x||_inf < 1e-3), which is
+      // when two successive chi2 values can come within the rounding noise of the reference's sums (99 % of the near ties of 60
+      // config-2 frames had both iterations armed; 64 % of all iterations are).  LDS planes (small batches) are always written.
+      const bool store_chi = b.chi_lds_pts > 0 || s_ctl[7] != 0;
       float* const chi_it = b.chi_terms + (size_t)(iter & 1) * b.chi_plane + (size_t)job.pt_off * 16;   // this iteration's plane of the points' chi2 terms
 
-      double acc[32];   // 0..20 H (upper, row-major), 21..26 Jres, 27 chi2, 28 n_meas, 29 evals, 30 evals of point patches, 31 unused
+      double acc[32];   // 0..20 H (upper, row-major), 21..26 Jres, 27 chi2, 28 n_meas, 29 evals, 30 evals of point patches whose chi2 terms went to HBM, 31 unused
 #pragma unroll
       for (int k = 0; k < 32; ++k) acc[k] = 0.0;
 
@@ -655,7 +659,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           // pixel arithmetic pins every later load behind it (measured +31 % launch time there, and the launch is within a few
           // per cent of the achievable HBM rate: every byte written costs its time, which is why line pixels are not stored).
 #ifndef PLSVO_CHI_NOSTORE   // (experiment switch: cost of keeping the terms)
-          if (accumulate && p < job.n_pts) {
+          if (accumulate && store_chi && p < job.n_pts) {
             if (b.chi_lds_pts > 0) {   // small batches: the planes are in LDS (kernel-uniform)
               float4* const chi_dst = reinterpret_cast<float4*>(s_win + (iter & 1) * b.chi_lds_pts * 16 + p * 16 + 8 * half);
               chi_dst[0] = chi_t0; chi_dst[1] = chi_t1;
@@ -698,7 +702,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
               wh = 1.0; wj = 1.0;
               if (half == 0) { acc[27] += sChi; acc[28] += (double)PLSVO_PATCH_AREA; }
             }
-            if (live && half == 0) { acc[29] += 1.0; if (!is_line) acc[30] += 1.0; }
+            if (live && half == 0) { acc[29] += 1.0; if (!is_line && store_chi && b.chi_lds_pts == 0) acc[30] += 1.0; }
             // -- 6x6 expansion shared by the lane pair: lane 0 adds r0 (A r0 + B r1)^T and D r0, lane 1 adds r1 (B r0 + C r1)^T and E r1
             if (wh != 0.0 || wj != 0.0) {
               const double xyz[3] = { X, Y, Z };
@@ -750,7 +754,9 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         // the reference's sequential float sums sit within ~0.25 sqrt(n) 2^-24 (one sigma) of these: inside 2 sqrt(n) 2^-24
         // (> 5 sigma of the difference of two such sums) the order of the two values is taken from the exact float sums
         const float band = PLSVO_CHI_BAND * __fsqrt_rn((float)nm_d) * 5.9604644775390625e-8f;
-        const bool tie = iter > 0 && !s_ctl[1] && !isnan(x[0]) && fabs(new_chi2 - old_chi2) <= (double)band * old_chi2;
+        const bool near = iter > 0 && !s_ctl[1] && !isnan(x[0]) && fabs(new_chi2 - old_chi2) <= (double)band * old_chi2;
+        const bool have_terms = b.chi_lds_pts > 0 || (s_ctl[7] != 0 && s_ctl[8] != 0);   // both iterations' terms were kept
+        const bool tie = near && have_terms;
         if (tie) {   // wave-uniform
           if (b.chi_lds_pts > 0)
             exact_chi2_pair_lds((const PLSVO_LDS float*)(s_win + (iter & 1) * b.chi_lds_pts * 16), (const PLSVO_LDS float*)(s_win + ((iter & 1) ^ 1) * b.chi_lds_pts * 16),
@@ -769,6 +775,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           s_pose[30] = nm_d;                                                   // n_meas_ of this iteration, for the next one's tie
           s_ctl[2] += 1;
           if (tie) s_ctl[6] += 1;
+          if (near && !have_terms) s_ctl[9] += 1;   // decided on the rounded-once sums after all
           int stop = s_ctl[1];
           if (isnan(x[0])) stop = 1;                                           // :700
           SE3d model = se3_load(s_pose + 12);
@@ -786,6 +793,8 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
             accepted = 1;
             if (norm_max6(x) <= job.eps) brk = 1;
           }
+          s_ctl[8] = s_ctl[7];
+          s_ctl[7] = (accepted && norm_max6(x) < 1e-3) ? 1 : 0;                // armed for the next iteration
           se3_store(model, s_pose + 12);
           quat_to_matrix(model.q, s_pose); s_pose[9] = model.t[0]; s_pose[10] = model.t[1]; s_pose[11] = model.t[2];
           s_ctl[1] = stop; s_ctl[0] = brk;
@@ -832,6 +841,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     st->patch_iters_pt += (unsigned long long)(s_pose[31] + 0.5);
     st->stop = s_ctl[1];
     st->chi2_ties += s_ctl[6];
+    st->chi2_unarmed += s_ctl[9];
     st->n_meas = (unsigned long long)(s_tot[28] + 0.5);
     for (int i = 0; i < 6; ++i) for (int jj = 0; jj < 6; ++jj) st->H[i * 6 + jj] = s_tot[sym6_index(i, jj)];
 #ifdef PLSVO_TIMING

@@ -800,17 +800,18 @@ extern "C" int plsvo_align_work_points(plsvo_ctx* c, uint64_t* point_patch_iters
   return PLSVO_OK;
 }
 
-extern "C" int plsvo_align_chi2_ties(plsvo_ctx* c, uint64_t* iterations, uint64_t* ties) {
+extern "C" int plsvo_align_chi2_ties(plsvo_ctx* c, uint64_t* iterations, uint64_t* ties, uint64_t* near_ties_without_terms) {
   CTX_CHECK(c);
   if (!c->a_staged) return fail(c, PLSVO_E_STATE, "align_chi2_ties: no staged batch");
   HIP_TRY(c, hipSetDevice(c->device));
   std::vector<AlignStateDev> st((size_t)c->a_n);
   HIP_TRY(c, hipMemcpyAsync(st.data(), c->a_d_state.p, (size_t)c->a_n * sizeof(AlignStateDev), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  uint64_t it = 0, t = 0;
-  for (auto& s : st) { t += (uint64_t)s.chi2_ties; for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) it += (uint64_t)s.iters[l]; }
+  uint64_t it = 0, t = 0, un = 0;
+  for (auto& s : st) { t += (uint64_t)s.chi2_ties; un += (uint64_t)s.chi2_unarmed; for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) it += (uint64_t)s.iters[l]; }
   if (iterations) *iterations = it;
   if (ties) *ties = t;
+  if (near_ties_without_terms) *near_ties_without_terms = un;
   return PLSVO_OK;
 }
 

@@ -80,9 +80,11 @@ struct AlignStateDev {
   int log_count;
   int iters[PLSVO_MAX_LEVELS];
   unsigned long long patch_levels, patch_iters;  // work counters
-  unsigned long long patch_iters_pt;             // of patch_iters, those of point features (they also write 64 B of chi2 terms)
+  unsigned long long patch_iters_pt;             // of patch_iters, those of point features that wrote 64 B of chi2 terms to HBM
   int error;                   // device-side capacity/consistency error
   int chi2_ties;               // Gauss-Newton iterations whose accept / roll-back decision was taken on the exact float chi2 sums
+  int chi2_unarmed;            // near ties met while the per-pixel terms of one of the two iterations had not been kept
+  int reserved2;
   unsigned long long phase_ticks[8];  // only filled by -DPLSVO_TIMING builds (s_memtime ticks per phase)
 };
 
