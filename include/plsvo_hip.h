@@ -69,6 +69,10 @@ void plsvo_hip_destroy(plsvo_ctx* ctx);
  * 330 = Eigen 3.2.2 and later (Ubuntu 16.04's 3.3-beta: exact zeros only).  Identical arithmetic on every full-rank system; they
  * differ with fewer than three point observations.  Takes effect at the next *_stage call. */
 #define PLSVO_OPT_LDLT_FLAVOUR 1
+/* Launch shapes (threads per frame) of the two hot kernels: 0 = chosen from the batch size (default), or a fixed 64 / 128 / 256 / 512
+ * (alignment), 64 / 256 / 512 (pose optimiser).  For tests and measurements: every shape computes the same thing. */
+#define PLSVO_OPT_ALIGN_THREADS 2
+#define PLSVO_OPT_POSEOPT_THREADS 3
 int plsvo_hip_set_option(plsvo_ctx* ctx, int option, int value);
 const char* plsvo_hip_last_error(const plsvo_ctx* ctx);   /* ctx may be NULL: last create error */
 void* plsvo_hip_stream(plsvo_ctx* ctx);                   /* the hipStream_t all work is enqueued on */

@@ -136,6 +136,13 @@ class Context:
         """320 (Eigen 3.1 ... 3.2.1, default) or 330 (Eigen 3.2.2+): zero-pivot rule of the optimisers' 6x6 LDLT solve"""
         self._chk(self.L.plsvo_hip_set_option(self.h, 1, int(flavour)))
 
+    def set_launch_shapes(self, align_threads=None, poseopt_threads=None):
+        """fix the threads-per-frame of the alignment / pose-optimiser kernels (0 = automatic); for tests and measurements"""
+        if align_threads is not None:
+            self._chk(self.L.plsvo_hip_set_option(self.h, 2, int(align_threads)))
+        if poseopt_threads is not None:
+            self._chk(self.L.plsvo_hip_set_option(self.h, 3, int(poseopt_threads)))
+
     def close(self):
         if getattr(self, "h", None):
             self.L.plsvo_hip_destroy(self.h)

@@ -253,6 +253,16 @@ extern "C" int plsvo_hip_set_option(plsvo_ctx* c, int option, int value) {
     c->a_staged = false; c->p_staged = false;   // the rule travels with the staged jobs
     return PLSVO_OK;
   }
+  if (option == PLSVO_OPT_ALIGN_THREADS) {
+    if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512) return fail(c, PLSVO_E_INVALID, "set_option: alignment launch shape is 0 (automatic), 64, 128, 256 or 512 threads per frame");
+    c->env_align_threads = value;
+    return PLSVO_OK;
+  }
+  if (option == PLSVO_OPT_POSEOPT_THREADS) {
+    if (value != 0 && value != 64 && value != 256 && value != 512) return fail(c, PLSVO_E_INVALID, "set_option: pose-optimiser launch shape is 0 (automatic), 64, 256 or 512 threads per frame");
+    c->env_poseopt_threads = value;
+    return PLSVO_OK;
+  }
   return fail(c, PLSVO_E_INVALID, "set_option: unknown option");
 }
 

@@ -14,7 +14,7 @@ L.plsvo_poseopt_phase_ticks.restype = C.c_int
 L.plsvo_poseopt_phase_ticks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 names = ["init+scale pass", "scale medians", "GN loop", "cov+cull", "final medians"]
 for threads in os.environ.get("TIMING_THREADS", "64,256,512").split(","):
-    os.environ["PLSVO_POSEOPT_THREADS"] = threads
+    ctx.set_launch_shapes(poseopt_threads=int(threads))
     ctx.poseopt_run(); ctx.synchronize()
     ctx.set_profiling(True); ctx.reset_profiling()
     ctx.poseopt_run(); ctx.synchronize()

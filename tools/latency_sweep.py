@@ -53,10 +53,7 @@ def main():
         ctx.poseopt_stage(pjobs)
         ctx.synchronize()
         for T in [int(x) for x in args.threads.split(",")]:
-            if T:
-                os.environ["PLSVO_ALIGN_THREADS"] = str(T)
-            else:
-                os.environ.pop("PLSVO_ALIGN_THREADS", None)
+            ctx.set_launch_shapes(align_threads=T)
 
             def timed(fn, K):
                 for _ in range(3):
