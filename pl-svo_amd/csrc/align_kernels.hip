@@ -43,9 +43,9 @@ namespace plsvo_hip {
 
 // ------------------------------------------------------------------------------------------------
 // image gather: pixels [x, x+7) of row y of a u8 pyramid level as floats, via aligned dword reads + v_alignbyte.
-//   TILED   the tiled mirror (plsvo_dev.hpp: 16 x 8 pixel tiles of 128 B, `pitch` = tiles per row): what the throughput launch shapes
-//           read -- they run within a few per cent of the achievable HBM rate and a window touches 1.9 lines instead of 5 (-7 % launch
-//           time at 32768 frames).  An aligned dword never straddles a tile row, so the over-read stays inside the level.
+//   TILED   the tiled mirror (plsvo_dev.hpp: 16 x 8 pixel tiles of 128 B, `pitch` = tiles per row): what the one-wave-per-frame launch
+//           shape reads -- it runs within a few per cent of the achievable HBM rate and a window touches 1.9 lines instead of 5 (-7 %
+//           launch time at 32768 frames).  An aligned dword never straddles a tile row, so the over-read stays inside the level.
 //   !TILED  the row-major slab (`pitch` = level width; the allocation is padded for the over-read): what a frame that has a CU to
 //           itself reads -- it is bound by latency and issue, and there the tile arithmetic and the three separate dword requests
 //           per row (instead of one 12-byte request) cost 12 % of a pass and 25-45 % of a level's set-up.
@@ -136,6 +136,11 @@ __device__ __forceinline__ void block_sync() {
 #endif
 #ifndef PLSVO_CHI_EXP
 #define PLSVO_CHI_EXP 0
+#endif
+// launch shapes up to this many threads per frame read the tiled pyramid mirror, larger ones the row-major slab (load_row7).
+// Measured: 64 threads (32768 frames, the chip saturated) -7 % launch time tiled; 128 threads (8192 frames) +4 % tiled; 512 +12 % per pass.
+#ifndef PLSVO_TILED_MAX_T
+#define PLSVO_TILED_MAX_T 64
 #endif
 // half-width of the near-tie band, in units of sqrt(n_meas) * 2^-24 (one sigma of the reference's float sum is ~0.25 of that)
 #ifndef PLSVO_CHI_BAND
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     //  which would force the whole argument struct into scratch memory)
     const int W = job.width >> level, Hh = job.height >> level;
     // throughput shapes read the tiled mirror of the pyramids, latency shapes the row-major slab (load_row7)
-    constexpr bool kTiled = T <= 128;
+    constexpr bool kTiled = T <= PLSVO_TILED_MAX_T;
     const unsigned int lvl_off = kTiled ? pyr_tiled_level_offset(job.width, job.height, level) : pyr_level_offset(job.width, job.height, level);
     const uint8_t* const pyr_base = kTiled ? b.pyr.tbase : b.pyr.base;
     const unsigned long long pyr_slot = kTiled ? b.pyr.tslot_bytes : b.pyr.slot_bytes;
