@@ -561,12 +561,15 @@ def main():
                 done1, tc1, lat = ob.bench(align_jobs[:n_s], rp, cp, pose_jobs[:n_s], 1, half, what=what, latencies=True)
                 cores = host_cores()
                 doneN, tcN = ob.bench(align_jobs[:n_s], rp, cp, pose_jobs[:n_s], cores, half, what=what)
+                pinned = ob.bench_threads_pinned()
                 single_fps = done1 / tc1
                 result["cpu_baseline"] = {
                     "value": round(doneN / tcN, 2), "unit": "frames/s", "cores": cores, "kind": "port",
                     "sample": f"{doneN} frames on {cores} threads in {tcN:.1f} s (independent streams, round-robin over the first "
                               f"{n_s} streams of the timed batch), oracle/libplsvo_oracle.so, timed inside the library; the reference itself is "
-                              f"single-threaded on this path; threads not pinned (the container's CPU quota allows {cores})",
+                              f"single-threaded on this path; {pinned} of {cores} threads pinned one per allowed CPU; the host has "
+                              f"{os.cpu_count()} logical CPUs, the container's affinity mask / CPU quota allows {cores}",
+                    "host_logical_cpus": os.cpu_count(), "threads_pinned": pinned,
                     "scaling_over_one_thread": round((doneN / tcN) / single_fps, 2),
                     "single_thread_value": round(single_fps, 2),
                     "single_thread_sample": f"{done1} frames in {tc1:.1f} s on one thread",

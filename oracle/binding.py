@@ -239,6 +239,13 @@ def bench(align_jobs, ref_pyrs, cur_pyrs, pose_jobs, n_threads, seconds, what=3,
     return int(done), float(el.value)
 
 
+def bench_threads_pinned():
+    """threads of the last bench() call that were pinned to a CPU of the process's affinity mask"""
+    L = lib()
+    L.plsvo_oracle_bench_threads_pinned.restype = C.c_int
+    return int(L.plsvo_oracle_bench_threads_pinned())
+
+
 # --- small helpers for unit tests -------------------------------------------------------------
 
 def se3_exp(u):

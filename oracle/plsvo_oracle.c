@@ -1,3 +1,6 @@
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE   /* sched_getaffinity / pthread_setaffinity_np for the CPU-baseline harness at the end of this file */
+#endif
 /*
  * plsvo_oracle.c -- CPU restatement of PL-SVO's sparse image alignment + pose optimisation.
  * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see plsvo_oracle.h for what that means and why).
@@ -1664,7 +1667,11 @@ void plsvo_oracle_update_point_seed(float x, float tau2, float state[5]) {
 /* CPU-baseline harness: the two hot functions over independent streams on n_threads POSIX threads */
 /* (bench.py's cpu_baseline leg; the reference itself is single-threaded on this path)           */
 /* ============================================================================================ */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE   /* sched_getaffinity / pthread_setaffinity_np: the baseline's threads are pinned */
+#endif
 #include <pthread.h>
+#include <sched.h>
 #include <time.h>
 
 typedef struct {
@@ -1673,12 +1680,34 @@ typedef struct {
   double seconds; long long done;
   int what;                 /* bit 0: SparseImgAlign::run, bit 1: optimizeGaussNewton */
   double* lat_us; int lat_cap, n_lat;   /* per-frame wall times of this thread (first lat_cap frames), or NULL */
+  int pinned;
 } bench_arg_t;
+
+static int g_bench_threads_pinned = 0;   /* of the last plsvo_oracle_bench* call */
+int plsvo_oracle_bench_threads_pinned(void) { return g_bench_threads_pinned; }
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
+/* pin the calling thread to the (tid mod #allowed)-th CPU of the process's affinity mask; returns 1 when pinned */
+static int pin_to_allowed_cpu(int tid) {
+  cpu_set_t allowed;
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return 0;
+  const int n = CPU_COUNT(&allowed);
+  if (n <= 0) return 0;
+  int want = tid % n, seen = 0;
+  for (int c = 0; c < CPU_SETSIZE; ++c) {
+    if (!CPU_ISSET(c, &allowed)) continue;
+    if (seen++ == want) {
+      cpu_set_t one; CPU_ZERO(&one); CPU_SET(c, &one);
+      return pthread_setaffinity_np(pthread_self(), sizeof(one), &one) == 0;
+    }
+  }
+  return 0;
+}
+
 static void* bench_worker(void* p) {
   bench_arg_t* a = (bench_arg_t*)p;
+  a->pinned = pin_to_allowed_cpu(a->tid);
   uint8_t* alive = (uint8_t*)malloc((size_t)a->max_seg + 1);
   uint8_t* pk = (uint8_t*)malloc((size_t)a->max_pts + 1);
   uint8_t* sk = (uint8_t*)malloc((size_t)a->max_seg + 1);
@@ -1728,12 +1757,14 @@ long long plsvo_oracle_bench_mode(int n_streams, const plsvo_align_in* aj, const
   bench_arg_t* args = (bench_arg_t*)malloc(sizeof(bench_arg_t) * (size_t)n_threads);
   const double t0 = now_s();
   for (int t = 0; t < n_threads; ++t) {
-    bench_arg_t a = { t, n_threads, n_streams, max_seg, max_pts, aj, ref, cur, pj, seconds, 0, what, t == 0 ? lat_us : NULL, lat_cap, 0 };
+    bench_arg_t a = { t, n_threads, n_streams, max_seg, max_pts, aj, ref, cur, pj, seconds, 0, what, t == 0 ? lat_us : NULL, lat_cap, 0, 0 };
     args[t] = a;
     pthread_create(&th[t], NULL, bench_worker, &args[t]);
   }
   long long total = 0;
-  for (int t = 0; t < n_threads; ++t) { pthread_join(th[t], NULL); total += args[t].done; }
+  int pinned = 0;
+  for (int t = 0; t < n_threads; ++t) { pthread_join(th[t], NULL); total += args[t].done; pinned += args[t].pinned; }
+  g_bench_threads_pinned = pinned;
   if (elapsed) *elapsed = now_s() - t0;
   if (n_lat) *n_lat = args[0].n_lat;
   free(th); free(args);

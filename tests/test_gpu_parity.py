@@ -42,6 +42,7 @@ CASES = [
     ("config1", 1234, 640, 480, 100, 0, 3, 2, 0),          # BASELINE configs[0]
     ("config2", 1235, 640, 480, 200, 80, 4, 3, 1),         # BASELINE configs[1]
     ("config3", 1236, 1280, 720, 400, 150, 5, 4, 2),       # BASELINE configs[2] (reference default levels)
+    ("config3-b", 5001, 1280, 720, 400, 150, 5, 4, 2),     # a second seed set of the same workload
     # segments only.  The reference's segment objective on its own does not converge (the oracle's trajectory: one accepted
     # step, then a chi2 increase and the roll-back to the initial pose; with the full synthetic motion the first step is a
     # 0.5 rad jump and every segment is culled).  Both are paths the device must follow: the small-motion one through the
@@ -640,7 +641,7 @@ def _poseopt_launch_shape_body(P, ob, gpu_ctx):
         assert Hh.rel(rd.cov, ro.cov) < 1e-6
 
 
-POSE_CASES = [("config5", 77, 500, 200, -1), ("frame-200-80", 78, 200, 80, -1), ("ten-arg", 79, 300, 100, 5),
+POSE_CASES = [("config5", 77, 500, 200, -1), ("config5-b", 1077, 500, 200, -1), ("frame-200-80", 78, 200, 80, -1), ("ten-arg", 79, 300, 100, 5),
               ("points-only", 80, 120, 0, -1), ("lines-only", 81, 0, 60, -1), ("tiny", 82, 7, 3, -1)]
 
 
