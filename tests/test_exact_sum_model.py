@@ -119,3 +119,78 @@ def test_additive_model_statement():
         if abs(float(t) - float(r)) == ulp / 2 or float(s) + float(r) >= 2.0 ** (e + 1):
             continue
         assert float(F(s + t)) == float(s) + float(r)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The same algorithm laid out the way one half-wave (32 lanes, one slot per lane, rounds of 32 slots) runs it on the device
+# (align_kernels.hip::exact_sum_slots32): lane-local work, two exclusive scans, a first-failing-lane loop.  Mirrors the kernel
+# statement by statement so that the kernel can be checked against it.
+# ------------------------------------------------------------------------------------------------------------------------------
+def half_wave_sum(t, margin=2.0 ** -10):
+    t = np.asarray(t, F)
+    n_slots = (len(t) + 15) // 16
+    rounds = (n_slots + 31) // 32
+    pad = rounds * 32 * 16
+    t = np.concatenate([t, np.zeros(pad - len(t), F)]).reshape(rounds, 32, 16)
+    s = F(0.0)                 # the true running float sum (wave-uniform inside the half)
+    base = 0.0                 # predicted prefix: plain double sum of everything before the round
+    redone = 0
+    for k in range(rounds):
+        tt = t[k]                                            # lane l holds tt[l, :]
+        d = tt.astype(np.float64).sum(axis=1)               # lane-local double sum
+        excl = np.concatenate([[0.0], np.cumsum(d)[:-1]])   # exclusive scan over the 32 lanes
+        lo, hi = base + excl, base + excl + d
+        e = np.zeros(32, int); safe = np.zeros(32, bool); delta = np.zeros(32)
+        for l in range(32):
+            if not (lo[l] > 0.0 and np.isfinite(hi[l])):
+                continue
+            el = int(np.floor(np.log2(lo[l])))
+            if not (lo[l] * (1.0 - margin) >= 2.0 ** el and hi[l] * (1.0 + margin) < 2.0 ** (el + 1)) or el - 24 < -126 or el > 126:
+                continue
+            C = F(2.0 ** el)
+            r = (C + tt[l]).astype(F) - C
+            dev = tt[l] - r                                   # exact in float
+            if (np.abs(dev) == F(2.0 ** (el - 24))).any():
+                continue
+            e[l], safe[l], delta[l] = el, True, r.astype(np.float64).sum()
+        dex = np.concatenate([[0.0], np.cumsum(delta)[:-1]])  # exclusive scan of the rounded slot sums
+        start = 0                                            # first lane not yet settled
+        s0 = float(s)                                        # true sum in front of lane `start`
+        off = 0.0                                            # dex value of lane `start`
+        while start < 32:
+            sl = s0 + (dex - off)                            # each lane's candidate start value, valid if every lane in [start, l) passes
+            ok = safe & (sl > 0) & (2.0 ** e.astype(float) <= sl) & (sl + delta < 2.0 ** (e + 1.0))
+            ok[:start] = True
+            bad = np.nonzero(~ok)[0]
+            f = int(bad[0]) if len(bad) else 32
+            if f == 32:                                       # everyone from `start` on passes
+                s0 = s0 + (dex[31] + delta[31] - off)
+                break
+            sf = F(s0 + (dex[f] - off))                       # exact: every lane in [start, f) passed
+            for x in tt[f]:
+                sf = F(sf + x)                                # the failing lane re-adds its own sixteen terms in order
+            redone += 1
+            s0, start = float(sf), f + 1
+            off = dex[f] + delta[f] if f < 31 else 0.0        # = dex[f + 1]: the scan value in front of the next lane
+            if start == 32:
+                break
+        s = F(s0)
+        assert float(s) == s0
+        base += d.sum()
+    return s, redone, n_slots
+
+
+@pytest.mark.parametrize("n", [7, 16, 500, 3200, 6400])
+def test_half_wave_layout_is_bit_exact(n):
+    rng = np.random.default_rng(100 + n)
+    for _ in range(8 if n <= 500 else 4):
+        t = chi2_like_terms(rng, n)
+        got, redone, ns = half_wave_sum(t)
+        assert got.tobytes() == seq_sum(t).tobytes()
+        if n >= 3200:
+            assert redone < 0.15 * ns
+    for t in (np.zeros(64, F), np.full(3200, F(0.5)), (rng.integers(0, 4, 3200) * 0.25).astype(F),
+              np.concatenate([np.full(100, F(1e-30)), chi2_like_terms(rng, 1000)]), (chi2_like_terms(rng, 3200) * F(2.0 ** 60)).astype(F),
+              (chi2_like_terms(rng, 3200) * F(2.0 ** -60)).astype(F)):
+        got, _, _ = half_wave_sum(t)
+        assert got.tobytes() == seq_sum(t).tobytes()
