@@ -304,6 +304,7 @@ extern "C" int plsvo_hip_config_pyramids(plsvo_ctx* c, int n_slots, int width, i
   d.tbase = c->pyr_tiled.as<uint8_t>();
   c->pyr = d;
   c->a_staged = false;
+  c->ch_staged = false;
   return PLSVO_OK;
 }
 
@@ -479,6 +480,7 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   if (!c->pyr.base) return fail(c, PLSVO_E_STATE, "align_stage: pyramids not configured");
   HIP_TRY(c, hipSetDevice(c->device));
   c->a_staged = false;
+  c->ch_staged = false;   // a resident frame step is built on the staged alignment batch: staging another one invalidates it
   std::vector<AlignJobDev> jobs((size_t)n);
   std::vector<double> T0((size_t)n * 7), ptpx, ptxyz, spx, epx, len, sp, sq;
   std::vector<uint8_t> alive;

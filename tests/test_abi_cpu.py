@@ -36,7 +36,10 @@ def test_ctypes_structs_match_the_c_header(P, tmp_path):
     structs = {"plsvo_pinhole": P.abi.Pinhole, "plsvo_align_in": P.abi.AlignIn, "plsvo_align_out": P.abi.AlignOut,
                "plsvo_align_iterlog": P.abi.AlignIterLog, "plsvo_poseopt_in": P.abi.PoseOptIn,
                "plsvo_poseopt_out": P.abi.PoseOptOut, "plsvo_poseopt_iterlog": P.abi.PoseOptIterLog,
-               "plsvo_structopt_in": P.abi.StructOptIn, "plsvo_structopt_out": P.abi.StructOptOut}
+               "plsvo_structopt_in": P.abi.StructOptIn, "plsvo_structopt_out": P.abi.StructOptOut,
+               "plsvo_match_in": P.abi.MatchIn, "plsvo_match_out": P.abi.MatchOut, "plsvo_reproject_in": P.abi.ReprojectIn,
+               "plsvo_reproject_out": P.abi.ReprojectOut, "plsvo_seeds_in": P.abi.SeedsIn, "plsvo_seeds_out": P.abi.SeedsOut,
+               "plsvo_chain_in": P.abi.ChainIn, "plsvo_chain_params": P.abi.ChainParams, "plsvo_chain_out": P.abi.ChainOut}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, ct in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
