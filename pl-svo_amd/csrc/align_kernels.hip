@@ -134,9 +134,6 @@ __device__ __forceinline__ void block_sync() {
 #ifndef PLSVO_CHI_NT
 #define PLSVO_CHI_NT 0
 #endif
-#ifndef PLSVO_CHI_EXP
-#define PLSVO_CHI_EXP 0
-#endif
 // launch shapes up to this many threads per frame read the tiled pyramid mirror, larger ones the row-major slab (load_row7).
 // Measured: 64 threads (32768 frames, the chip saturated) -7 % launch time tiled; 128 threads (8192 frames) +4 % tiled; 512 +12 % per pass.
 #ifndef PLSVO_TILED_MAX_T
