@@ -98,6 +98,16 @@ __device__ U block_radix_select(GET get, int n, int k, int* s_hist, int* s_sel) 
 // s_ctl[0] break flag
 
 // one GN loop (src/pose_optimizer.cpp:103-195 and the identical text at :469-563)
+// sqrt(a*a + b*b) in float with every product and the sum rounded on its own (Eigen's Vector2f::norm() in the un-contracted build the
+// oracle pins, src/pose_optimizer.cpp:84-87).  HIP's __fmul_rn / __fadd_rn are plain `*` / `+` and hipcc contracts by default: fused,
+// the value is one ulp off for some inputs, and when that input is the median line error the MAD scale -- hence every Tukey weight --
+// moves by a float ulp (found on the second config-5 seed set: chi2 of the first iteration 2.9e-8 off, tests/test_gpu_parity.py).
+__device__ __forceinline__ float norm2_f32(float a, float b) {
+#pragma clang fp contract(off)
+  const float p = a * a, q = b * b;
+  return sqrtf(p + q);
+}
+
 template <int PO_T>
 __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseStateDev* st, int job_id, double* s_red,
                              double* s_pose, int* s_ctl, int n_iter, int phase, double scale_pt, double scale_ls,
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* 
         const double l0 = b.seg_line[3 * s], l1 = b.seg_line[3 * s + 1], l2 = b.seg_line[3 * s + 2];
         const float es = (float)(l0 * (xs0 / xs2) + l1 * (xs1 / xs2) + l2 * 1.0);   // not scaled by the level (:84-87)
         const float ee = (float)(l0 * (xe0 / xe2) + l1 * (xe1 / xe2) + l2 * 1.0);
-        errs[f] = sqrtf(__fadd_rn(__fmul_rn(es, es), __fmul_rn(ee, ee)));
+        errs[f] = norm2_f32(es, ee);
       }
     }
   }
