@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds on the default bench command (no tests).  usage: tools/r03_bench_ab.sh <tag> <reps> [lib suffixes...]
+# A/B of library builds on the default bench command (no tests).  usage: tools/ab_bench.sh <tag> <reps> [lib suffixes...]
 TAG=$1; REPS=$2; shift; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG

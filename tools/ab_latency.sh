@@ -1,5 +1,5 @@
 #!/bin/bash
-# latency A/B of library builds + a parity subset on the default build.  usage: tools/r03_latab.sh <tag> [lib suffixes...]
+# latency A/B of library builds + a parity subset on the default build.  usage: tools/ab_latency.sh <tag> [lib suffixes...]
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 GPU call: full GPU suite (no -x: every failure is reported) + A/B of library builds on the default bench command
-# usage: tools/r03_ab.sh <tag> [lib suffixes...]     -> gpurun_out/<tag>/
+# usage: tools/ab_suite.sh <tag> [lib suffixes...]     -> gpurun_out/<tag>/
 TAG=${1:-r03a}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
