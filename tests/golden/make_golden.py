@@ -92,6 +92,23 @@ def widened_rows():
     print("seeds_small statuses", np.bincount(outs["out1_pt_status"], minlength=5), np.bincount(outs["out2_pt_status"], minlength=5))
 
 
+def frame_chain():
+    """fixture of the frame step chained as FrameHandlerMono::processFrame chains it (pl-svo_amd/sequence.py on the oracle): a 4-frame
+    sequence, the per-frame poses / covariances / match counts of the oracle's chain"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_sequence import OracleBackend
+    seqm = importlib.import_module("pl-svo_amd.sequence")
+    seq = seqm.make_sequence(9501, n_frames=4, W=320, H=240, n_pts=60, n_seg=12)
+    res = seqm.run_sequence(OracleBackend(ob), seq)
+    keys = ("poses_true", "pt_pos", "pt_px0", "pt_f0", "seg_spos", "seg_epos", "seg_spx0", "seg_epx0", "seg_sf0", "seg_ef0")
+    np.savez_compressed(os.path.join(HERE, "chain_small.npz"), images=np.stack(seq["images"]), cam=np.array(seq["cam"], float), **{k: seq[k] for k in keys},
+                        out_T=np.stack([r["T"] for r in res]), out_cov=np.stack([r["cov"] for r in res]),
+                        out_n_matched_pt=np.array([r["n_matched_pt"] for r in res]), out_n_matched_seg=np.array([r["n_matched_seg"] for r in res]),
+                        out_n_kept_pt=np.array([r.get("n_kept_pt", -1) for r in res]), out_n_kept_seg=np.array([r.get("n_kept_seg", -1) for r in res]))
+    print("chain_small matched", [r["n_matched_pt"] for r in res], [r["n_matched_seg"] for r in res])
+
+
 if __name__ == "__main__":
     main()
     widened_rows()
+    frame_chain()
