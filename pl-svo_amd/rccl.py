@@ -56,14 +56,25 @@ def comm_destroy(comm):
         lib().ncclCommDestroy(C.c_void_p(comm))
 
 
+def exchange_unique_id(make_id=None):
+    """Every rank of the initialised torch.distributed process group returns the SAME 128 bytes: rank 0 creates them (make_id, default
+    unique_id()), the process group carries them to the others.  Without a process group: this process's own id."""
+    import torch.distributed as dist
+    make_id = make_id or unique_id
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return make_id()
+    box = [make_id() if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    uid = box[0]
+    if not isinstance(uid, (bytes, bytearray)) or len(uid) != 128:
+        raise RuntimeError("the rendezvous did not deliver a 128-byte RCCL unique id")
+    return bytes(uid)
+
+
 def comm_over_process_group():
     """One communicator spanning the initialised torch.distributed process group (a single-rank one without it): rank 0's unique
     id travels through the process group, then every rank joins."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return comm_init(1, 0, unique_id())
-    world, rank = dist.get_world_size(), dist.get_rank()
-    box = [unique_id() if rank == 0 else None]
-    if world > 1:
-        dist.broadcast_object_list(box, src=0)
-    return comm_init(world, rank, box[0])
+    return comm_init(dist.get_world_size(), dist.get_rank(), exchange_unique_id())

@@ -139,3 +139,35 @@ def test_two_rank_bench_control_flow():
     assert np.array_equal(g0, g1) and g0.shape == (world * n_local, 7)
     assert list(g0[:, 0]) == [1234 + i for i in range(world * n_local)]
     assert (g0[:, 1] == 6).all()
+
+
+def _uid_worker(rank, world, port, q):
+    """the rendezvous half of pl-svo_amd/rccl.py::comm_over_process_group (what bench.py does at N > 1 before plsvo_gather_poses):
+    rank 0's 128-byte communicator id reaches every rank through the process group"""
+    sys.path.insert(0, ROOT)
+    import importlib
+    R = importlib.import_module("pl-svo_amd.rccl")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        uid = R.exchange_unique_id(make_id=lambda: bytes((7 * rank + k) % 251 for k in range(128)))   # a rank-dependent id: only rank 0's may arrive
+        q.put((rank, uid))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_unique_id_rendezvous():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uid_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    expect = bytes(k % 251 for k in range(128))
+    assert got[0] == expect and got[1] == expect and len(expect) == 128
