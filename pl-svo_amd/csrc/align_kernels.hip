@@ -38,6 +38,7 @@
 #include "plsvo_dev.hpp"
 #include "plsvo_math.hpp"
 #include "plsvo_wave.hpp"
+#include "align_refpatch.hpp"
 
 namespace plsvo_hip {
 
@@ -75,16 +76,6 @@ __device__ __forceinline__ void load_row7(const uint8_t* img, int pitch, int x, 
   o7[6] = (float)((w1 >> 16) & 0xffu);
 }
 
-// wTL*a + wTR*b + wBL*c + wBR*d, evaluated left to right in float, every product and every sum rounded on its own
-// (src/sparse_img_align.cpp:251, 458, 620).  HIP's __fmul_rn / __fadd_rn are plain `*` / `+` and hipcc contracts by default, so
-// the guarantee comes from the pragma: without it the compiler fused different products at the two call sites, and a static
-// camera (cur == ref, T = I) saw one-ulp residuals where the reference sees exact zeros (tests: static-camera cases).
-__device__ __forceinline__ float bilinear(float wTL, float wTR, float wBL, float wBR, float a, float b, float c, float d) {
-#pragma clang fp contract(off)
-  const float p0 = wTL * a, p1 = wTR * b, p2 = wBL * c, p3 = wBR * d;
-  return ((p0 + p1) + p2) + p3;
-}
-
 // (float)(1.0 / (1.0 + (double)a)) for a float a >= 0 -- the reference's robust weight
 // (src/sparse_img_align.cpp:479) -- without a double division: 1 + a is split exactly into s_hi + s_lo
 // (two-sum), y0 = rcp(s_hi), the exact residual e = 1 - s_hi*y0 comes from one fma, and
@@ -100,21 +91,35 @@ __device__ __forceinline__ float robust_weight(float a) {
   return __fmaf_rn(y0, c, y0);
 }
 
-// Patch::setPosition + computeInterpWeights (src/feature.cpp:189-208): position as float, weights
-// computed in double and stored as float
-struct PatchW { int ui, vi; float wTL, wTR, wBL, wBR; };
-__device__ __forceinline__ PatchW patch_weights(float u, float v) {
-  PatchW p;
-  const float fu = floorf(u), fv = floorf(v);
-  p.ui = (int)fu; p.vi = (int)fv;
-  const float su = u - fu, sv = v - fv;
-  p.wTL = (float)((1.0 - (double)su) * (1.0 - (double)sv));
-  p.wTR = (float)((double)su * (1.0 - (double)sv));
-  p.wBL = (float)((1.0 - (double)su) * (double)sv);
-  p.wBR = (float)((double)su * (double)sv);
-  return p;
+// ------------------------------------------------------------------------------------------------
+// PLSVO_BYTE_CACHE (experiment build, `make byte_cache`): the per-slot cache of the reference patch holds the 7x7 window of image BYTES
+// and the two sub-pixel fractions (one 64-B record: 7 rows of 8 B, then su, sv) instead of 3 x 16 floats of interpolated intensity and
+// gradient (192 B).  Every iteration rebuilds ref / dx / dy from the record with the very operations the precompute used, so the values
+// -- and every result -- are bit-identical; per patch-iteration the kernel streams 64 B instead of 192 B and pays ~200 more float
+// operations per lane.  The record lives in the cache_ref array (16 floats = 64 B per slot); cache_dx / cache_dy are not touched.
+// ------------------------------------------------------------------------------------------------
+#ifndef PLSVO_BYTE_CACHE
+#define PLSVO_BYTE_CACHE 0
+#endif
+template <bool TILED>
+__device__ __forceinline__ uint2 load_row8_raw(const uint8_t* img, int pitch, int x, int y) {   // bytes [x, x+8) of row y (same requests as load_row7)
+  uint32_t d0, d1, d2, sh;
+  if constexpr (TILED) {
+    const int a = x & ~3;
+    sh = (uint32_t)(x & 3);
+    const int row = tiled_row_offset(pitch, y);
+    d0 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a)));
+    d1 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a + 4)));
+    d2 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a + 8)));
+  } else {
+    const int off = y * pitch + x, a = off & ~3;
+    sh = (uint32_t)(off & 3);
+    d0 = *reinterpret_cast<const uint32_t*>(img + a);
+    d1 = *reinterpret_cast<const uint32_t*>(img + a + 4);
+    d2 = *reinterpret_cast<const uint32_t*>(img + a + 8);
+  }
+  return make_uint2(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh));
 }
-
 // optional per-phase timing (compile with -DPLSVO_TIMING): thread 0 accumulates s_memtime deltas
 #ifdef PLSVO_TIMING
 #define TICK(slot) do { if (tid == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); s_time[slot] += t__ - s_tlast; s_tlast = t__; } } while (0)
@@ -424,6 +429,16 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       if (p < n_slots && s_meta[p].x != SLOT_HOLE) {
         const float u = b.patch_uvref[2 * (pbase + p)], v = b.patch_uvref[2 * (pbase + p) + 1];
         const PatchW pw = patch_weights(u, v);
+#if PLSVO_BYTE_CACHE
+        {   // lane `row` of the slot's four writes record rows `row` and `row + 4` (image rows vi-3+.., columns ui-3 .. ui+3); lane 3 the fractions
+          unsigned char* const rec = reinterpret_cast<unsigned char*>(b.cache_ref) + ((pbase + p) << 6);
+          const int cx = pw.ui - 3, ry = pw.vi - 3 + row;
+          *reinterpret_cast<uint2*>(rec + 8 * row) = load_row8_raw<kTiled>(ref_img, pitch, cx, ry);
+          if (row < 3) *reinterpret_cast<uint2*>(rec + 8 * (row + 4)) = load_row8_raw<kTiled>(ref_img, pitch, cx, ry + 4);
+          else *reinterpret_cast<float2*>(rec + 56) = make_float2(u - floorf(u), v - floorf(v));
+          continue;
+        }
+#endif
         // patch row `row` sits on image row vi-2+row; the stencil needs image rows -1..+2 around it
         const int r0 = pw.vi - 2 + row - 1;
         const int c0 = pw.ui - 2 - 1;
@@ -431,20 +446,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) load_row7<kTiled>(ref_img, pitch, c0, r0 + rr, I[rr]);
         float4 vr, vx, vy;
-        float* pr = reinterpret_cast<float*>(&vr); float* pxp = reinterpret_cast<float*>(&vx); float* pyp = reinterpret_cast<float*>(&vy);
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          const int c = x + 1;  // column of pixel x inside I[.][0..6]
-          // B(r,c) = wTL*I[r][c] + wTR*I[r][c+1] + wBL*I[r+1][c] + wBR*I[r+1][c+1]
-          const float ref = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, I[1][c], I[1][c + 1], I[2][c], I[2][c + 1]);
-          const float xp = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, I[1][c + 1], I[1][c + 2], I[2][c + 1], I[2][c + 2]);
-          const float xm = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, I[1][c - 1], I[1][c], I[2][c - 1], I[2][c]);
-          const float yp = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, I[2][c], I[2][c + 1], I[3][c], I[3][c + 1]);
-          const float ym = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, I[0][c], I[0][c + 1], I[1][c], I[1][c + 1]);
-          pr[x] = ref;
-          pxp[x] = __fmul_rn(0.5f, __fsub_rn(xp, xm));
-          pyp[x] = __fmul_rn(0.5f, __fsub_rn(yp, ym));
-        }
+        ref_row_direct(I, pw.wTL, pw.wTR, pw.wBL, pw.wBR, vr, vx, vy);
         const size_t q = (pbase + p) * 4 + row;  // float4 index: slot-major, row-minor -> coalesced
         reinterpret_cast<float4*>(b.cache_ref)[q] = vr;
         reinterpret_cast<float4*>(b.cache_dx)[q] = vx;
@@ -490,7 +492,11 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         //   VGPRs, no gain over depth 1); depth 0: no pipelining.
         struct SlotA { int2 meta; bool cand; double X, Y, Z; };
         struct SlotB { bool live; float u, v; int sh0, sh1, sh2; uint32_t r0a, r0b, r1a, r1b, r2a, r2b; };
+#if PLSVO_BYTE_CACHE
+        struct SlotC { uint4 q01, q23; uint2 q4; float2 sw; };
+#else
         struct SlotC { float4 vr0, vx0, vy0, vr1, vx1, vy1; };
+#endif
         auto stage_a = [&](int pb_) -> SlotA {
           SlotA f;
           const int p_ = pb_ + pair;
@@ -537,6 +543,17 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         };
         auto stage_c_loads = [&](int pb_, bool cand_) -> SlotC {
           SlotC c;
+#if PLSVO_BYTE_CACHE
+          c.q01 = make_uint4(0u, 0u, 0u, 0u); c.q23 = c.q01; c.q4 = make_uint2(0u, 0u); c.sw = make_float2(0.f, 0.f);
+          if (cand_) {
+            const unsigned char* const rec = reinterpret_cast<const unsigned char*>(b.cache_ref) + ((pbase + pb_ + pair) << 6);
+            c.q01 = *reinterpret_cast<const uint4*>(rec + 16 * half);
+            c.q23 = *reinterpret_cast<const uint4*>(rec + 16 * half + 16);
+            c.q4 = *reinterpret_cast<const uint2*>(rec + 16 * half + 32);
+            c.sw = *reinterpret_cast<const float2*>(rec + 56);
+          }
+          return c;
+#else
           c.vr0 = make_float4(0.f, 0.f, 0.f, 0.f); c.vx0 = c.vr0; c.vy0 = c.vr0; c.vr1 = c.vr0; c.vx1 = c.vr0; c.vy1 = c.vr0;
           if (cand_) {
             const size_t q = (pbase + pb_ + pair) * 4 + 2 * half;
@@ -545,6 +562,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
             c.vy0 = reinterpret_cast<const float4*>(b.cache_dy)[q];  c.vy1 = reinterpret_cast<const float4*>(b.cache_dy)[q + 1];
           }
           return c;
+#endif
         };
 #ifndef PLSVO_PIPELINE
 #define PLSVO_PIPELINE 1
@@ -579,9 +597,14 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           const bool is_line = !hole && meta.x < 0;
           const bool cand = sa.cand;
           const double X = sa.X, Y = sa.Y, Z = sa.Z;
-          const float4 vr0 = sc.vr0, vx0 = sc.vx0, vy0 = sc.vy0, vr1 = sc.vr1, vx1 = sc.vx1, vy1 = sc.vy1;
           const float u = sb.u, v = sb.v;
           const bool live = sb.live;
+#if PLSVO_BYTE_CACHE
+          float4 vr0, vx0, vy0, vr1, vx1, vy1;
+          if (live) ref_rows_from_record(sc.q01, sc.q23, sc.q4, sc.sw.x, sc.sw.y, vr0, vx0, vy0, vr1, vx1, vy1);
+#else
+          const float4 vr0 = sc.vr0, vx0 = sc.vx0, vy0 = sc.vy0, vr1 = sc.vr1, vx1 = sc.vx1, vy1 = sc.vy1;
+#endif
 
           // -- residuals and the five patch sums over this lane's two patch rows (8 pixels)
           double sA = 0, sB = 0, sC = 0, sD = 0, sE = 0, sChi = 0;

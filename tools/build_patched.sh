@@ -1,0 +1,16 @@
+#!/bin/bash
+# Builds pl-svo_amd/libplsvo_hip_<suffix>.so from the tree with one of tools/patches/*.patch applied to a scratch copy of csrc
+# (the tree itself is not modified), for an A/B through PLSVO_HIP_LIB (tools/ab_latency.sh <tag> "" _<suffix>).
+# usage: tools/build_patched.sh tools/patches/slot_parallel_exact_sum_dpp.patch dpp
+set -e
+PATCH=$(realpath $1); SUF=$2
+R=$(cd $(dirname $0)/.. && pwd)
+W=$(mktemp -d /tmp/plsvo_patched.XXXX)
+mkdir -p $W/pl-svo_amd $W/include
+cp -r $R/pl-svo_amd/csrc $W/pl-svo_amd/csrc
+cp $R/include/plsvo_hip.h $W/include/
+(cd $W && patch -p1 -s < $PATCH)
+make -s -C $W/pl-svo_amd/csrc -j8 OUT=$W/lib.so
+cp $W/lib.so $R/pl-svo_amd/libplsvo_hip_$SUF.so
+echo "built pl-svo_amd/libplsvo_hip_$SUF.so"
+rm -rf $W
