@@ -173,9 +173,20 @@ inline int max(int a, int b) { return a > b ? a : b; }
 inline unsigned long long __ballot(int p) { return wave_emu::ballot(p != 0); }
 inline int __any(int p) { return wave_emu::ballot(p != 0) != 0ull; }
 inline int __all(int p) { return wave_emu::ballot(p != 0) == ~0ull; }
-template <class T> inline T __shfl(T v, int src, int width = 64) { (void)width; return wave_emu::shfl_generic(v, src & 63); }
-template <class T> inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return wave_emu::shfl_generic(v, (wave_emu::lane() ^ mask) & 63); }
+// HIP's shuffles: `width` (a power of two) splits the wave into independent segments, source lanes are relative to the segment
+template <class T> inline T __shfl(T v, int src, int width = 64) {
+  const int l = wave_emu::lane();
+  return wave_emu::shfl_generic(v, (l & ~(width - 1)) | (src & (width - 1)));
+}
+template <class T> inline T __shfl_xor(T v, int mask, int width = 64) {
+  const int l = wave_emu::lane(), t = l ^ mask;
+  return wave_emu::shfl_generic(v, (t & ~(width - 1)) == (l & ~(width - 1)) ? t : l);
+}
 template <class T> inline T __shfl_up(T v, unsigned d, int width = 64) {
   const int l = wave_emu::lane(), base = l & ~(width - 1);
   return wave_emu::shfl_generic(v, (l - (int)d) >= base ? l - (int)d : l);
+}
+template <class T> inline T __shfl_down(T v, unsigned d, int width = 64) {
+  const int l = wave_emu::lane(), end = (l & ~(width - 1)) + width;
+  return wave_emu::shfl_generic(v, (l + (int)d) < end ? l + (int)d : l);
 }
