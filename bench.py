@@ -376,6 +376,8 @@ def main():
 
     P = importlib.import_module("pl-svo_amd")
     capi, synth, abi, D = P.capi, P.synth, P.abi, P.dist
+    if hasattr(capi.lib(), "plsvo_emu_build"):   # tests/host/build_emu.sh: the device sources on a CPU wave emulator -- a test vehicle, never a measurement
+        raise SystemExit("bench.py: PLSVO_HIP_LIB names a host emulation build of the library; the benchmark runs the gfx950 library only")
     B = args.batch if args.batch > 0 else cfg["batch"]
     W, H = cfg["W"], cfg["H"]
     # shards: blocks of B streams with their own context.  Normally one per rank; BASELINE configs[3] fixes eight of them, so with

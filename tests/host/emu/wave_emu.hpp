@@ -1,13 +1,14 @@
-// wave_emu.hpp -- a lock-step wave64 emulator for the HOST, test infrastructure only (tests/host/): it lets g++ compile the device
-// headers of pl-svo_amd/csrc/ unchanged (tests/host/emu/hip/hip_runtime.h stands in for <hip/hip_runtime.h>) and run their wave-level
-// functions on 64 cooperative fibres (ucontext), one per lane.  Every cross-lane operation -- DPP, v_readlane, ds_bpermute, ballot,
-// shuffles, the wave barrier -- is a rendezvous: each lane deposits its operand and yields; when all 64 have arrived each computes its
-// own result from the others' deposits.  Only wave-uniform control flow around cross-lane operations is supported, and that is CHECKED:
-// lanes meeting at different operations abort the run.
+// wave_emu.hpp -- a lock-step wave64 / workgroup emulator for the HOST.  Test infrastructure only (tests/host/): it lets a host compiler
+// build the device sources of pl-svo_amd/csrc/ unchanged (tests/host/emu/hip/hip_runtime.h stands in for <hip/hip_runtime.h>) and run
+// them on cooperative fibres (ucontext), one per lane.  Every cross-lane operation -- DPP, v_readlane, ds_bpermute, ballot, shuffles,
+// the wave barrier -- is a rendezvous of the 64 lanes of a wave: each lane deposits its operand and yields; when it is resumed all lanes
+// have arrived and it computes its own result from their deposits.  __syncthreads is a rendezvous of the workgroup.  Only wave-uniform
+// control flow around cross-lane operations is supported, and that is CHECKED: lanes of a wave meeting at different operations abort.
 //
 // DPP semantics implemented (CDNA3/4 ISA, `v_mov_b32_dpp`): quad_perm, row_shl/shr/ror, row_mirror, row_half_mirror, row_bcast15,
-// row_bcast31, wave_shr1; a lane whose row or bank is masked out keeps `old`; a lane without a source lane receives 0 with bound_ctrl
-// and keeps `old` without.  The functions of the tree that have run on an MI355X (reductions, solve) are the check of these semantics.
+// row_bcast31, wave_shr1; a lane whose row or bank is masked out keeps `old`; a lane without a source lane (or whose source lane has left
+// the kernel) receives 0 with bound_ctrl and keeps `old` without.  The functions of the tree that have run on an MI355X (reductions,
+// solve, the alignment kernel) are the check of these semantics.
 #pragma once
 #include <ucontext.h>
 
@@ -21,68 +22,99 @@
 
 namespace wave_emu {
 constexpr int W = 64;
+constexpr int MAXT = 1024;
+constexpr int TAG_SYNC = 9000;
 struct State {
-  ucontext_t main_ctx, ctx[W];
-  std::vector<char> stack[W];
-  bool done[W];
-  int cur = -1;
-  uint64_t slot[2][W];
-  int tag[W];
-  long seq[W];
+  ucontext_t main_ctx;
+  std::vector<ucontext_t> ctx;
+  std::vector<std::vector<char>> stack;
+  std::vector<char> done, at_sync;
+  std::vector<uint64_t> slot[2];
+  std::vector<long> slot_seq[2];   // the operation a deposit belongs to: a lane takes part in operation q iff slot_seq[q & 1][lane] == q
+  std::vector<int> tag, site_line;
+  std::vector<const char*> site_file;
+  std::vector<long> seq;
+  int T = 0, cur = -1, sync_arrived = 0;
   std::function<void()> body;
   unsigned tid_base = 0;
+  State() : ctx(MAXT), stack(MAXT), done(MAXT), at_sync(MAXT), tag(MAXT), site_line(MAXT), site_file(MAXT, ""), seq(MAXT) { for (int k = 0; k < 2; ++k) { slot[k].resize(MAXT); slot_seq[k].resize(MAXT); } }
 };
 inline State& S() { static State s; return s; }
-inline int lane() { return S().cur; }
+inline int fibre() { return S().cur; }
+inline int lane() { return S().cur & 63; }
 inline void yield_lane() { State& s = S(); swapcontext(&s.ctx[s.cur], &s.main_ctx); }
 inline void trampoline() {
   State& s = S();
   s.body();
-  s.done[s.cur] = true;
+  s.done[s.cur] = 1;
   for (;;) swapcontext(&s.ctx[s.cur], &s.main_ctx);
 }
-// run `f` on the 64 lanes of one wave, in lock step at every cross-lane operation
+// run `f` on the T threads of one workgroup (T <= 1024): waves in lock step at every cross-lane operation, the workgroup at __syncthreads
 template <class F>
-void run_wave(F f, unsigned tid_base = 0) {
+void run_block(int T, F f, unsigned tid_base = 0) {
   State& s = S();
-  s.body = f; s.tid_base = tid_base;
-  for (int l = 0; l < W; ++l) {
-    s.stack[l].assign(512 * 1024, 0);
+  if (T < 1 || T > MAXT) { fprintf(stderr, "wave_emu: workgroup of %d threads\n", T); abort(); }
+  s.body = f; s.tid_base = tid_base; s.T = T; s.sync_arrived = 0;
+  for (int l = 0; l < T; ++l) {
+    if (s.stack[l].empty()) s.stack[l].assign(384 * 1024, 0);
     getcontext(&s.ctx[l]);
     s.ctx[l].uc_stack.ss_sp = s.stack[l].data();
     s.ctx[l].uc_stack.ss_size = s.stack[l].size();
     s.ctx[l].uc_link = &s.main_ctx;
     makecontext(&s.ctx[l], trampoline, 0);
-    s.done[l] = false; s.seq[l] = 0; s.tag[l] = 0;
+    s.done[l] = 0; s.at_sync[l] = 0; s.seq[l] = 0; s.tag[l] = 0; s.slot_seq[0][l] = -1; s.slot_seq[1][l] = -1;
   }
   for (;;) {
-    int alive = 0;
-    for (int l = 0; l < W; ++l)
+    // Between two rendezvous a lane runs alone.  On the hardware the lanes of a wave execute every instruction together, so "all lanes
+    // read a shared value, then lane 0 overwrites it" needs no fence there; here the lanes are resumed in DESCENDING order so that the
+    // usual single writer -- thread 0 / lane 0 -- runs last and its writes cannot reach reads that precede them in program order.
+    // (A hazard this does not cover makes the emulated result wrong, never silently right: the tests compare against the oracle.)
+    for (int l = T - 1; l >= 0; --l)
       if (!s.done[l]) { s.cur = l; swapcontext(&s.main_ctx, &s.ctx[l]); }
-    long q = -1; int t = 0;
-    for (int l = 0; l < W; ++l) {
-      if (s.done[l]) continue;
-      if (alive++ == 0) { q = s.seq[l]; t = s.tag[l]; }
-      else if (s.seq[l] != q || s.tag[l] != t) {
-        fprintf(stderr, "wave_emu: lanes diverged at a cross-lane operation (lane %d: op #%ld tag %d, expected #%ld tag %d)\n", l, s.seq[l], s.tag[l], q, t);
-        abort();
+    int alive = 0;
+    for (int w0 = 0; w0 < T; w0 += W) {   // lock-step check, wave by wave
+      long q = -1; int t = 0, first = -1;
+      for (int l = w0; l < w0 + W && l < T; ++l) {
+        if (s.done[l]) continue;
+        ++alive;
+        if (first < 0) { first = l; q = s.seq[l]; t = s.tag[l]; }
+        else if (s.seq[l] != q || s.tag[l] != t) {
+          fprintf(stderr, "wave_emu: lanes of a wave diverged at a cross-lane operation (thread %d: op #%ld tag %d at %s:%d; thread %d: op #%ld tag %d at %s:%d)\n",
+                  l, s.seq[l], s.tag[l], s.site_file[l], s.site_line[l], first, q, t, s.site_file[first], s.site_line[first]);
+          abort();
+        }
       }
     }
     if (alive == 0) break;
-    if (alive != W) { fprintf(stderr, "wave_emu: %d lanes left the function while others wait at a cross-lane operation\n", W - alive); abort(); }
+    if (s.sync_arrived > 0 && s.sync_arrived == alive) {   // every thread still in the kernel waits at the barrier: release (between sweeps)
+      for (int l = 0; l < T; ++l) s.at_sync[l] = 0;
+      s.sync_arrived = 0;
+    }
   }
   s.cur = -1;
 }
-// rendezvous: deposit v, wait for the other lanes; peek(q, l) then reads lane l's deposit
+template <class F>
+void run_wave(F f, unsigned tid_base = 0) { run_block(W, f, tid_base); }
+
+// rendezvous of a wave: deposit v, wait for the other lanes; peek(q, l) then reads the deposit of lane l of this wave
 inline long rendezvous(uint64_t v, int tag) {
   State& s = S();
   const int l = s.cur;
   const long q = ++s.seq[l];
-  s.slot[q & 1][l] = v; s.tag[l] = tag;
+  s.slot[q & 1][l] = v; s.slot_seq[q & 1][l] = q; s.tag[l] = tag;
   yield_lane();
   return q;
 }
-inline uint64_t peek(long q, int l) { return S().slot[q & 1][l & 63]; }
+inline uint64_t peek(long q, int l) { State& s = S(); return s.slot[q & 1][(s.cur & ~63) | (l & 63)]; }
+inline bool lane_present(long q, int l) { State& s = S(); const int f = (s.cur & ~63) | (l & 63); return f < s.T && s.slot_seq[q & 1][f] == q; }   // lane l takes part in operation q
+inline void set_site(const char* f, int line) { State& s = S(); s.site_file[s.cur] = f; s.site_line[s.cur] = line; }
+inline void syncthreads() {
+  State& s = S();
+  const int l = s.cur;
+  ++s.seq[l]; s.tag[l] = TAG_SYNC;
+  s.at_sync[l] = 1; ++s.sync_arrived;
+  while (s.at_sync[l]) yield_lane();
+}
 
 inline int dpp_source(int l, int ctrl) {   // source lane of lane l, or -1
   const int row = l & ~15, r = l & 15;
@@ -102,7 +134,7 @@ inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, b
   const int l = lane();
   if (!((row_mask >> (l >> 4)) & 1) || !((bank_mask >> ((l & 15) >> 2)) & 1)) return old;
   const int s = dpp_source(l, ctrl);
-  if (s < 0) return bound_ctrl ? 0 : old;
+  if (s < 0 || !lane_present(q, s)) return bound_ctrl ? 0 : old;
   return (int)(uint32_t)peek(q, s);
 }
 inline int readlane(int v, int src_lane) {
@@ -116,7 +148,7 @@ inline int ds_bpermute(int byte_addr, int v) {
 inline unsigned long long ballot(bool p) {
   const long q = rendezvous(p ? 1u : 0u, 4000);
   unsigned long long m = 0;
-  for (int l = 0; l < W; ++l) m |= (unsigned long long)(peek(q, l) & 1u) << l;
+  for (int l = 0; l < W; ++l) if (lane_present(q, l)) m |= (unsigned long long)(peek(q, l) & 1u) << l;
   return m;
 }
 inline void wave_barrier() { rendezvous(0, 5000); }
@@ -130,63 +162,3 @@ inline T shfl_generic(T v, int src) {
   return out;
 }
 }  // namespace wave_emu
-
-// ---- what the device headers expect from <hip/hip_runtime.h> ------------------------------------------------------------------
-#define __device__
-#define __host__
-#define __global__
-#define __forceinline__ inline
-#define __noinline__
-struct WaveEmuTid { operator unsigned() const { return wave_emu::S().tid_base + (unsigned)wave_emu::lane(); } };
-struct WaveEmuDim { WaveEmuTid x; };
-static const WaveEmuDim threadIdx = {};
-struct float2 { float x, y; };
-struct float4 { float x, y, z, w; };
-struct double2 { double x, y; };
-struct int2 { int x, y; };
-struct uint2 { uint32_t x, y; };
-struct uint4 { uint32_t x, y, z, w; };
-inline double2 make_double2(double x, double y) { double2 r = { x, y }; return r; }
-inline int2 make_int2(int x, int y) { int2 r = { x, y }; return r; }
-inline float4 make_float4(float x, float y, float z, float w) { float4 r = { x, y, z, w }; return r; }
-
-inline int __double2loint(double v) { uint64_t b; memcpy(&b, &v, 8); return (int)(uint32_t)b; }
-inline int __double2hiint(double v) { uint64_t b; memcpy(&b, &v, 8); return (int)(uint32_t)(b >> 32); }
-inline double __hiloint2double(int hi, int lo) { const uint64_t b = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double v; memcpy(&v, &b, 8); return v; }
-inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
-inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
-inline float __fadd_rn(float a, float b) { return a + b; }
-inline float __fsub_rn(float a, float b) { return a - b; }
-inline float __fmul_rn(float a, float b) { return a * b; }
-inline float __fsqrt_rn(float a) { return sqrtf(a); }
-inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
-inline int min(int a, int b) { return a < b ? a : b; }
-inline int max(int a, int b) { return a > b ? a : b; }
-#define __builtin_amdgcn_update_dpp wave_emu::update_dpp
-#define __builtin_amdgcn_readlane wave_emu::readlane
-#define __builtin_amdgcn_ds_bpermute wave_emu::ds_bpermute
-#define __builtin_amdgcn_wave_barrier wave_emu::wave_barrier
-#define __builtin_amdgcn_fence(order, scope) ((void)0)
-#define __builtin_amdgcn_rcp(x) (1.0 / (x))
-#define __builtin_amdgcn_rsq(x) (1.0 / sqrt(x))
-#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
-inline unsigned long long __ballot(int p) { return wave_emu::ballot(p != 0); }
-inline int __any(int p) { return wave_emu::ballot(p != 0) != 0ull; }
-inline int __all(int p) { return wave_emu::ballot(p != 0) == ~0ull; }
-// HIP's shuffles: `width` (a power of two) splits the wave into independent segments, source lanes are relative to the segment
-template <class T> inline T __shfl(T v, int src, int width = 64) {
-  const int l = wave_emu::lane();
-  return wave_emu::shfl_generic(v, (l & ~(width - 1)) | (src & (width - 1)));
-}
-template <class T> inline T __shfl_xor(T v, int mask, int width = 64) {
-  const int l = wave_emu::lane(), t = l ^ mask;
-  return wave_emu::shfl_generic(v, (t & ~(width - 1)) == (l & ~(width - 1)) ? t : l);
-}
-template <class T> inline T __shfl_up(T v, unsigned d, int width = 64) {
-  const int l = wave_emu::lane(), base = l & ~(width - 1);
-  return wave_emu::shfl_generic(v, (l - (int)d) >= base ? l - (int)d : l);
-}
-template <class T> inline T __shfl_down(T v, unsigned d, int width = 64) {
-  const int l = wave_emu::lane(), end = (l & ~(width - 1)) + width;
-  return wave_emu::shfl_generic(v, (l + (int)d) < end ? l + (int)d : l);
-}

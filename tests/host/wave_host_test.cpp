@@ -33,7 +33,7 @@ static int selfcheck() {
       if (l == 63) { sum63 = s; max63 = m; }
     });
     if (sum63 != want_sum) return fail("wave_sum_to_lane63");
-    if (max63 != want_max) return fail("wave_max_to_lane63");
+    if (max63 != want_max) { fprintf(stderr, "max63 %g want %g\n", max63, want_max); return fail("wave_max_to_lane63"); }
   }
   // ---- row_reduce_scatter32 + reduce_rows_finish<ROWS>: a 256-thread workgroup = 4 waves run one after the other, 16 row partials
   {

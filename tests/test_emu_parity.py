@@ -1,0 +1,93 @@
+"""The whole library on the CPU.  tests/host/build_emu.sh compiles every .hip of pl-svo_amd/csrc/ -- kernels and C ABI, unchanged -- as
+host C++ against tests/host/emu/ (device language + HIP runtime on a lock-step wave64 emulator: one fibre per lane, DPP / readlane /
+bpermute / ballot / barriers as rendezvous, a launch = its workgroups one after the other) into libplsvo_hip_emu.so.  The `-m gpu` parity
+tests then run against THAT library (PLSVO_HIP_LIB) in a sub-process: the same assertions against the oracle that the MI355X run makes,
+on the same device source, a frame in a second instead of microseconds.
+
+What this is: a functional check of the device SOURCE (indexing, control flow, the order of float operations) that needs no GPU, and
+the way kernel variants that have not been on a GPU yet are checked bit for bit against the build that has.  What it is not: a
+statement about the compiled gfx950 code (fma contraction, the hardware's rcp/rsq seeds, memory ordering inside a wave) -- the `-m gpu`
+run on the MI355X stays the parity gate.  The emulated library is test infrastructure: it lives in a temporary directory, exports the
+marker `plsvo_emu_build`, and bench.py refuses it."""
+import os
+import pickle
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CXX = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+pytestmark = pytest.mark.skipif(not os.path.exists(CXX), reason="host emulation build needs clang++ (ext_vector_type, address spaces)")
+
+
+def build_emu(out_dir, src_dir="", *flags):
+    subprocess.run([os.path.join(ROOT, "tests", "host", "build_emu.sh"), str(out_dir), str(src_dir), *flags], check=True, capture_output=True)
+    return os.path.join(str(out_dir), "libplsvo_hip_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu_lib(tmp_path_factory):
+    return build_emu(tmp_path_factory.mktemp("emu_default"))
+
+
+def emu_env(lib):
+    # one BLAS thread per process: four test workers with eight spinning BLAS threads each take five times as long
+    return dict(os.environ, PLSVO_HIP_LIB=lib, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+
+
+# the GPU tests that finish in seconds per case under emulation (a config-3 frame or a seed sweep is minutes)
+SUBSET = ("(test_gpu_parity and (halfsample and shape2 or matches_oracle and not config3 or every_launch_shape and not 512 or long_lines or edge_cases "
+          "or fewer_patches or border_features or single_linearisation or pose_optimizer and not seed_sweep or ldlt_flavour or errors_are_reported "
+          "or device_trace)) or test_golden or test_depth_filter or test_structure_opt or test_match_direct or test_reproject_trajectory "
+          "or (test_sequence and (matches_the_oracle_chain or grid_rule))")
+
+
+def test_gpu_parity_suite_passes_on_the_emulated_library(emu_lib):
+    env = emu_env(emu_lib)
+    mods = ["test_gpu_parity.py", "test_golden.py", "test_depth_filter.py", "test_structure_opt.py", "test_match_direct.py",
+            "test_reproject_trajectory.py", "test_sequence.py"]
+    out = subprocess.run([sys.executable, "-m", "pytest", *[os.path.join(ROOT, "tests", m) for m in mods], "-m", "gpu", "-q", "-x", "-n", "4",
+                          "-p", "no:cacheprovider", "-k", SUBSET], env=env, capture_output=True, text=True, cwd=ROOT)
+    tail = out.stdout[-3000:] + out.stderr[-1000:]
+    assert out.returncode == 0, tail
+    last = [l for l in out.stdout.splitlines() if " passed" in l][-1]
+    assert " failed" not in last and int(last.split(" passed")[0].split()[-1]) >= 60, tail
+
+
+def run_variant(lib, out_pkl):
+    env = emu_env(lib)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host", "emu_variant_runner.py"), str(out_pkl)], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    return pickle.load(open(out_pkl, "rb"))
+
+
+def patched_sources(tmp_path, patch_name):
+    if shutil.which("patch") is None:
+        pytest.skip("patch(1) not available")
+    w = tmp_path / "src"
+    (w / "pl-svo_amd").mkdir(parents=True)
+    (w / "include").mkdir()
+    shutil.copytree(os.path.join(ROOT, "pl-svo_amd", "csrc"), w / "pl-svo_amd" / "csrc", ignore=shutil.ignore_patterns("*.o"))
+    shutil.copy(os.path.join(ROOT, "include", "plsvo_hip.h"), w / "include")
+    with open(os.path.join(ROOT, "tools", "patches", patch_name)) as f:
+        subprocess.run(["patch", "-p1", "-s"], stdin=f, cwd=str(w), check=True)
+    return w / "pl-svo_amd" / "csrc"
+
+
+@pytest.mark.parametrize("variant", ["byte_cache", "dpp_exact_sum"])
+def test_kernel_variants_are_bitwise_the_default_build(emu_lib, tmp_path, variant):
+    """A/B builds of align_fused_kernel that exist for speed only -- the byte-record reference-patch cache (-DPLSVO_BYTE_CACHE=1) and the
+    DPP form of the slot-parallel near-tie sums (tools/patches/) -- must return, bit for bit, what the default build returns: poses,
+    counts, culled segments, every iteration's chi2 and step, the number of near ties resolved; at 64 and 256 threads per frame."""
+    base = run_variant(emu_lib, tmp_path / "base.pkl")
+    if variant == "byte_cache":
+        lib = build_emu(tmp_path / "emu_variant", "", "-DPLSVO_BYTE_CACHE=1")
+    else:
+        lib = build_emu(tmp_path / "emu_variant", patched_sources(tmp_path, "slot_parallel_exact_sum_dpp.patch"))
+    var = run_variant(lib, tmp_path / "variant.pkl")
+    assert base.keys() == var.keys()
+    for k in base:
+        assert base[k] == var[k], k
+    assert any(v[5][1] > 0 for v in base.values())      # the cases do contain near ties decided on the exact float sums
