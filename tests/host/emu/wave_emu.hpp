@@ -20,6 +20,14 @@
 #include <functional>
 #include <vector>
 
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define WAVE_EMU_ASAN 1
+#include <sanitizer/asan_interface.h>
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
+
 namespace wave_emu {
 constexpr int W = 64;
 constexpr int MAXT = 1024;
@@ -37,17 +45,45 @@ struct State {
   int T = 0, cur = -1, sync_arrived = 0;
   std::function<void()> body;
   unsigned tid_base = 0;
+  const void* main_stack_bottom = nullptr;
+  size_t main_stack_size = 0;
   State() : ctx(MAXT), stack(MAXT), done(MAXT), at_sync(MAXT), tag(MAXT), site_line(MAXT), site_file(MAXT, ""), seq(MAXT) { for (int k = 0; k < 2; ++k) { slot[k].resize(MAXT); slot_seq[k].resize(MAXT); } }
 };
 inline State& S() { static State s; return s; }
 inline int fibre() { return S().cur; }
 inline int lane() { return S().cur & 63; }
-inline void yield_lane() { State& s = S(); swapcontext(&s.ctx[s.cur], &s.main_ctx); }
+// AddressSanitizer builds (tests/host/build_emu.sh ... -fsanitize=address) tell the runtime about every stack switch
+inline void switch_to_lane(int l) {
+  State& s = S();
+  s.cur = l;
+#ifdef WAVE_EMU_ASAN
+  void* fake = nullptr;
+  __sanitizer_start_switch_fiber(&fake, s.stack[l].data(), s.stack[l].size());
+  swapcontext(&s.main_ctx, &s.ctx[l]);
+  __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#else
+  swapcontext(&s.main_ctx, &s.ctx[l]);
+#endif
+}
+inline void yield_lane() {
+  State& s = S();
+#ifdef WAVE_EMU_ASAN
+  void* fake = nullptr;
+  __sanitizer_start_switch_fiber(&fake, s.main_stack_bottom, s.main_stack_size);
+  swapcontext(&s.ctx[s.cur], &s.main_ctx);
+  __sanitizer_finish_switch_fiber(fake, &s.main_stack_bottom, &s.main_stack_size);
+#else
+  swapcontext(&s.ctx[s.cur], &s.main_ctx);
+#endif
+}
 inline void trampoline() {
   State& s = S();
+#ifdef WAVE_EMU_ASAN
+  __sanitizer_finish_switch_fiber(nullptr, &s.main_stack_bottom, &s.main_stack_size);
+#endif
   s.body();
   s.done[s.cur] = 1;
-  for (;;) swapcontext(&s.ctx[s.cur], &s.main_ctx);
+  for (;;) yield_lane();
 }
 // run `f` on the T threads of one workgroup (T <= 1024): waves in lock step at every cross-lane operation, the workgroup at __syncthreads
 template <class F>
@@ -57,6 +93,9 @@ void run_block(int T, F f, unsigned tid_base = 0) {
   s.body = f; s.tid_base = tid_base; s.T = T; s.sync_arrived = 0;
   for (int l = 0; l < T; ++l) {
     if (s.stack[l].empty()) s.stack[l].assign(384 * 1024, 0);
+#ifdef WAVE_EMU_ASAN
+    __asan_unpoison_memory_region(s.stack[l].data(), s.stack[l].size());   // frames a finished fibre abandoned
+#endif
     getcontext(&s.ctx[l]);
     s.ctx[l].uc_stack.ss_sp = s.stack[l].data();
     s.ctx[l].uc_stack.ss_size = s.stack[l].size();
@@ -70,7 +109,7 @@ void run_block(int T, F f, unsigned tid_base = 0) {
     // usual single writer -- thread 0 / lane 0 -- runs last and its writes cannot reach reads that precede them in program order.
     // (A hazard this does not cover makes the emulated result wrong, never silently right: the tests compare against the oracle.)
     for (int l = T - 1; l >= 0; --l)
-      if (!s.done[l]) { s.cur = l; swapcontext(&s.main_ctx, &s.ctx[l]); }
+      if (!s.done[l]) switch_to_lane(l);
     int alive = 0;
     for (int w0 = 0; w0 < T; w0 += W) {   // lock-step check, wave by wave
       long q = -1; int t = 0, first = -1;
