@@ -108,8 +108,16 @@ void run_block(int T, F f, unsigned tid_base = 0) {
     // read a shared value, then lane 0 overwrites it" needs no fence there; here the lanes are resumed in DESCENDING order so that the
     // usual single writer -- thread 0 / lane 0 -- runs last and its writes cannot reach reads that precede them in program order.
     // (A hazard this does not cover makes the emulated result wrong, never silently right: the tests compare against the oracle.)
-    for (int l = T - 1; l >= 0; --l)
-      if (!s.done[l]) switch_to_lane(l);
+    // WAVE_EMU_ORDER=asc0last resumes them 1, 2, .., T-1, then the lane 0 of every wave: a run that passes in BOTH orders does not depend on
+    // the lock step for any exchange through memory between lanes other than "lane 0 writes last" (tests/host/run_emu_orders.sh).
+    static const bool asc0last = getenv("WAVE_EMU_ORDER") && !strcmp(getenv("WAVE_EMU_ORDER"), "asc0last");
+    if (asc0last) {
+      for (int l = 0; l < T; ++l) if ((l & 63) != 0 && !s.done[l]) switch_to_lane(l);
+      for (int l = 0; l < T; l += 64) if (!s.done[l]) switch_to_lane(l);
+    } else {
+      for (int l = T - 1; l >= 0; --l)
+        if (!s.done[l]) switch_to_lane(l);
+    }
     int alive = 0;
     for (int w0 = 0; w0 < T; w0 += W) {   // lock-step check, wave by wave
       long q = -1; int t = 0, first = -1;
