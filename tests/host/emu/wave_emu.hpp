@@ -10,7 +10,9 @@
 // the kernel) receives 0 with bound_ctrl and keeps `old` without.  The functions of the tree that have run on an MI355X (reductions,
 // solve, the alignment kernel) are the check of these semantics.
 #pragma once
+#if !defined(__x86_64__)
 #include <ucontext.h>
+#endif
 
 #include <cmath>
 #include <cstdint>
@@ -29,12 +31,41 @@
 #endif
 
 namespace wave_emu {
+// ---- fibre switch.  x86-64: a hand-written switch of the callee-saved registers and the stack pointer (swapcontext() makes two
+// rt_sigprocmask system calls per switch, which was 80 % of the emulation's run time); elsewhere: ucontext.
+#if defined(__x86_64__)
+struct Context { void* sp = nullptr; };
+__attribute__((naked, noinline)) inline void context_switch(void** /*save_sp: rdi*/, void* /*load_sp: rsi*/) {
+  __asm__ volatile(
+      "pushq %rbp\n pushq %rbx\n pushq %r12\n pushq %r13\n pushq %r14\n pushq %r15\n"
+      "movq %rsp, (%rdi)\n"
+      "movq %rsi, %rsp\n"
+      "popq %r15\n popq %r14\n popq %r13\n popq %r12\n popq %rbx\n popq %rbp\n"
+      "ret\n");
+}
+inline void context_make(Context& c, char* stack, size_t size, void (*entry)()) {
+  uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+  void** p = reinterpret_cast<void**>(top);
+  *--p = nullptr;                                  // the return address `entry` would return to (it never returns)
+  *--p = reinterpret_cast<void*>(entry);           // popped by the switch's `ret`
+  for (int k = 0; k < 6; ++k) *--p = nullptr;      // rbp, rbx, r12..r15
+  c.sp = p;
+}
+inline void context_swap(Context& from, Context& to) { context_switch(&from.sp, to.sp); }
+#else
+struct Context { ucontext_t uc; };
+inline void context_make(Context& c, char* stack, size_t size, void (*entry)()) {
+  getcontext(&c.uc); c.uc.uc_stack.ss_sp = stack; c.uc.uc_stack.ss_size = size; c.uc.uc_link = nullptr; makecontext(&c.uc, entry, 0);
+}
+inline void context_swap(Context& from, Context& to) { swapcontext(&from.uc, &to.uc); }
+#endif
+
 constexpr int W = 64;
 constexpr int MAXT = 1024;
 constexpr int TAG_SYNC = 9000;
 struct State {
-  ucontext_t main_ctx;
-  std::vector<ucontext_t> ctx;
+  Context main_ctx;
+  std::vector<Context> ctx;
   std::vector<std::vector<char>> stack;
   std::vector<char> done, at_sync;
   std::vector<uint64_t> slot[2];
@@ -59,10 +90,10 @@ inline void switch_to_lane(int l) {
 #ifdef WAVE_EMU_ASAN
   void* fake = nullptr;
   __sanitizer_start_switch_fiber(&fake, s.stack[l].data(), s.stack[l].size());
-  swapcontext(&s.main_ctx, &s.ctx[l]);
+  context_swap(s.main_ctx, s.ctx[l]);
   __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
 #else
-  swapcontext(&s.main_ctx, &s.ctx[l]);
+  context_swap(s.main_ctx, s.ctx[l]);
 #endif
 }
 inline void yield_lane() {
@@ -70,10 +101,10 @@ inline void yield_lane() {
 #ifdef WAVE_EMU_ASAN
   void* fake = nullptr;
   __sanitizer_start_switch_fiber(&fake, s.main_stack_bottom, s.main_stack_size);
-  swapcontext(&s.ctx[s.cur], &s.main_ctx);
+  context_swap(s.ctx[s.cur], s.main_ctx);
   __sanitizer_finish_switch_fiber(fake, &s.main_stack_bottom, &s.main_stack_size);
 #else
-  swapcontext(&s.ctx[s.cur], &s.main_ctx);
+  context_swap(s.ctx[s.cur], s.main_ctx);
 #endif
 }
 inline void trampoline() {
@@ -96,11 +127,7 @@ void run_block(int T, F f, unsigned tid_base = 0) {
 #ifdef WAVE_EMU_ASAN
     __asan_unpoison_memory_region(s.stack[l].data(), s.stack[l].size());   // frames a finished fibre abandoned
 #endif
-    getcontext(&s.ctx[l]);
-    s.ctx[l].uc_stack.ss_sp = s.stack[l].data();
-    s.ctx[l].uc_stack.ss_size = s.stack[l].size();
-    s.ctx[l].uc_link = &s.main_ctx;
-    makecontext(&s.ctx[l], trampoline, 0);
+    context_make(s.ctx[l], s.stack[l].data(), s.stack[l].size(), trampoline);
     s.done[l] = 0; s.at_sync[l] = 0; s.seq[l] = 0; s.tag[l] = 0; s.slot_seq[0][l] = -1; s.slot_seq[1][l] = -1;
   }
   for (;;) {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The GPU parity tests against an AddressSanitizer build of the host emulation (tests/host/build_emu.sh): every load and store of the
 # kernels and of the C ABI checked against the bounds of the hipMalloc'ed buffers.  ~9 minutes on 8 cores; not part of the pytest suite.
-# Round 3, HEAD of that day: 82 passed, no AddressSanitizer report (the one failure is test_hip_resident_chain_equals_the_per_call_chain,
+# Round 3, HEAD of that day (ucontext fibres; the hand-written switch is annotated the same way): 82 passed, no AddressSanitizer report (the one failure is test_hip_resident_chain_equals_the_per_call_chain,
 # whose 1e-9 tolerance is tuned to the gfx950 arithmetic: tests/test_emu_parity.py leaves it out for the same reason).
 # usage: tests/host/run_emu_asan.sh [pytest -k expression]
 R=$(cd $(dirname $0)/../.. && pwd)

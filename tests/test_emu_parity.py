@@ -2,7 +2,7 @@
 host C++ against tests/host/emu/ (device language + HIP runtime on a lock-step wave64 emulator: one fibre per lane, DPP / readlane /
 bpermute / ballot / barriers as rendezvous, a launch = its workgroups one after the other) into libplsvo_hip_emu.so.  The `-m gpu` parity
 tests then run against THAT library (PLSVO_HIP_LIB) in a sub-process: the same assertions against the oracle that the MI355X run makes,
-on the same device source, a frame in a second instead of microseconds.
+on the same device source, a frame in 0.05 - 0.4 s instead of microseconds.
 
 What this is: a functional check of the device SOURCE (indexing, control flow, the order of float operations) that needs no GPU, and
 the way kernel variants that have not been on a GPU yet are checked bit for bit against the build that has.  What it is not: a
@@ -37,23 +37,21 @@ def emu_env(lib):
     return dict(os.environ, PLSVO_HIP_LIB=lib, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
 
 
-# the GPU tests that finish in seconds per case under emulation (a config-3 frame or a seed sweep is minutes)
-SUBSET = ("(test_gpu_parity and (halfsample and shape2 or matches_oracle and not config3 or every_launch_shape and not 512 or long_lines or edge_cases "
-          "or fewer_patches or border_features or single_linearisation or pose_optimizer and not seed_sweep or ldlt_flavour or errors_are_reported "
-          "or device_trace)) or test_golden or test_depth_filter or test_structure_opt or test_match_direct or test_reproject_trajectory "
-          "or (test_sequence and (matches_the_oracle_chain or grid_rule))")
+# every `-m gpu` test except: the ones that need a second process or RCCL, the C++ adapter (it links the product library), the
+# full-size property test (32768 frames), and the resident-vs-per-call chain comparison, whose 1e-9 tolerance is tuned to the gfx950
+# arithmetic (the two chains part on a float tie at another frame under the host's).  The seed sweeps run 12 seeds each here.
+SUBSET = "not rccl and not config4 and not bench_distributed and not test_gpu_adapter and not full_size and not resident_chain_equals"
 
 
 def test_gpu_parity_suite_passes_on_the_emulated_library(emu_lib):
     env = emu_env(emu_lib)
-    mods = ["test_gpu_parity.py", "test_golden.py", "test_depth_filter.py", "test_structure_opt.py", "test_match_direct.py",
-            "test_reproject_trajectory.py", "test_sequence.py"]
-    out = subprocess.run([sys.executable, "-m", "pytest", *[os.path.join(ROOT, "tests", m) for m in mods], "-m", "gpu", "-q", "-x", "-n", "4",
+    env["PLSVO_SWEEP_SEEDS"] = "12"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-m", "gpu", "-q", "-x", "-n", "6",
                           "-p", "no:cacheprovider", "-k", SUBSET], env=env, capture_output=True, text=True, cwd=ROOT)
     tail = out.stdout[-3000:] + out.stderr[-1000:]
     assert out.returncode == 0, tail
     last = [l for l in out.stdout.splitlines() if " passed" in l][-1]
-    assert " failed" not in last and int(last.split(" passed")[0].split()[-1]) >= 60, tail
+    assert " failed" not in last and int(last.split(" passed")[0].split()[-1]) >= 85, tail
 
 
 def run_variant(lib, out_pkl):
