@@ -161,6 +161,18 @@ __host__ __device__ inline size_t align_chi_window_offset(int threads, int cap, 
   o += (size_t)cap * (sizeof(int2) + sizeof(float)) + (size_t)scap * sizeof(int) + ((size_t)2 * scap + 2) * sizeof(float);
   return (o + 15) & ~(size_t)15;
 }
+// everything the kernel's own tables take; what the launch adds behind them is the staging area of PLSVO_LDS_IMG
+__host__ __device__ inline size_t align_lds_used(int threads, int cap, int scap, int chi_lds_pts) {
+  const size_t window = 1024 * sizeof(float), planes = (size_t)2 * chi_lds_pts * 16 * sizeof(float);
+  return align_chi_window_offset(threads, cap, scap) + (planes > window ? planes : window) + 16;
+}
+// PLSVO_LDS_IMG (experiment build, `make lds_img`): a pyramid level of the CURRENT image that fits into the LDS the workgroup has to
+// spare (AlignBatchDev::lds_img_bytes: level 3 of a 640x480 frame is 4.8 KB, next to eight frames' tables on a CU; a frame that has the CU
+// to itself fits level 1) is copied there once per level, and the 5x5 windows of every iteration are gathered from LDS instead of
+// through L2: half of all patch-iterations of the BASELINE workloads run on the coarsest level.  Same bytes, same arithmetic.
+#ifndef PLSVO_LDS_IMG
+#define PLSVO_LDS_IMG 0
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // The chi2 the solver compares (`new_chi2 > chi2_`, [ext] vk::NLLSSolver::optimizeGaussNewton) is
@@ -304,6 +316,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   float* s_abs = reinterpret_cast<float*>(s_meta + cap);                 // cap: sum |res| of the slot's 16 pixels, -1 = sample not in the image
   int* s_dead = reinterpret_cast<int*>(s_abs + cap);                     // scap: per segment, 0 = alive, k + 1 = culled at iteration k of this level
   float* s_lterm = reinterpret_cast<float*>(s_dead + scap);              // 2 * scap + 2: exact chi2 term of every line, two iterations; the two sums
+  unsigned char* const s_img = smem + align_lds_used(T, cap, scap, b.chi_lds_pts);   // PLSVO_LDS_IMG: b.lds_img_bytes bytes for a level of the current image
   float* s_win = reinterpret_cast<float*>(smem + align_chi_window_offset(T, cap, scap));   // 1024: two 32-slot windows of chi_terms, or the two planes themselves (chi_lds_pts)
 
 #ifdef PLSVO_TIMING
@@ -366,6 +379,17 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 
     if (tid == 0) { s_ctl[0] = 0; s_ctl[2] = 0; s_ctl[5] = 0; s_ctl[7] = 0; s_ctl[8] = 0; s_pose[27] = 0.0; }
     for (int p = tid; p < n_slots; p += T) s_meta[p] = make_int2(SLOT_HOLE, 0);
+#if PLSVO_LDS_IMG
+    // the level of the current image, row-major (pitch W), from the row-major slab: 16 bytes per thread and step; the slab has >= 64
+    // bytes of slack behind every level and the staging area 16, for the aligned dword pairs of the gather
+    const bool lds_img = W * Hh + 16 <= b.lds_img_bytes;   // kernel argument and level geometry: workgroup-uniform
+    if (lds_img) {
+      const uint8_t* const src = b.pyr.base + (size_t)job.cur_slot * b.pyr.slot_bytes + pyr_level_offset(job.width, job.height, level);
+      for (int i = tid * 16; i < W * Hh + 16; i += T * 16) *reinterpret_cast<uint4*>(s_img + i) = *reinterpret_cast<const uint4*>(src + i);
+    }
+#else
+    constexpr bool lds_img = false;
+#endif
     block_sync<T>();
 
     // ---- slot table: every feature fills the slots the host layout gives it ----
@@ -524,6 +548,17 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
             const int ui = (int)floorf(g.u), vi = (int)floorf(g.v);
             const int x0 = ui - 2, y0 = vi - 2 + 2 * half;
             int a0, a1, a2, b0, b1, b2;
+            if (lds_img) {   // (constexpr false unless built with PLSVO_LDS_IMG)
+              const int off = y0 * W + x0;
+              g.sh0 = off & 3; g.sh1 = (off + W) & 3; g.sh2 = (off + 2 * W) & 3;
+              a0 = off & ~3; a1 = (off + W) & ~3; a2 = (off + 2 * W) & ~3;
+              // (explicit LDS address space: left generic, the compiler merges this path with the global one into flat_load)
+              const PLSVO_LDS unsigned char* const li = (const PLSVO_LDS unsigned char*)s_img;
+              g.r0a = *(const PLSVO_LDS uint32_t*)(li + a0); g.r0b = *(const PLSVO_LDS uint32_t*)(li + a0 + 4);
+              g.r1a = *(const PLSVO_LDS uint32_t*)(li + a1); g.r1b = *(const PLSVO_LDS uint32_t*)(li + a1 + 4);
+              g.r2a = *(const PLSVO_LDS uint32_t*)(li + a2); g.r2b = *(const PLSVO_LDS uint32_t*)(li + a2 + 4);
+              return g;
+            }
             if constexpr (kTiled) {
               g.sh0 = g.sh1 = g.sh2 = x0 & 3;
               const int ca = tiled_col_offset(x0 & ~3), cb = tiled_col_offset((x0 & ~3) + 4);
@@ -876,10 +911,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 }
 
 // LDS bytes the kernel needs for slot capacity `cap` and segment capacity `scap` (host side helper)
-size_t align_level_lds_bytes(int threads, int cap, int scap, int chi_lds_pts) {
-  const size_t window = 1024 * sizeof(float), planes = (size_t)2 * chi_lds_pts * 16 * sizeof(float);
-  return align_chi_window_offset(threads, cap, scap) + (planes > window ? planes : window) + 16;
-}
+size_t align_level_lds_bytes(int threads, int cap, int scap, int chi_lds_pts) { return align_lds_used(threads, cap, scap, chi_lds_pts); }
 
 template <int T>
 static hipError_t launch_fused_T(const AlignBatchDev& b, int cap, int scap, int level_hi, int level_lo, int do_init, size_t lds, hipStream_t stream) {

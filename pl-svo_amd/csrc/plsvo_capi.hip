@@ -19,6 +19,10 @@
 #include "plsvo_dev.hpp"
 #include "plsvo_math.hpp"
 
+#ifndef PLSVO_LDS_IMG
+#define PLSVO_LDS_IMG 0
+#endif
+
 namespace plsvo_hip {
 // kernels (align_kernels.hip, poseopt_kernels.hip, pyramid_kernels.hip)
 size_t align_level_lds_bytes(int threads, int cap, int scap, int chi_lds_pts);
@@ -659,7 +663,19 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
   int max_pts = 0, chi_lds_pts = 0;
   for (const AlignJobDev& J : c->a_jobs) max_pts = std::max(max_pts, J.n_pts);
   pick_align_config(c, c->a_n, cap, scap, max_pts, &threads, &lds, &chi_lds_pts);
-  c->a_b.chi_lds_pts = chi_lds_pts; c->a_b.reserved1 = 0;
+  c->a_b.chi_lds_pts = chi_lds_pts; c->a_b.lds_img_bytes = 0;
+#if PLSVO_LDS_IMG   // experiment build (make lds_img): what is left of the workgroup's share of the CU's LDS may hold a level of the current image
+  {
+    const size_t wgs_per_cu = threads <= 64 ? 8 : threads <= 128 ? 4 : threads <= 256 ? 2 : 1;
+    const size_t share = std::min((size_t)(160 * 1024) / wgs_per_cu, c->lds_per_block);
+    size_t want = 0;   // the largest level image any job of the batch reads (+ 16 bytes for the aligned over-read)
+    if (have_levels) for (const AlignJobDev& J : c->a_jobs) want = std::max(want, (size_t)(J.width >> J.min_level) * (size_t)(J.height >> J.min_level) + 16);
+    size_t budget = share > lds + 256 ? share - lds - 256 : 0;
+    budget = std::min(budget, (want + 15) & ~(size_t)15) & ~(size_t)15;
+    c->a_b.lds_img_bytes = (int)budget;
+    lds += budget;
+  }
+#endif
   if (lds > c->lds_per_block) return fail(c, PLSVO_E_CAPACITY, "align_run: slot tables do not fit in LDS (too many features in one job)");
   const bool per_level = c->env_align_per_level;
   if (!per_level || !have_levels) {

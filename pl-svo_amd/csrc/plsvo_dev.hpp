@@ -117,7 +117,8 @@ struct AlignBatchDev {
   float* chi_terms;
   unsigned long long chi_plane;
   int chi_lds_pts;             // > 0: the two planes live in LDS instead (capacity in points per plane): small batches, where a
-  int reserved1;               //      workgroup has LDS to spare and nothing to hide a global store's acknowledge behind
+  int lds_img_bytes;           //      workgroup has LDS to spare and nothing to hide a global store's acknowledge behind.  lds_img_bytes: LDS bytes behind the
+                               //      kernel's own tables that it may stage a level of the current image in (0 unless built with PLSVO_LDS_IMG)
   double* poses;               // 7 per job: final model, contiguous (what a device-side consumer / the RCCL gather reads)
   PyrDesc pyr;
   plsvo_align_iterlog* log;    // log_cap per job, or null

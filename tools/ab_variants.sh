@@ -1,11 +1,12 @@
 #!/bin/bash
-# GPU call for library VARIANTS that have never run (round 3 left two: _bc = byte-record cache, _dpp = DPP near-tie chains).
+# GPU call for library VARIANTS that have never run (round 3 left four: _bc = byte-record cache, _li = coarse level of the current image in
+# LDS, _bcli = both, _dpp = DPP near-tie chains; all bit-identical to the default build under host emulation, tests/test_emu_parity.py).
 # For each suffix: the parity subset THROUGH that library (PLSVO_HIP_LIB), then two repetitions of the default bench command and
 # config 3, interleaved with the default build so that box-to-box differences cancel; then the single-frame latency sweep.
 # Build the variants in the container first (the .so files travel with the snapshot):
-#   make -C pl-svo_amd/csrc byte_cache
+#   make -C pl-svo_amd/csrc byte_cache lds_img bc_lds_img
 #   tools/build_patched.sh tools/patches/slot_parallel_exact_sum_dpp.patch dpp
-# usage: tools/ab_variants.sh <tag> _bc _dpp        -> gpurun_out/<tag>/
+# usage: tools/ab_variants.sh <tag> _bc _li _bcli _dpp        -> gpurun_out/<tag>/
 TAG=${1:-ab}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
