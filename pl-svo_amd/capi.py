@@ -5,6 +5,7 @@ raises if no gfx950 device can be used.  Nothing in this module imports or calls
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -48,6 +49,10 @@ def lib():
         raise ImportError(f"{LIB_PATH} not found: build it with `make -C pl-svo_amd/csrc` "
                           f"(or __graft_entry__.build()); plsvo_hip has no CPU fallback")
     L = C.CDLL(LIB_PATH)
+    if hasattr(L, "plsvo_emu_build"):
+        # tests/host/build_emu.sh: the device sources on a CPU wave emulator.  Only ever reached through an explicit PLSVO_HIP_LIB
+        # (tests/test_emu_parity.py); said out loud so that nothing measured or shipped can pass for the gfx950 library by accident.
+        sys.stderr.write(f"pl-svo_amd: {LIB_PATH} is a HOST EMULATION build of the kernels (test infrastructure), not the gfx950 library\n")
     ctxp = C.c_void_p
     vp = C.c_void_p
     sig = {
