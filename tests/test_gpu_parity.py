@@ -824,6 +824,78 @@ def test_full_size_properties(P, gpu_ctx):
         assert ang < 2e-4 and dist < 2e-3
 
 
+def _device_bytes(host):
+    """`host` (uint8 array) in memory the library's device pointers can address: HBM through torch on a GPU box; the array itself when
+    the library is the host emulation build (tests/test_emu_parity.py), whose device memory is host memory.  -> (keep-alive, pointer, read-back)"""
+    import torch
+    if torch.cuda.is_available():
+        t = torch.from_numpy(host).cuda()
+        torch.cuda.synchronize()
+        return t, t.data_ptr(), lambda: t.cpu().numpy()
+    return host, host.ctypes.data, lambda: host
+
+
+@pytest.mark.gpu
+def test_abi_utility_entry_points(P, ob, gpu_ctx):
+    """The entry points around the hot path that the benchmark and a device-resident caller use: pyramids built from level-0 images that
+    are already in device memory (strided rows), slot-to-slot copies, the one-call form, pose copies on the device, work counters,
+    kernel timers, device info -- each against the oracle or against the per-call path."""
+    import ctypes as C
+    W, H, nlev = 162, 122, 3                     # odd quarter widths: the 16-byte fast path and the byte tail of copy_level0 both run
+    rng = np.random.default_rng(77)
+    stride = W + 14
+    imgs = rng.integers(0, 256, (3, H, stride), dtype=np.uint8)
+    keep, d_ptr, _ = _device_bytes(imgs.reshape(-1).copy())
+    gpu_ctx.config_pyramids(6, W, H, nlev)
+    gpu_ctx.build_pyramids_dev(0, 3, d_ptr, stride, H * stride, 0)
+    gpu_ctx.synchronize()
+    for k in range(3):
+        for d, o in zip(gpu_ctx.download_pyramid(k), ob.build_pyramid(np.ascontiguousarray(imgs[k, :, :W]), nlev, 0)):
+            assert np.array_equal(d, o)
+    gpu_ctx.copy_slots(3, 0, 3)
+    for k in range(3):
+        for d, o in zip(gpu_ctx.download_pyramid(3 + k), gpu_ctx.download_pyramid(k)):
+            assert np.array_equal(d, o)
+    with pytest.raises(P.capi.PlsvoError):
+        gpu_ctx.copy_slots(1, 0, 3)              # overlapping ranges
+    # one-call form == stage / run / fetch; the copied slots (tiled mirror included) align like the originals
+    st, ref, cur, job = Hh.make_case(ob, 31, 320, 240, 60, 20, 4, 3, 1)
+    gpu_ctx.config_pyramids(4, 320, 240, 4)
+    gpu_ctx.upload_pyramid(0, ref)
+    gpu_ctx.upload_pyramid(1, cur)
+    gpu_ctx.copy_slots(2, 0, 2)
+    gpu_ctx.align_set_trace(0)
+    gpu_ctx.set_profiling(True)
+    gpu_ctx.reset_profiling()
+    r0 = gpu_ctx.sparse_align(job)
+    out = P.abi.AlignOut()
+    alive = np.ones(max(job.n_seg, 1), dtype=np.uint8)
+    out.seg_alive_out = alive.ctypes.data_as(P.abi.c_u8_p)
+    assert gpu_ctx.L.plsvo_sparse_align(gpu_ctx.h, C.byref(job.c), C.byref(out)) == 0
+    assert np.array_equal(np.array(list(out.T_cur_from_ref)), r0.T) and np.array_equal(alive[:job.n_seg], r0.seg_alive)
+    st2, ref2, cur2, job2 = Hh.make_case(ob, 31, 320, 240, 60, 20, 4, 3, 1)
+    job2.c.ref_slot, job2.c.cur_slot = 2, 3
+    for T in (0, 64):                            # 64: the shape that reads the tiled mirror and keeps the chi2 terms in HBM planes
+        gpu_ctx.set_launch_shapes(align_threads=T)
+        job.c.ref_slot, job.c.cur_slot = 0, 1
+        a = gpu_ctx.sparse_align(job)
+        b = gpu_ctx.sparse_align(job2)
+        assert np.array_equal(a.T, b.T) and a.n_meas == b.n_meas
+    levels, iters = gpu_ctx.align_work()
+    assert 0 < levels <= iters and 0 < gpu_ctx.align_work_points() <= iters      # (point patch-iterations whose terms went to HBM)
+    gpu_ctx.set_launch_shapes(align_threads=0)
+    ms, launches = gpu_ctx.kernel_time(1)        # PLSVO_K_ALIGN_LEVEL: the fused alignment launch
+    assert launches >= 5 and ms > 0.0
+    gpu_ctx.set_profiling(False)
+    # the result poses where a device-side consumer reads them
+    keep2, d_dst, back = _device_bytes(np.zeros(7 * 8, np.uint8))
+    gpu_ctx.align_copy_poses(d_dst)
+    gpu_ctx.synchronize()
+    assert np.array_equal(back().view(np.float64), b.T)
+    name, cus, mem = gpu_ctx.device_info()
+    assert cus > 0 and mem > 0 and name
+
+
 @pytest.mark.gpu
 def test_gather_poses_over_a_single_rank_rccl_communicator(P, gpu_ctx):
     """plsvo_gather_poses (C ABI, ncclAllGather on the ctx stream) with a world of one rank: the only configuration a
