@@ -824,6 +824,46 @@ def test_full_size_properties(P, gpu_ctx):
         assert ang < 2e-4 and dist < 2e-3
 
 
+@pytest.mark.gpu
+def test_every_entry_point_rejects_malformed_arguments(P, gpu_ctx):
+    """Negative counts, missing arrays and impossible parameters come back as PLSVO_E_INVALID with a message naming the entry point --
+    before anything is enqueued -- and leave the context usable."""
+    import ctypes as C
+    A, L, h = P.abi, gpu_ctx.L, gpu_ctx.h
+    gpu_ctx.config_pyramids(2, 160, 120, 3)
+
+    def rejected(rc, name):
+        msg = (L.plsvo_hip_last_error(h) or b"").decode()
+        assert rc != 0 and name in msg, (name, rc, msg)
+
+    so = A.StructOptIn(); so.n_pts = -1
+    rejected(L.plsvo_structure_optimize(h, C.byref(so), C.byref(A.StructOptOut())), "structure_optimize")
+    so = A.StructOptIn(); so.n_pts = 3                       # landmarks without their arrays
+    rejected(L.plsvo_structure_optimize(h, C.byref(so), C.byref(A.StructOptOut())), "structure_optimize")
+    mi = A.MatchIn()                                         # n_pyr_levels = 0
+    rejected(L.plsvo_match_direct(h, C.byref(mi), C.byref(A.MatchOut())), "match_direct")
+    mi = A.MatchIn(); mi.n = 4; mi.n_frames = 1; mi.n_pyr_levels = 3
+    rejected(L.plsvo_match_direct(h, C.byref(mi), C.byref(A.MatchOut())), "match_direct")
+    rejected(L.plsvo_reproject(h, C.byref(A.ReprojectIn()), C.byref(A.ReprojectOut())), "reproject")          # cell_size = 0
+    rejected(L.plsvo_chain_stage(h, 0, None, None), "chain_stage")
+    cp = A.ChainParams()                                     # cell_size = 0
+    rejected(L.plsvo_chain_stage(h, 1, C.byref(A.ChainIn()), C.byref(cp)), "chain_stage")
+    rejected(L.plsvo_frame_step_batch(h, 1, C.byref(A.ChainIn()), C.byref(cp), C.byref(A.ChainOut())), "chain_stage")
+    rejected(L.plsvo_update_seeds(h, C.byref(A.SeedsIn()), C.byref(A.SeedsOut())), "update_seeds")            # n_pyr_levels = 0
+    si = A.SeedsIn(); si.n_pyr_levels = 3; si.n_pt = 2; si.n_frames = 1; si.cam.width, si.cam.height = 160, 120
+    rejected(L.plsvo_update_seeds(h, C.byref(si), C.byref(A.SeedsOut())), "update_seeds")                     # seeds without their arrays
+    po = A.PoseOptIn(); po.n_pts = -2
+    rejected(L.plsvo_pose_optimize(h, C.byref(po), C.byref(A.PoseOptOut())), "poseopt_stage")
+    po = A.PoseOptIn(); po.n_pts = 5
+    rejected(L.plsvo_pose_optimize(h, C.byref(po), C.byref(A.PoseOptOut())), "poseopt_stage")
+    rejected(L.plsvo_poseopt_copy_poses(h, None), "poseopt_copy_poses")
+    rejected(L.plsvo_hip_kernel_time(h, 99, None, None), "kernel_time")
+    # still usable
+    img = np.random.default_rng(5).integers(0, 256, (120, 160), dtype=np.uint8)
+    gpu_ctx.build_pyramid(0, img, 0)
+    assert np.array_equal(gpu_ctx.download_level(0, 0), img)
+
+
 def _device_bytes(host):
     """`host` (uint8 array) in memory the library's device pointers can address: HBM through torch on a GPU box; the array itself when
     the library is the host emulation build (tests/test_emu_parity.py), whose device memory is host memory.  -> (keep-alive, pointer, read-back)"""
