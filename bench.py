@@ -514,6 +514,8 @@ def main():
                 "roofline": roofline,
                 "kernel_ms_per_step": {"align_fused": round(lvl_ms / args.steps, 4), "pose_opt": round(pose_ms / args.steps, 4)},
             }
+            if os.environ.get("PLSVO_HIP_LIB"):   # an A/B build of the library (tools/ab_variants.sh): the line says which one it measured
+                result["config"]["library"] = os.path.basename(os.environ["PLSVO_HIP_LIB"])
             if local_shards > 1:
                 # every shard alone: K steps, then a host synchronisation (what one GPU of the 8-GPU deployment would do per step)
                 per = []
