@@ -54,6 +54,21 @@ def test_gpu_parity_suite_passes_on_the_emulated_library(emu_lib):
     assert " failed" not in last and int(last.split(" passed")[0].split()[-1]) >= 87, tail
 
 
+def test_cpp_adapter_on_the_emulated_library(emu_lib):
+    """The C++ drop-in (pl-svo_amd/host/plsvo/hip_adapter.hpp, built into host/adapter_driver by __graft_entry__.build()) links the
+    product library; with the emulated one preloaded its calls land there, and the adapter tests -- reference-side mutations, direct
+    matcher, depth filter, verbose output, each against the oracle -- run without a GPU.  (The sanitizer variant of the driver is left
+    out: its runtime insists on being the first preloaded library.)"""
+    if not os.path.exists(os.path.join(ROOT, "pl-svo_amd", "host", "adapter_driver")):
+        pytest.skip("host/adapter_driver not built (run __graft_entry__.build())")
+    env = emu_env(emu_lib)
+    env["LD_PRELOAD"] = emu_lib
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_adapter.py"), "-m", "gpu", "-q", "-p", "no:cacheprovider",
+                          "-k", "not sanitizers"], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0 and " failed" not in out.stdout, out.stdout[-3000:] + out.stderr[-1000:]
+    assert "4 passed" in out.stdout, out.stdout[-500:]
+
+
 def run_variant(lib, out_pkl):
     env = emu_env(lib)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host", "emu_variant_runner.py"), str(out_pkl)], env=env, capture_output=True, text=True)
