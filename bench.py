@@ -476,24 +476,31 @@ def main():
                     a_, b_ = sh["ctx"].align_work()
                     patch_levels += a_; patch_iters += b_
                 pt_iters = sum(sh["ctx"].align_work_points() for sh in shard)
+                # A/B builds of the kernel move other bytes (pl-svo_amd/csrc/Makefile): the byte-record cache streams 64 B per patch-iteration
+                # instead of 192 and writes 64 B per patch-level; the offline PMC figure belongs to the default build only
+                flags = (capi.lib().plsvo_hip_build_flags() or b"").decode().split() if hasattr(capi.lib(), "plsvo_hip_build_flags") else []
+                cache_b = 64 if "byte_cache" in flags else 192
+                OWN_ITER = OWN_BYTES_PER_PATCH_ITER - 192 + cache_b
+                OWN_LEVEL = OWN_BYTES_PER_PATCH_LEVEL - 192 - 192 + (84 if "byte_cache" in flags else 192) + cache_b   # 7 rows x 3 dwords read, one record written
+                MIN_ITER, MIN_LEVEL = MIN_BYTES_PER_PATCH_ITER - 192 + cache_b, MIN_BYTES_PER_PATCH_LEVEL - 192 + cache_b
                 survey_bytes = patch_levels * BYTES_PER_PATCH_LEVEL + patch_iters * BYTES_PER_PATCH_ITER
-                own_bytes = patch_levels * OWN_BYTES_PER_PATCH_LEVEL + patch_iters * OWN_BYTES_PER_PATCH_ITER + pt_iters * CHI_BYTES_PER_POINT_ITER
-                min_bytes = patch_levels * MIN_BYTES_PER_PATCH_LEVEL + patch_iters * MIN_BYTES_PER_PATCH_ITER + pt_iters * CHI_BYTES_PER_POINT_ITER
+                own_bytes = patch_levels * OWN_LEVEL + patch_iters * OWN_ITER + pt_iters * CHI_BYTES_PER_POINT_ITER
+                min_bytes = patch_levels * MIN_LEVEL + patch_iters * MIN_ITER + pt_iters * CHI_BYTES_PER_POINT_ITER
                 launches_per_step = max(lvl_launches, 1) / max(args.steps, 1)          # one per shard
                 avg_ms = lvl_ms / max(lvl_launches, 1)
                 per_launch = lambda nbytes: nbytes / launches_per_step
                 rate = lambda nbytes: per_launch(nbytes) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
                 achieved = rate(min_bytes)
-                traffic, traffic_src, traffic_raw = offline_traffic(n_local, args.config) if args.config in (2, 3) else (None, None, None)
+                traffic, traffic_src, traffic_raw = offline_traffic(n_local, args.config) if (args.config in (2, 3) and not flags) else (None, None, None)
                 roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                             "traffic": traffic, "traffic_source": traffic_src, "traffic_uncorrected": traffic_raw,
                             "kernel": "align_fused_kernel", "avg_launch_ms": round(avg_ms, 4), "launches": int(lvl_launches),
                             "algorithmic_bytes_per_launch": int(per_launch(min_bytes)),
-                            "definition": "bytes this formulation cannot avoid moving (per patch-iteration: 25 B window of the current image + 192 B "
-                                          "cached reference patch and gradients + 24 B 3-D point, + 64 B of chi2 terms per POINT patch-iteration; per "
-                                          "patch-level: 49 B reference window + 216 B cache and point written; device-side work counters) / hipEvent time "
+                            "definition": ("bytes this formulation cannot avoid moving (per patch-iteration: 25 B window of the current image + %d B "
+                                          "cached reference patch + 24 B 3-D point, + 64 B of chi2 terms per POINT patch-iteration; per "
+                                          "patch-level: 49 B reference window + %d B cache and point written; device-side work counters) / hipEvent time "
                                           "of the launch on the launch stream / 8 TB/s.  A bound: no workload can exceed 1.  The kernel's own requests "
-                                          "(sector-granular gathers: kernel_requested_*) and the memory-side traffic (traffic, offline PMC passes) sit above it",
+                                          "(sector-granular gathers: kernel_requested_*) and the memory-side traffic (traffic, offline PMC passes) sit above it") % (cache_b, cache_b + 24),
                             "kernel_requested_bytes_per_launch": int(per_launch(own_bytes)),
                             "kernel_requested_GBps": round(rate(own_bytes), 1),
                             "traffic_over_requested": round(traffic / per_launch(own_bytes), 3) if traffic else None,
@@ -516,6 +523,8 @@ def main():
             }
             if os.environ.get("PLSVO_HIP_LIB"):   # an A/B build of the library (tools/ab_variants.sh): the line says which one it measured
                 result["config"]["library"] = os.path.basename(os.environ["PLSVO_HIP_LIB"])
+                if hasattr(capi.lib(), "plsvo_hip_build_flags"):
+                    result["config"]["build_flags"] = (capi.lib().plsvo_hip_build_flags() or b"").decode().strip()
             if local_shards > 1:
                 # every shard alone: K steps, then a host synchronisation (what one GPU of the 8-GPU deployment would do per step)
                 per = []

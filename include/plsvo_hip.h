@@ -577,6 +577,9 @@ int plsvo_hip_reset_profiling(plsvo_ctx* ctx);
 
 /* library / device info */
 const char* plsvo_hip_version(void);
+/* compile-time experiment switches of THIS build of the alignment kernel, space-separated ("" for the default build; "byte_cache",
+ * "lds_img": pl-svo_amd/csrc/Makefile's A/B targets).  bench.py prices its roofline with the bytes the build really moves. */
+const char* plsvo_hip_build_flags(void);
 int plsvo_hip_device_info(plsvo_ctx* ctx, char* name, int name_len, int* cu_count, size_t* hbm_bytes);
 
 #ifdef __cplusplus

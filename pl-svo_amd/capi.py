@@ -27,7 +27,7 @@ SYMBOLS = [
     "plsvo_chain_stage", "plsvo_chain_run", "plsvo_chain_fetch", "plsvo_frame_step_batch", "plsvo_chain_poses_dev",
     "plsvo_gather_poses",
     "plsvo_hip_set_profiling", "plsvo_hip_kernel_time", "plsvo_hip_reset_profiling",
-    "plsvo_hip_version", "plsvo_hip_device_info",
+    "plsvo_hip_version", "plsvo_hip_build_flags", "plsvo_hip_device_info",
 ]
 
 
@@ -108,6 +108,7 @@ def lib():
         "plsvo_hip_kernel_time": (C.c_int, [ctxp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
         "plsvo_hip_reset_profiling": (C.c_int, [ctxp]),
         "plsvo_hip_version": (C.c_char_p, []),
+        "plsvo_hip_build_flags": (C.c_char_p, []),
         "plsvo_hip_device_info": (C.c_int, [ctxp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     }
     for name, (res, args) in sig.items():

@@ -913,6 +913,19 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 // LDS bytes the kernel needs for slot capacity `cap` and segment capacity `scap` (host side helper)
 size_t align_level_lds_bytes(int threads, int cap, int scap, int chi_lds_pts) { return align_lds_used(threads, cap, scap, chi_lds_pts); }
 
+}  // namespace plsvo_hip
+extern "C" const char* plsvo_hip_build_flags(void) {
+  return ""
+#if PLSVO_BYTE_CACHE
+         "byte_cache "
+#endif
+#if PLSVO_LDS_IMG
+         "lds_img "
+#endif
+      ;
+}
+namespace plsvo_hip {
+
 template <int T>
 static hipError_t launch_fused_T(const AlignBatchDev& b, int cap, int scap, int level_hi, int level_lo, int do_init, size_t lds, hipStream_t stream) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_fused_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
