@@ -10,8 +10,13 @@ CXX=${EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}
 mkdir -p $OUT
 FLAGS="-x c++ -D__HIPCC__ -std=c++17 -O1 -fPIC -ffp-contract=off -Wno-unknown-pragmas -Wno-unknown-attributes -Wno-ignored-attributes -Wno-unused-value -I $R/tests/host/emu -I $SRC $*"
 OBJS=""
+# EMU_CONTRACT=fast: fma contraction (-ffp-contract=fast-honor-pragmas -mfma: hipcc's own default mode) for the translation units the device Makefile compiles with hipcc's default
+# (contraction allowed), off for the three it compiles with -ffp-contract=off -- the host compiler's choice of WHICH products to fuse is
+# its own, so this is a probe of how much the results depend on that choice, not a model of the gfx950 code.  Default: off everywhere.
 for f in align_kernels poseopt_kernels pyramid_kernels structopt_kernels match_kernels seeds_kernels chain_kernels plsvo_capi; do
-  $CXX $FLAGS -c $SRC/$f.hip -o $OUT/$f.o &
+  C=""
+  case $f in structopt_kernels|match_kernels|seeds_kernels) ;; *) [ "$EMU_CONTRACT" = fast ] && C="-ffp-contract=fast-honor-pragmas -mfma" ;; esac
+  $CXX $FLAGS $C -c $SRC/$f.hip -o $OUT/$f.o &
   OBJS="$OBJS $OUT/$f.o"
 done
 $CXX $FLAGS -c $R/tests/host/emu_runtime.cpp -o $OUT/emu_runtime.o &
