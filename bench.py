@@ -365,6 +365,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # DRY RUN (tests/test_emu_parity.py only): PLSVO_BENCH_DRY_RUN=1 together with a host emulation build of the library runs this very
+    # script on the CPU -- same staging, same calls, same JSON assembly, tiny batch -- so that a mistake in it shows up in the CPU suite
+    # and not at the end of a round.  Its line says what it is; without the emulated library the variable has no effect.
+    dry = os.environ.get("PLSVO_BENCH_DRY_RUN") == "1" and hasattr(importlib.import_module("pl-svo_amd").capi.lib(), "plsvo_emu_build")
+    if dry:
+        import contextlib
+        import types
+        torch.cuda.set_device = lambda *_a, **_k: None
+        torch.cuda.synchronize = lambda *_a, **_k: None
+        torch.cuda.Stream = lambda *_a, **_k: types.SimpleNamespace(cuda_stream=None)
+        torch.cuda.stream = lambda *_a, **_k: contextlib.nullcontext()
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.dist_selftest
     if use_dist:
@@ -372,11 +383,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
 
     P = importlib.import_module("pl-svo_amd")
     capi, synth, abi, D = P.capi, P.synth, P.abi, P.dist
-    if hasattr(capi.lib(), "plsvo_emu_build"):   # tests/host/build_emu.sh: the device sources on a CPU wave emulator -- a test vehicle, never a measurement
+    if hasattr(capi.lib(), "plsvo_emu_build") and not dry:   # tests/host/build_emu.sh: the device sources on a CPU wave emulator -- a test vehicle, never a measurement
         raise SystemExit("bench.py: PLSVO_HIP_LIB names a host emulation build of the library; the benchmark runs the gfx950 library only")
     B = args.batch if args.batch > 0 else cfg["batch"]
     W, H = cfg["W"], cfg["H"]
@@ -513,7 +524,8 @@ def main():
                 "metric": cfg["metric"],
                 "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic" if not dry else "synthetic -- DRY RUN on the host emulation build of the library: NOT a measurement",
                 "config": {"workload": cfg["workload"], "streams_per_gpu": n_local, "global_batch": world * n_local,
                            "shards": shards_total, "streams_per_shard": B,
                            "parallelism": (f"streams sharded x{world}, pose all-gather through plsvo_gather_poses (RCCL)" if world > 1 else

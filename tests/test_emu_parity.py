@@ -69,6 +69,38 @@ def test_cpp_adapter_on_the_emulated_library(emu_lib):
     assert "4 passed" in out.stdout, out.stdout[-500:]
 
 
+@pytest.mark.parametrize("argv", [["--batch", "4", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.4", "--no-latency"],
+                                  ["--config", "5", "--batch", "6", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.4"],
+                                  ["--config", "4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]], ids=["config2", "config5", "config4-shards"])
+def test_bench_script_dry_run(emu_lib, argv):
+    """bench.py itself -- staging, the timed control flow, the work counters, the roofline and CPU-baseline blocks, the JSON line --
+    executed end to end on the CPU: PLSVO_BENCH_DRY_RUN=1 is honoured only together with the emulated library and the line says so.
+    The numbers mean nothing; that the script runs, and prints the contract's fields, is the point."""
+    import json
+    env = emu_env(emu_lib)
+    env["PLSVO_BENCH_DRY_RUN"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert "DRY RUN" in d["data"] and d["config"]["library"] == "libplsvo_hip_emu.so" and d["value"] > 0
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["algorithmic_bytes_per_launch"] > 0 and r["launches"] >= 1
+    if "--no-cpu-baseline" not in argv:
+        cb = d["cpu_baseline"]
+        assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["sample"]
+
+
+def test_bench_script_refuses_the_emulated_library_without_the_dry_run_switch(emu_lib):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "2", "--steps", "1"], env=emu_env(emu_lib), capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
 def run_variant(lib, out_pkl):
     env = emu_env(lib)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host", "emu_variant_runner.py"), str(out_pkl)], env=env, capture_output=True, text=True)
