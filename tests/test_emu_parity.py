@@ -101,6 +101,18 @@ def test_bench_script_refuses_the_emulated_library_without_the_dry_run_switch(em
     assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
 
 
+def test_smoke_entry_dry_run(emu_lib):
+    """__graft_entry__.smoke() -- the function the driver runs on the MI355X before the benchmark -- executed on the CPU against the
+    emulated library (PLSVO_SMOKE_DRY_RUN=1; without the switch it refuses that library)."""
+    env = emu_env(emu_lib)
+    code = "import __graft_entry__ as g; g.smoke()"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode != 0 and "host emulation build" in out.stderr
+    env["PLSVO_SMOKE_DRY_RUN"] = "1"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0 and "smoke DRY RUN on the host emulation build ok" in out.stdout, out.stdout[-1000:] + out.stderr[-2000:]
+
+
 def run_variant(lib, out_pkl):
     env = emu_env(lib)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host", "emu_variant_runner.py"), str(out_pkl)], env=env, capture_output=True, text=True)
