@@ -69,7 +69,7 @@ def test_cpp_adapter_on_the_emulated_library(emu_lib):
     assert "4 passed" in out.stdout, out.stdout[-500:]
 
 
-@pytest.mark.parametrize("argv", [["--batch", "4", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.4", "--no-latency"],
+@pytest.mark.parametrize("argv", [["--batch", "8", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.4"],
                                   ["--config", "5", "--batch", "6", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.4"],
                                   ["--config", "4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]], ids=["config2", "config5", "config4-shards"])
 def test_bench_script_dry_run(emu_lib, argv):
@@ -91,6 +91,8 @@ def test_bench_script_dry_run(emu_lib, argv):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["algorithmic_bytes_per_launch"] > 0 and r["launches"] >= 1
+    if argv[0] == "--batch":     # the default workload also carries the small-batch leg
+        assert d["latency"]["B1"]["frames_per_s"] > 0 and d["latency"]["B8"]["frames_per_s"] > 0, d.get("latency")
     if "--no-cpu-baseline" not in argv:
         cb = d["cpu_baseline"]
         assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["sample"]
