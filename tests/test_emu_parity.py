@@ -71,7 +71,7 @@ def test_cpp_adapter_on_the_emulated_library(emu_lib):
 
 @pytest.mark.parametrize("argv", [["--batch", "8", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.4"],
                                   ["--config", "5", "--batch", "6", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.4"],
-                                  ["--config", "4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]], ids=["config2", "config5", "config4-shards"])
+                                  ["--config", "4", "--batch", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]], ids=["config2", "config5", "config4-shards"])
 def test_bench_script_dry_run(emu_lib, argv):
     """bench.py itself -- staging, the timed control flow, the work counters, the roofline and CPU-baseline blocks, the JSON line --
     executed end to end on the CPU: PLSVO_BENCH_DRY_RUN=1 is honoured only together with the emulated library and the line says so.
