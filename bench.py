@@ -389,7 +389,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dry:   # the CPU dry run of the N > 1 path: gloo ranks, torch.distributed's all-gather in place of the C ABI's RCCL one
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cpu") if dry else torch.device("cuda", local_rank)
 
     P = importlib.import_module("pl-svo_amd")
@@ -447,7 +450,7 @@ def main():
             for v, sh in enumerate(shard):
                 sh["ctx"].poseopt_copy_poses(t.data_ptr() + v * B * 7 * 8)
 
-        comm = P.rccl.comm_over_process_group() if use_dist else None       # the gather is the C ABI's, on the library's stream
+        comm = P.rccl.comm_over_process_group() if (use_dist and not dry) else None       # the gather is the C ABI's, on the library's stream
         def gather(local, out):
             ctx.gather_poses(comm, local.data_ptr(), n_local, out.data_ptr())
 
@@ -457,7 +460,7 @@ def main():
                 sh["ctx"].reset_profiling()
         elapsed, gathered = D.timed_sharded_steps(step_local, copy_local, local_poses, args.steps, args.warmup,
                                                   device_sync=lambda: torch.cuda.synchronize(dev), before_timed=timers_on,
-                                                  gather=gather if use_dist else None, force_gather=args.dist_selftest)
+                                                  gather=gather if (use_dist and not dry) else None, force_gather=args.dist_selftest)
         for sh in shard:
             sh["ctx"].set_profiling(False)
         if comm is not None:

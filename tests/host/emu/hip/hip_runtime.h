@@ -122,7 +122,7 @@ struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcess
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "wave_emu: error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 8; return hipSuccess; }   // (an 8-GPU node: one emulated device per rank of a dry run)
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   memset(p, 0, sizeof(*p));
   snprintf(p->name, sizeof(p->name), "wave_emu host emulation"); snprintf(p->gcnArchName, sizeof(p->gcnArchName), "host");

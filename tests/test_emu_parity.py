@@ -98,6 +98,31 @@ def test_bench_script_dry_run(emu_lib, argv):
         assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["sample"]
 
 
+@pytest.mark.parametrize("argv", [["--batch", "3", "--steps", "2", "--warmup", "1"], ["--config", "4", "--batch", "1", "--steps", "1", "--warmup", "0"]],
+                         ids=["config2-2ranks", "config4-2ranks"])
+def test_bench_script_dry_run_with_two_ranks(emu_lib, argv):
+    """The N > 1 path of bench.py exactly as the driver launches it (torch.distributed.run, one rank per GPU) -- rank / seed partition, the
+    shards of a rank, the timed control flow with its barrier and MAX over ranks, the pose all-gather, rank 0's line -- with two gloo
+    ranks on the CPU, each on its own emulated device.  (The gather is torch.distributed's here; the C ABI's RCCL one needs GPUs.)"""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = emu_env(emu_lib)
+    env["PLSVO_BENCH_DRY_RUN"] = "1"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", *argv, "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "DRY RUN" in d["data"] and d["value"] > 0
+    per_rank = d["config"]["streams_per_gpu"]
+    assert d["config"]["global_batch"] == 2 * per_rank and d["config"]["shards"] == (8 if "--config" in argv else 2)
+
+
 def test_bench_script_refuses_the_emulated_library_without_the_dry_run_switch(emu_lib):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "2", "--steps", "1"], env=emu_env(emu_lib), capture_output=True, text=True, cwd=ROOT)
     assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
