@@ -101,6 +101,14 @@ __device__ __forceinline__ float robust_weight(float a) {
 #ifndef PLSVO_BYTE_CACHE
 #define PLSVO_BYTE_CACHE 0
 #endif
+// PLSVO_TIE_RECOMPUTE (experiment build, `make tie_recompute`): a near tie whose per-pixel terms were NOT kept (HBM planes are written only
+// while the solver is armed: 19 of 2083 near ties over 1000 emulated config-2 frames, 4 of which then leave the oracle's path -- among
+// them the sweep's worst error, 1.6e-3 of the inter-frame translation) re-runs the pixel arithmetic of the point patches for the
+// missing iteration(s) -- stage 1: this iteration's pose, stage 2: the previous one's (old_model_) -- writes the planes, and only then
+// decides.  Nothing changes on the path every other iteration takes; with the switch off the stage loop folds away.
+#ifndef PLSVO_TIE_RECOMPUTE
+#define PLSVO_TIE_RECOMPUTE 0
+#endif
 template <bool TILED>
 __device__ __forceinline__ uint2 load_row8_raw(const uint8_t* img, int pitch, int x, int y) {   // bytes [x, x+8) of row y (same requests as load_row7)
   uint32_t d0, d1, d2, sh;
@@ -347,6 +355,9 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     s_pose[26] = st->chi2; s_pose[28] = 0.0; s_pose[29] = 0.0; s_pose[31] = 0.0;
     for (int k = 0; k < 32; ++k) s_tot[k] = 0.0;
     s_ctl[1] = st->stop; s_ctl[3] = 0; s_ctl[6] = 0; s_ctl[9] = 0;
+#if PLSVO_TIE_RECOMPUTE
+    s_ctl[10] = 0;
+#endif
   }
   if (b.chi_lds_pts > 0) {   // LDS planes: the slots between the last point and the next multiple of 4 are read by the exact sums: +0
     const int tail0 = job.n_pts * 16, tail1 = ((job.n_pts + 3) & ~3) * 16;
@@ -487,24 +498,51 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     const double f_sel = half ? job.fy : job.fx, c_sel = half ? job.cy : job.cx;
 
     for (int iter = 0; iter < job.n_iter; ++iter) {
-      // this lane's share of the pose: the row of R (and t) of its image coordinate, and the depth row
-      const double Ra = s_pose[3 * half], Rb = s_pose[3 * half + 1], Rc = s_pose[3 * half + 2], ta = s_pose[9 + half];
-      const double Rz0 = s_pose[6], Rz1 = s_pose[7], Rz2 = s_pose[8], tz = s_pose[11];
+#if PLSVO_TIE_RECOMPUTE
+     int redo_mask = 0;   // bit 0 = this iteration's terms are missing, bit 1 = the previous iteration's (workgroup-uniform)
+     for (int stage = 0; stage < 3; ++stage) {   // 0: the iteration proper; 1, 2: terms-only re-runs of a near tie (rare)
+      if (stage > 0 && !(redo_mask & stage)) continue;
+      const bool terms_only = stage > 0;
+      const int last_stage = (redo_mask & 2) ? 2 : ((redo_mask & 1) ? 1 : 0);
+#else
+     {
+      constexpr int stage = 0, last_stage = 0;
+      constexpr bool terms_only = false;
+#endif
+      // this lane's share of the pose: the row of R (and t) of its image coordinate, and the depth row (stage 2: of the previous
+      // iteration's pose, whose rotation matrix thread 0 left in s_red -- free between the reduction and the next pass)
+#if PLSVO_TIE_RECOMPUTE
+      const double* const pose_rt = (stage == 2) ? s_red : s_pose;
+#else
+      const double* const pose_rt = s_pose;
+#endif
+      const double Ra = pose_rt[3 * half], Rb = pose_rt[3 * half + 1], Rc = pose_rt[3 * half + 2], ta = pose_rt[9 + half];
+      const double Rz0 = pose_rt[6], Rz1 = pose_rt[7], Rz2 = pose_rt[8], tz = pose_rt[11];
 
       // HBM planes are written only while the solver is ARMED: the step that led to this iteration was small (||x||_inf < 1e-3), which is
       // when two successive chi2 values can come within the rounding noise of the reference's sums (99 % of the near ties of 60
       // config-2 frames had both iterations armed; 64 % of all iterations are).  LDS planes (small batches) are always written.
-      const bool store_chi = b.chi_lds_pts > 0 || s_ctl[7] != 0;
-      float* const chi_it = b.chi_terms + (size_t)(iter & 1) * b.chi_plane + (size_t)job.pt_off * 16;   // this iteration's plane of the points' chi2 terms
+      const bool store_chi = terms_only || b.chi_lds_pts > 0 || s_ctl[7] != 0;
+#if PLSVO_TIE_RECOMPUTE
+      const int chi_par = (stage == 2) ? ((iter & 1) ^ 1) : (iter & 1);
+#else
+#define chi_par (iter & 1)
+#endif
+      float* const chi_it = b.chi_terms + (size_t)chi_par * b.chi_plane + (size_t)job.pt_off * 16;   // this iteration's plane of the points' chi2 terms (stage 2: the previous iteration's)
 
       double acc[32];   // 0..20 H (upper, row-major), 21..26 Jres, 27 chi2, 28 n_meas, 29 evals, 30 evals of point patches whose chi2 terms went to HBM, 31 unused
 #pragma unroll
       for (int k = 0; k < 32; ++k) acc[k] = 0.0;
 
       // pass 0: residual sums only (two-pass levels); pass 1: the (fused) pass that accumulates
-      for (int pass = long_lines ? 0 : 1; pass < 2; ++pass) {
-        const bool write_abs = !long_lines || pass == 0;
-        const bool accumulate = pass == 1;
+      for (int pass = (long_lines && !terms_only) ? 0 : 1; pass < 2; ++pass) {
+        const bool write_abs = (!long_lines || pass == 0) && !terms_only;
+        const bool accumulate = pass == 1 && !terms_only;
+#if PLSVO_TIE_RECOMPUTE
+        const int n_rounds_slots = terms_only ? min(n_slots, job.n_pts) : n_slots;   // a terms-only re-run visits the point slots only
+#else
+#define n_rounds_slots n_slots
+#endif
         // Three stages per slot, software-pipelined over the rounds of the pass (PLSVO_PIPELINE = depth):
         //   stage A  table entry + 3-D point                      (does not depend on the pose)
         //   stage B  warp + project the point, gather the 5x5 window of the current image (needs A)
@@ -611,7 +649,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         SlotA a_nxt = stage_a(0);
         SlotC c_nxt = stage_c_loads(0, a_nxt.cand);
 #endif
-        for (int pb = 0; pb < n_slots; pb += T / 2) {
+        for (int pb = 0; pb < n_rounds_slots; pb += T / 2) {
           const int p = pb + pair;
 #if PLSVO_PIPELINE >= 2
           const SlotA sa = a_cur;
@@ -719,7 +757,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           // pixel arithmetic pins every later load behind it (measured +31 % launch time there, and the launch is within a few
           // per cent of the achievable HBM rate: every byte written costs its time, which is why line pixels are not stored).
 #ifndef PLSVO_CHI_NOSTORE   // (experiment switch: cost of keeping the terms)
-          if (accumulate && store_chi && p < job.n_pts) {
+          if ((accumulate || terms_only) && store_chi && p < job.n_pts) {
             if (b.chi_lds_pts > 0) {   // small batches: the planes are in LDS (kernel-uniform)
               float4* const chi_dst = reinterpret_cast<float4*>(s_win + (iter & 1) * b.chi_lds_pts * 16 + p * 16 + 8 * half);
               chi_dst[0] = chi_t0; chi_dst[1] = chi_t1;
@@ -788,20 +826,21 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       TICK(1);
 
       // -- reduction (fixed shape): butterfly inside the DPP rows, rows and waves through LDS
-      {
+      if (!terms_only) {
         double out2[2];
         row_reduce_scatter32(acc, out2);
         const int k0 = row_reduce_scatter32_index(lane);
         *reinterpret_cast<double2*>(s_red + (tid >> 4) * 32 + k0) = make_double2(out2[0], out2[1]);
       }
-      block_sync<T>();
+      block_sync<T>();   // (after a terms-only re-run: the planes it wrote are visible to wave 0)
       TICK(2);
 
       // -- wave 0: totals (fixed order) in lanes 0..29, cooperative 6x6 solve, then lane 0 takes the accept / roll back /
       //    update decision
-      if (wave == 0) {
-        const double tot = reduce_rows_finish<ROWS>(s_red);
-        if (lane < 30) s_tot[lane] = tot;
+      if (wave == 0 && stage == last_stage) {
+        // (after terms-only re-runs the totals of the iteration are read back from s_tot and the solve is simply done again)
+        const double tot = terms_only ? s_tot[lane & 31] : reduce_rows_finish<ROWS>(s_red);
+        if (lane < 30 && !terms_only) s_tot[lane] = tot;
         TICK(3);
         double x[6];
         wave_solve6_reg(tot, x, job.ldlt_flavour);                             // solve() :699
@@ -815,21 +854,39 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         // (> 5 sigma of the difference of two such sums) the order of the two values is taken from the exact float sums
         const float band = PLSVO_CHI_BAND * __fsqrt_rn((float)nm_d) * 5.9604644775390625e-8f;
         const bool near = iter > 0 && !s_ctl[1] && !isnan(x[0]) && fabs(new_chi2 - old_chi2) <= (double)band * old_chi2;
-        const bool have_terms = b.chi_lds_pts > 0 || (s_ctl[7] != 0 && s_ctl[8] != 0);   // both iterations' terms were kept
+        const bool have_terms = terms_only || b.chi_lds_pts > 0 || (s_ctl[7] != 0 && s_ctl[8] != 0);   // both iterations' terms were kept (or have just been rebuilt)
         const bool tie = near && have_terms;
+#if PLSVO_TIE_RECOMPUTE
+        const bool defer = near && !have_terms;   // wave-uniform: rebuild the missing plane(s) first, decide afterwards
+        if (defer && lane == 0) {
+          s_ctl[10] = (s_ctl[7] != 0 ? 0 : 1) | (s_ctl[8] != 0 ? 0 : 2);
+          if (s_ctl[8] == 0) {   // rotation matrix + translation of old_model_ for stage 2 (s_red is free until the next reduction)
+            const SE3d om = se3_load(s_pose + 19);
+            quat_to_matrix(om.q, s_red); s_red[9] = om.t[0]; s_red[10] = om.t[1]; s_red[11] = om.t[2];
+          }
+        }
+#else
+        constexpr bool defer = false;
+#endif
         if (tie) {   // wave-uniform
           if (b.chi_lds_pts > 0)
             exact_chi2_pair_lds((const PLSVO_LDS float*)(s_win + (iter & 1) * b.chi_lds_pts * 16), (const PLSVO_LDS float*)(s_win + ((iter & 1) ^ 1) * b.chi_lds_pts * 16),
                                 job.n_pts, job.n_seg, iter, (const PLSVO_LDS int*)s_dead, (const PLSVO_LDS float*)s_lterm, scap, (PLSVO_LDS float*)s_lterm + 2 * scap);
           else
-            exact_chi2_pair((const PLSVO_GLOBAL float*)chi_it, (const PLSVO_GLOBAL float*)(b.chi_terms + (size_t)((iter & 1) ^ 1) * b.chi_plane + (size_t)job.pt_off * 16),
+#if PLSVO_TIE_RECOMPUTE   // (chi_it is the plane a terms-only stage writes, not necessarily this iteration's)
+            exact_chi2_pair((const PLSVO_GLOBAL float*)(b.chi_terms + (size_t)(iter & 1) * b.chi_plane + (size_t)job.pt_off * 16),
+#else
+            exact_chi2_pair((const PLSVO_GLOBAL float*)chi_it,
+#endif
+                            (const PLSVO_GLOBAL float*)(b.chi_terms + (size_t)((iter & 1) ^ 1) * b.chi_plane + (size_t)job.pt_off * 16),
                             job.n_pts, job.n_seg, iter, (const PLSVO_LDS int*)s_dead, (PLSVO_LDS float*)s_win, (const PLSVO_LDS float*)s_lterm, scap,
                             (PLSVO_LDS float*)s_lterm + 2 * scap);
           const float FA = s_lterm[2 * scap], FB = s_lterm[2 * scap + 1];   // chi2 of this / of the previous iteration, before the division
           new_chi2 = (double)(FA / (float)nm);
           old_chi2 = (double)(FB / (float)(unsigned long long)(s_pose[30] + 0.5));
         }
-        if (lane == 0) {
+        if (lane == 0 && !defer) {
+          if (PLSVO_TIE_RECOMPUTE) s_ctl[10] = 0;
           s_pose[27] += ev_d;
           s_pose[31] += ev_pt;
           s_pose[30] = nm_d;                                                   // n_meas_ of this iteration, for the next one's tie
@@ -872,6 +929,10 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       }
       TICK(5);
       block_sync<T>();
+#if PLSVO_TIE_RECOMPUTE
+      if (stage == 0) redo_mask = s_ctl[10];   // (0 unless wave 0 deferred its decision)
+#endif
+     }   // stages of the iteration
       if (b.log && tid == 0) {  // H and Jres of the trace come from s_tot (written by lanes 0..26 above)
         const int lc = st->log_count - 1;
         if (lc >= 0 && lc < b.log_cap) {
@@ -921,6 +982,9 @@ extern "C" const char* plsvo_hip_build_flags(void) {
 #endif
 #if PLSVO_LDS_IMG
          "lds_img "
+#endif
+#if PLSVO_TIE_RECOMPUTE
+         "tie_recompute "
 #endif
       ;
 }

@@ -4,7 +4,7 @@
 # For each suffix: the parity subset THROUGH that library (PLSVO_HIP_LIB), then two repetitions of the default bench command and
 # config 3, interleaved with the default build so that box-to-box differences cancel; then the single-frame latency sweep.
 # Build the variants in the container first (the .so files travel with the snapshot):
-#   make -C pl-svo_amd/csrc byte_cache lds_img bc_lds_img
+#   make -C pl-svo_amd/csrc byte_cache lds_img bc_lds_img tie_recompute      (_tr: parity variant, rebuilds the chi2 terms of unarmed near ties)
 #   tools/build_patched.sh tools/patches/slot_parallel_exact_sum_dpp.patch dpp
 # usage: tools/ab_variants.sh <tag> _bc _li _bcli _dpp        -> gpurun_out/<tag>/
 TAG=${1:-ab}; shift
