@@ -1,6 +1,6 @@
 """One config-2 frame (seed given) at the one-wave-per-frame launch shape through whatever library PLSVO_HIP_LIB names; prints a JSON line:
 whether the device followed the oracle's Gauss-Newton path, the near-tie counters, the inter-frame pose error.  tests/test_emu_parity.py
-uses it on a seed whose near tie falls on an iteration whose per-pixel terms the default build does not keep.  usage: ... <seed>"""
+uses it on a seed whose near tie falls on an iteration whose per-pixel terms the default build does not keep.  usage: ... <seed> [threads per frame, default 64]"""
 import importlib
 import json
 import os
@@ -15,11 +15,12 @@ import helpers as Hh  # noqa: E402
 
 ob.build()
 seed = int(sys.argv[1])
+threads = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 ctx = P.capi.Context(0)
 assert hasattr(P.capi.lib(), "plsvo_emu_build"), "this runner is for host emulation builds"
 st, ref, cur, job = Hh.make_case(ob, seed, 640, 480, 200, 80, 4, 3, 1)
 res_o, log_o = ob.sparse_align(job, ref, cur, max_log=200)
-ctx.set_launch_shapes(align_threads=64)
+ctx.set_launch_shapes(align_threads=threads)
 ctx.config_pyramids(2, 640, 480, 4)
 ctx.upload_pyramid(0, ref)
 ctx.upload_pyramid(1, cur)

@@ -147,16 +147,19 @@ def test_tie_recompute_variant_follows_the_oracle_where_the_default_build_cannot
     -DPLSVO_TIE_RECOMPUTE=1 the kernel rebuilds the missing terms first and follows the oracle (1e-9)."""
     import json
 
-    def run(lib):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host", "emu_tie_case_runner.py"), "4373"], env=emu_env(lib), capture_output=True, text=True)
+    def run(lib, threads):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host", "emu_tie_case_runner.py"), "4373", str(threads)], env=emu_env(lib),
+                             capture_output=True, text=True)
         assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-2000:]
         return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 
-    base = run(emu_lib)
-    assert not base["same_path"] and base["near_ties_without_terms"] == 1 and base["inter_trans_rel"] > 1e-4      # the case is what it claims to be
-    var = run(build_emu(tmp_path / "emu_tr", "", "-DPLSVO_TIE_RECOMPUTE=1"))
-    assert var["same_path"] and var["near_ties_without_terms"] == 0 and var["decided_on_exact_sums"] == base["decided_on_exact_sums"] + 1
-    assert var["inter_trans_rel"] < 1e-7 and var["inter_rot_rad"] < 1e-9 and var["iters_device"] == var["iters_oracle"]
+    lib_tr = build_emu(tmp_path / "emu_tr", "", "-DPLSVO_TIE_RECOMPUTE=1")
+    for threads in (64, 128):      # 128: two waves per frame, the re-run passes go through the workgroup barriers
+        base = run(emu_lib, threads)
+        assert not base["same_path"] and base["near_ties_without_terms"] == 1 and base["inter_trans_rel"] > 1e-4      # the case is what it claims to be
+        var = run(lib_tr, threads)
+        assert var["same_path"] and var["near_ties_without_terms"] == 0 and var["decided_on_exact_sums"] == base["decided_on_exact_sums"] + 1
+        assert var["inter_trans_rel"] < 1e-7 and var["inter_rot_rad"] < 1e-9 and var["iters_device"] == var["iters_oracle"]
 
 
 def run_variant(lib, out_pkl):
