@@ -112,6 +112,8 @@ SWEEPS = [
     ("config3", 5000, 60, 1280, 720, 400, 150, 5, 4, 2, 0),
     # the benchmark's launch shape: one wave per frame, tiled pyramid mirror, chi2 terms in HBM planes kept only while the steps are small
     ("config2-one-wave-per-frame", 4000, 60, 640, 480, 200, 80, 4, 3, 1, 64),
+    # config 3 at ITS benchmark shape (8192 streams -> two waves per frame: row-major slab, HBM planes, arming)
+    ("config3-two-waves-per-frame", 5000, 40, 1280, 720, 400, 150, 5, 4, 2, 128),
 ]
 
 
