@@ -18,10 +18,11 @@ seed = int(sys.argv[1])
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 ctx = P.capi.Context(0)
 assert hasattr(P.capi.lib(), "plsvo_emu_build"), "this runner is for host emulation builds"
-st, ref, cur, job = Hh.make_case(ob, seed, 640, 480, 200, 80, 4, 3, 1)
+cfg3 = len(sys.argv) > 3 and sys.argv[3] == "config3"
+st, ref, cur, job = Hh.make_case(ob, seed, 1280, 720, 400, 150, 5, 4, 2) if cfg3 else Hh.make_case(ob, seed, 640, 480, 200, 80, 4, 3, 1)
 res_o, log_o = ob.sparse_align(job, ref, cur, max_log=200)
 ctx.set_launch_shapes(align_threads=threads)
-ctx.config_pyramids(2, 640, 480, 4)
+ctx.config_pyramids(2, 1280, 720, 5) if cfg3 else ctx.config_pyramids(2, 640, 480, 4)
 ctx.upload_pyramid(0, ref)
 ctx.upload_pyramid(1, cur)
 ctx.align_set_trace(200)
