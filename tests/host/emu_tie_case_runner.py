@@ -1,4 +1,5 @@
-"""One config-2 frame (seed given) at the one-wave-per-frame launch shape through whatever library PLSVO_HIP_LIB names; prints a JSON line:
+"""One config-2 (or config-3) frame (seed given) at a given launch shape through whatever library PLSVO_HIP_LIB names -- the emulated one in the
+CPU suite, the gfx950 one on a GPU box (tools/ab_variants.sh) --; prints a JSON line:
 whether the device followed the oracle's Gauss-Newton path, the near-tie counters, the inter-frame pose error.  tests/test_emu_parity.py
 uses it on a seed whose near tie falls on an iteration whose per-pixel terms the default build does not keep.  usage: ... <seed> [threads per frame, default 64]"""
 import importlib
@@ -17,7 +18,6 @@ ob.build()
 seed = int(sys.argv[1])
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 ctx = P.capi.Context(0)
-assert hasattr(P.capi.lib(), "plsvo_emu_build"), "this runner is for host emulation builds"
 cfg3 = len(sys.argv) > 3 and sys.argv[3] == "config3"
 st, ref, cur, job = Hh.make_case(ob, seed, 1280, 720, 400, 150, 5, 4, 2) if cfg3 else Hh.make_case(ob, seed, 640, 480, 200, 80, 4, 3, 1)
 res_o, log_o = ob.sparse_align(job, ref, cur, max_log=200)
