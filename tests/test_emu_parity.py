@@ -8,7 +8,8 @@ What this is: a functional check of the device SOURCE (indexing, control flow, t
 the way kernel variants that have not been on a GPU yet are checked bit for bit against the build that has.  What it is not: a
 statement about the compiled gfx950 code (fma contraction, the hardware's rcp/rsq seeds, memory ordering inside a wave) -- the `-m gpu`
 run on the MI355X stays the parity gate.  The emulated library is test infrastructure: it lives in a temporary directory, exports the
-marker `plsvo_emu_build`, and bench.py refuses it."""
+marker `plsvo_emu_build`, and bench.py / smoke() refuse it unless asked for a DRY RUN -- which this module also does: the round's two
+driver-run scripts are executed end to end here (bench.py: configs 2, 5, 4, and under torchrun with two ranks), labelled as such."""
 import os
 import pickle
 import shutil
