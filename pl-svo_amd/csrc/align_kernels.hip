@@ -971,6 +971,11 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   }
 }
 
+#if !PLSVO_TIE_RECOMPUTE
+#undef chi_par
+#undef n_rounds_slots
+#endif
+
 // LDS bytes the kernel needs for slot capacity `cap` and segment capacity `scap` (host side helper)
 size_t align_level_lds_bytes(int threads, int cap, int scap, int chi_lds_pts) { return align_lds_used(threads, cap, scap, chi_lds_pts); }
 
