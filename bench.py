@@ -197,7 +197,7 @@ def host_fed_leg(P, torch, dev, stream, streams, cfg, n_streams=1024, steps=12):
     n = min(n_streams, len(streams))
     W, H = cfg["W"], cfg["H"]
     sub = streams[:n]
-    ctx = capi.Context(dev.index, stream=stream.cuda_stream)
+    ctx = capi.Context(dev.index or 0, stream=stream.cuda_stream)
     try:
         ctx.config_pyramids(2 * n, W, H, cfg["pyr"])               # ref frames in slots [0, n), cur frames in [n, 2n)
         host = []
@@ -272,7 +272,7 @@ def chain_leg(P, torch, dev, stream, streams, cfg, n_streams=4096, steps=10, cpu
     n = min(n_streams, len(streams))
     W, H = cfg["W"], cfg["H"]
     sub = streams[:n]
-    ctx = capi.Context(dev.index, stream=stream.cuda_stream)
+    ctx = capi.Context(dev.index or 0, stream=stream.cuda_stream)
     try:
         ctx.config_pyramids(2 * n, W, H, cfg["pyr"])
         for c0 in range(0, n, 256):
@@ -381,8 +381,11 @@ def main():
         import types
         torch.cuda.set_device = lambda *_a, **_k: None
         torch.cuda.synchronize = lambda *_a, **_k: None
-        torch.cuda.Stream = lambda *_a, **_k: types.SimpleNamespace(cuda_stream=None)
+        _noop = lambda *_a, **_k: None
+        torch.cuda.Stream = lambda *_a, **_k: types.SimpleNamespace(cuda_stream=None, wait_event=_noop)
+        torch.cuda.Event = lambda *_a, **_k: types.SimpleNamespace(record=_noop)
         torch.cuda.stream = lambda *_a, **_k: contextlib.nullcontext()
+        torch.Tensor.pin_memory = lambda self, *_a, **_k: self
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.dist_selftest
     if use_dist:
@@ -621,7 +624,7 @@ def main():
                         result["latency"]["B8_vs_cpu_all_cores"] = round(result["latency"]["B8"]["frames_per_s"] / cb["value"], 2)
                 except Exception as e:   # an auxiliary leg never takes the headline line down
                     result["latency"] = {"error": str(e)[:300]}
-            if world == 1 and args.config == 2 and not args.no_latency and not args.dist_selftest and not dry:
+            if world == 1 and args.config == 2 and not args.no_latency and not args.dist_selftest:
                 try:
                     result["host_fed"] = host_fed_leg(P, torch, dev, stream, streams, cfg)
                 except Exception as e:   # never take the headline line down

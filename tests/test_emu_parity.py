@@ -94,6 +94,10 @@ def test_bench_script_dry_run(emu_lib, argv):
     assert r["algorithmic_bytes_per_launch"] > 0 and r["launches"] >= 1
     if argv[0] == "--batch":     # the default workload also carries the small-batch leg
         assert d["latency"]["B1"]["frames_per_s"] > 0 and d["latency"]["B8"]["frames_per_s"] > 0, d.get("latency")
+        # ... and the host-fed and resident-frame-step legs (guarded by try/except in the script: an error would only show up here)
+        assert d["host_fed"].get("frames_per_s", 0) > 0 and "error" not in d["host_fed"], d["host_fed"]
+        assert d["frame_chain"].get("frames_per_s", 0) > 0 and "error" not in d["frame_chain"], d["frame_chain"]
+        assert d["frame_chain"]["cpu_oracle_chain"]["max_rot_diff_vs_device_rad"] < 1e-4
     if "--no-cpu-baseline" not in argv:
         cb = d["cpu_baseline"]
         assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and cb["sample"]
