@@ -626,11 +626,11 @@ def main():
                     result["latency"] = {"error": str(e)[:300]}
             if world == 1 and args.config == 2 and not args.no_latency and not args.dist_selftest:
                 try:
-                    result["host_fed"] = host_fed_leg(P, torch, dev, stream, streams, cfg)
+                    result["host_fed"] = host_fed_leg(P, torch, dev, stream, streams, cfg, **({"steps": 2} if dry else {}))
                 except Exception as e:   # never take the headline line down
                     result["host_fed"] = {"error": str(e)[:300]}
                 try:
-                    result["frame_chain"] = chain_leg(P, torch, dev, stream, streams, cfg)
+                    result["frame_chain"] = chain_leg(P, torch, dev, stream, streams, cfg, **({"steps": 2, "cpu_frames": 2} if dry else {}))
                 except Exception as e:
                     result["frame_chain"] = {"error": str(e)[:300]}
             print(json.dumps(result), flush=True)
