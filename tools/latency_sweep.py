@@ -33,7 +33,8 @@ def main():
     args = ap.parse_args()
     import torch
     P = importlib.import_module("pl-svo_amd")
-    dev = torch.device("cuda", 0)
+    on_gpu = torch.cuda.is_available()     # (without a GPU: a dry run against a host emulation build named by PLSVO_HIP_LIB, tests/host/)
+    dev = torch.device("cuda", 0) if on_gpu else torch.device("cpu")
     ctx = P.capi.Context(0)
     rows = []
     W, H = args.width, args.height
@@ -43,7 +44,8 @@ def main():
         for c0 in range(0, B, 256):
             sub = streams[c0:c0 + 256]
             imgs = P.synth.render_streams(sub, device=dev)
-            torch.cuda.synchronize()      # the library enqueues on its own stream: the rendered images must be complete before it reads them
+            if on_gpu:
+                torch.cuda.synchronize()  # the library enqueues on its own stream: the rendered images must be complete before it reads them
             ctx.build_pyramids_dev(2 * c0, 2 * len(sub), imgs.data_ptr(), W, W * H, 0)
             ctx.synchronize()
         jobs = [P.align_job_from_stream(s, args.max_level, args.min_level, ref_slot=0 if args.same_images else 2 * i,
