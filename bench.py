@@ -6,7 +6,7 @@ One "step" = one pass of the hot path over one batch of B independent synthetic 
 Default workload = BASELINE.json configs[1]: 640x480, 200 points + 80 line segments, 4-image pyramid
 (alignment levels 3..1).  Per-GPU batch is fixed as N grows ("weak" scaling); streams are independent, so
 ranks exchange nothing on the data path -- the only collective is the RCCL all-gather of the per-stream
-result poses (7 doubles each), once per step (pl-svo_amd/dist.py::timed_sharded_steps is the timed region).
+result records (96-byte plsvo_pose_record: pose + n_tracked, num_obs_pt, num_obs_ls, status), once per step (pl-svo_amd/dist.py::timed_sharded_steps is the timed region).
 
   python bench.py --gpus 1 --steps K --warmup W            (single process)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -447,11 +447,14 @@ def main():
                 sh["ctx"].poseopt_run()
 
         n_local = local_shards * B
-        local_poses = torch.empty((n_local, 7), dtype=torch.float64, device=dev)
+        # what a rank publishes per stream: the 96-byte plsvo_pose_record (pose + n_tracked, num_obs_pt, num_obs_ls, status),
+        # packed on the device from the resident state of the two launches, on their stream
+        REC = P.abi.POSE_RECORD_BYTES
+        local_poses = torch.empty((n_local, REC), dtype=torch.uint8, device=dev)
 
         def copy_local(t):
             for v, sh in enumerate(shard):
-                sh["ctx"].poseopt_copy_poses(t.data_ptr() + v * B * 7 * 8)
+                sh["ctx"].pack_pose_records(t.data_ptr() + v * B * REC)
 
         comm = P.rccl.comm_over_process_group() if (use_dist and not dry) else None       # the gather is the C ABI's, on the library's stream
         def gather(local, out):
@@ -541,7 +544,7 @@ def main():
                 "data": "synthetic" if not dry else "synthetic -- DRY RUN on the host emulation build of the library: NOT a measurement",
                 "config": {"workload": cfg["workload"], "streams_per_gpu": n_local, "global_batch": world * n_local,
                            "shards": shards_total, "streams_per_shard": B,
-                           "parallelism": (f"streams sharded x{world}, pose all-gather through plsvo_gather_poses (RCCL)" if world > 1 else
+                           "parallelism": (f"streams sharded x{world}, all-gather of 96-byte pose records through plsvo_gather_poses (RCCL)" if world > 1 else
                                            ("single GPU, N>1 code path with one rank (--dist-selftest)" if args.dist_selftest else "single GPU"))},
                 "roofline": roofline,
                 "kernel_ms_per_step": {"align_fused": round(lvl_ms / args.steps, 4), "pose_opt": round(pose_ms / args.steps, 4)},

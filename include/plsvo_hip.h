@@ -553,11 +553,38 @@ int plsvo_update_seeds(plsvo_ctx* ctx, const plsvo_seeds_in* in, plsvo_seeds_out
 /* multi-GPU: gather of per-stream pose records (new; the reference is single-process)         */
 /* ------------------------------------------------------------------------------------------ */
 
-/* All-gather of n_local pose records (7 doubles each, device memory) over an RCCL communicator
- * (ncclComm_t passed as void*), enqueued on the ctx stream: d_all receives world_size*n_local
- * records, rank-major.  No other collective exists on this path (streams are independent). */
-int plsvo_gather_poses(plsvo_ctx* ctx, void* rccl_comm, const double* d_local, int n_local,
-                       double* d_all);
+/* The per-stream record a rank publishes after a frame step: what FrameHandlerMono::processFrame decides on
+ * afterwards -- the pose it keeps (src/frame_handler_mono.cpp:92, :327-329), SparseImgAlign::run's return value (:272-274), the pose
+ * optimiser's surviving observations (sfba_n_edges_final = num_obs_pt + num_obs_ls, :327-335) -- so that the rank that holds the
+ * gathered table sees which streams lost tracking without a second exchange.  Fixed size: 96 bytes. */
+#define PLSVO_REC_ALIGN      0x01   /* an alignment batch contributed (n_tracked, PLSVO_REC_ALIGN_STOP, PLSVO_REC_ALIGN_ERROR valid) */
+#define PLSVO_REC_ALIGN_STOP 0x02   /* the alignment's solver raised stop_ (NaN in solve, src/sparse_img_align.cpp:700) */
+#define PLSVO_REC_ALIGN_ERROR 0x04  /* device-side capacity / consistency error (plsvo_align_out.status bit 1) */
+#define PLSVO_REC_POSEOPT    0x08   /* a pose-optimisation batch contributed (T_f_w is its result; num_obs_*, error_final valid) */
+#define PLSVO_REC_POSEOPT_EMPTY 0x10 /* optimizeGaussNewton returned early: no observation (src/pose_optimizer.cpp:88-89) */
+typedef struct plsvo_pose_record {
+  double T_f_w[7];                  /* qx qy qz qw tx ty tz: pose_optimizer's T_f_w when PLSVO_REC_POSEOPT, else the alignment's T_cur_from_ref */
+  uint64_t n_tracked;               /* SparseImgAlign::run's return value, n_meas_ / patch_area_ (src/sparse_img_align.cpp:94) */
+  uint64_t num_obs_pt;              /* optimizeGaussNewton's num_obs_pt (src/pose_optimizer.cpp:218-226) */
+  uint64_t num_obs_ls;              /* ... num_obs_ls (:239-245) */
+  double error_final;               /* ... error_final (:247-251) */
+  int32_t status;                   /* PLSVO_REC_* */
+  int32_t stream;                   /* index of the stream in the publishing context's batch */
+} plsvo_pose_record;
+
+/* Writes one record per stream of the resident batch into device memory (d_dst: n records), enqueued on the ctx stream after the
+ * launches that produce them: the resident frame step (plsvo_chain_stage) if one is staged, else the staged alignment and / or
+ * pose-optimisation batches (which must then have the same number of jobs).  *n_out (may be NULL) receives the record count. */
+int plsvo_pack_pose_records(plsvo_ctx* ctx, plsvo_pose_record* d_dst, int* n_out);
+/* The same records in host memory (out: n records, n = the resident batch's size): packs into a ctx-owned device buffer, copies,
+ * synchronises the ctx stream.  For a single-process host that wants the table without a communicator. */
+int plsvo_fetch_pose_records(plsvo_ctx* ctx, int n, plsvo_pose_record* out);
+
+/* All-gather of n_local pose records (device memory) over an RCCL communicator (ncclComm_t passed as void*), enqueued on the ctx
+ * stream: d_all receives world_size*n_local records, rank-major (96 B per stream: 768 B per rank for BASELINE configs[3]).  No other
+ * collective exists on this path (streams are independent). */
+int plsvo_gather_poses(plsvo_ctx* ctx, void* rccl_comm, const plsvo_pose_record* d_local, int n_local,
+                       plsvo_pose_record* d_all);
 
 /* ------------------------------------------------------------------------------------------ */
 /* timing (hipEvent pairs recorded on the ctx stream around each kernel family)                */

@@ -122,6 +122,17 @@ class ChainOut(C.Structure):
                 ("found", c_u8_p), ("px", c_double_p), ("search_level", c_i32_p), ("sel_pt", c_i32_p), ("sel_seg", c_i32_p)]
 
 
+class PoseRecord(C.Structure):
+    """plsvo_pose_record: the 96-byte per-stream record a rank publishes (plsvo_pack_pose_records / plsvo_gather_poses)"""
+    _fields_ = [("T_f_w", C.c_double * 7), ("n_tracked", C.c_uint64), ("num_obs_pt", C.c_uint64), ("num_obs_ls", C.c_uint64),
+                ("error_final", C.c_double), ("status", C.c_int32), ("stream", C.c_int32)]
+
+
+POSE_RECORD_BYTES = 96
+POSE_RECORD_DTYPE = np.dtype([("T_f_w", np.float64, 7), ("n_tracked", np.uint64), ("num_obs_pt", np.uint64), ("num_obs_ls", np.uint64),
+                              ("error_final", np.float64), ("status", np.int32), ("stream", np.int32)])
+REC_ALIGN, REC_ALIGN_STOP, REC_ALIGN_ERROR, REC_POSEOPT, REC_POSEOPT_EMPTY = 0x01, 0x02, 0x04, 0x08, 0x10
+
 c_float_p = C.POINTER(C.c_float)
 
 

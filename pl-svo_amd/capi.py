@@ -25,7 +25,7 @@ SYMBOLS = [
     "plsvo_poseopt_set_trace", "plsvo_poseopt_fetch_trace", "plsvo_poseopt_poses_dev", "plsvo_poseopt_copy_poses", "plsvo_poseopt_work",
     "plsvo_structure_optimize", "plsvo_match_direct", "plsvo_reproject", "plsvo_trajectory_record", "plsvo_update_seeds",
     "plsvo_chain_stage", "plsvo_chain_run", "plsvo_chain_fetch", "plsvo_frame_step_batch", "plsvo_chain_poses_dev",
-    "plsvo_gather_poses",
+    "plsvo_pack_pose_records", "plsvo_fetch_pose_records", "plsvo_gather_poses",
     "plsvo_hip_set_profiling", "plsvo_hip_kernel_time", "plsvo_hip_reset_profiling",
     "plsvo_hip_version", "plsvo_hip_build_flags", "plsvo_hip_device_info",
 ]
@@ -103,6 +103,8 @@ def lib():
         "plsvo_chain_poses_dev": (vp, [ctxp]),
         "plsvo_align_slot_layout": (C.c_int, [C.POINTER(abi.AlignIn), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                               C.POINTER(C.c_longlong)]),
+        "plsvo_pack_pose_records": (C.c_int, [ctxp, vp, C.POINTER(C.c_int)]),
+        "plsvo_fetch_pose_records": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.PoseRecord)]),
         "plsvo_gather_poses": (C.c_int, [ctxp, vp, vp, C.c_int, vp]),
         "plsvo_hip_set_profiling": (C.c_int, [ctxp, C.c_int]),
         "plsvo_hip_kernel_time": (C.c_int, [ctxp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -410,7 +412,21 @@ class Context:
         self._chk(self.L.plsvo_update_seeds(self.h, C.byref(job.c), C.byref(out)))
         return job.trim(bufs)
 
+    def pack_pose_records(self, d_dst):
+        """plsvo_pack_pose_records: one 96-byte plsvo_pose_record per stream of the resident batch into device memory at d_dst (enqueued on
+        the ctx stream); returns the record count"""
+        n = C.c_int(0)
+        self._chk(self.L.plsvo_pack_pose_records(self.h, C.c_void_p(d_dst), C.byref(n)))
+        return int(n.value)
+
+    def fetch_pose_records(self, n):
+        """plsvo_fetch_pose_records: the resident batch's n records as a numpy structured array (abi.POSE_RECORD_DTYPE)"""
+        out = np.zeros(n, dtype=abi.POSE_RECORD_DTYPE)
+        self._chk(self.L.plsvo_fetch_pose_records(self.h, n, out.ctypes.data_as(C.POINTER(abi.PoseRecord))))
+        return out
+
     def gather_poses(self, rccl_comm, d_local, n_local, d_all):
+        """plsvo_gather_poses: all-gather of n_local plsvo_pose_record (96 B each, device pointers) over an RCCL communicator"""
         self._chk(self.L.plsvo_gather_poses(self.h, C.c_void_p(rccl_comm), C.c_void_p(d_local), n_local, C.c_void_p(d_all)))
 
 

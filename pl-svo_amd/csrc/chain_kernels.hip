@@ -16,10 +16,42 @@
 //                         other matches.  Then the selected features are written as pose-optimiser input, in selection order.
 #include <hip/hip_runtime.h>
 
+#include "../../include/plsvo_hip.h"
 #include "plsvo_dev.hpp"
 #include "plsvo_math.hpp"
 
 namespace plsvo_hip {
+
+// The record a rank publishes per stream (include/plsvo_hip.h: plsvo_pose_record): pose + what the host decides "tracking
+// lost" on (src/frame_handler_mono.cpp:272-274, :327-335), packed from the resident state of the alignment / pose-optimisation launches
+// that precede it on the stream.  One lane per stream; 96 B written per record.
+__global__ void __launch_bounds__(64) pack_pose_records_kernel(const AlignStateDev* ast, const PoseStateDev* pst, int n, plsvo_pose_record* dst) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= n) return;
+  plsvo_pose_record r;
+  int status = 0;
+  r.n_tracked = 0; r.num_obs_pt = 0; r.num_obs_ls = 0; r.error_final = 0.0;
+  for (int k = 0; k < 7; ++k) r.T_f_w[k] = k == 3 ? 1.0 : 0.0;
+  if (ast) {
+    const AlignStateDev& a = ast[j];
+    status |= PLSVO_REC_ALIGN | (a.stop ? PLSVO_REC_ALIGN_STOP : 0) | (a.error ? PLSVO_REC_ALIGN_ERROR : 0);
+    r.n_tracked = a.n_meas / PLSVO_PATCH_AREA;                       // run() returns n_meas_ / patch_area_  :94
+    for (int k = 0; k < 7; ++k) r.T_f_w[k] = a.T[k];
+  }
+  if (pst) {
+    const PoseStateDev& q = pst[j];
+    status |= PLSVO_REC_POSEOPT | ((q.status & 1) ? PLSVO_REC_POSEOPT_EMPTY : 0);
+    r.num_obs_pt = q.num_obs_pt; r.num_obs_ls = q.num_obs_ls; r.error_final = q.error_final;
+    for (int k = 0; k < 7; ++k) r.T_f_w[k] = q.T[k];
+  }
+  r.status = status; r.stream = j;
+  dst[j] = r;
+}
+hipError_t launch_pack_pose_records(const AlignStateDev* ast, const PoseStateDev* pst, int n, plsvo_pose_record* dst, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_pose_records_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, ast, pst, n, dst);
+  return hipGetLastError();
+}
 
 __global__ void __launch_bounds__(64) chain_pose_kernel(const ChainBatchDev b) {
   const int j = blockIdx.x * 64 + threadIdx.x;

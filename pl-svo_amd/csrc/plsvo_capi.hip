@@ -38,6 +38,7 @@ hipError_t launch_halfsample(const uint8_t* src, size_t src_pitch, int in_w, int
 hipError_t launch_copy_level0(const uint8_t* src, size_t src_pitch, int w, int h, int stride, uint8_t* dst, size_t dst_pitch,
                               int n_slots, hipStream_t stream);
 hipError_t launch_chain_pose(const ChainBatchDev& b, hipStream_t stream);
+hipError_t launch_pack_pose_records(const AlignStateDev* ast, const PoseStateDev* pst, int n, plsvo_pose_record* dst, hipStream_t stream);
 hipError_t launch_chain_active(const ChainBatchDev& b, hipStream_t stream);
 hipError_t launch_chain_select(const ChainBatchDev& b, hipStream_t stream);
 hipError_t launch_tile_level(const uint8_t* src, size_t src_pitch, int w, int h, uint8_t* dst, size_t dst_pitch, int n_slots, hipStream_t stream);
@@ -132,6 +133,7 @@ struct plsvo_ctx {
   ReprojBatchDev ch_reproj{};
   PoseBatchDev ch_pose{};
   DevBuf ch_d_state, ch_d_ptkeep, ch_d_segkeep, ch_d_s32, ch_d_s64, ch_d_poses;
+  DevBuf rec_d;   // plsvo_fetch_pose_records
 
   // structure optimisation (one-shot batches)
   DevBuf s_d_in, s_d_out;
@@ -242,7 +244,7 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
   DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_tiled, &c->pyr_upload, &c->a_d_blob, &c->a_d_state, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv, &c->a_d_cref, &c->a_d_cdx,
                      &c->a_d_cdy, &c->a_d_chi, &c->a_d_log, &c->a_d_poses, &c->p_d_blob, &c->p_d_state, &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64,
                      &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out, &c->ch_d_blob, &c->ch_d_work, &c->ch_d_po, &c->ch_d_state,
-                     &c->ch_d_ptkeep, &c->ch_d_segkeep, &c->ch_d_s32, &c->ch_d_s64, &c->ch_d_poses };
+                     &c->ch_d_ptkeep, &c->ch_d_segkeep, &c->ch_d_s32, &c->ch_d_s64, &c->ch_d_poses, &c->rec_d };
   for (DevBuf* b : bufs) b->release();
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -1514,11 +1516,46 @@ extern "C" int plsvo_update_seeds(plsvo_ctx* c, const plsvo_seeds_in* in, plsvo_
 }
 
 // ---- multi-GPU gather ------------------------------------------------------------------------------
-extern "C" int plsvo_gather_poses(plsvo_ctx* c, void* rccl_comm, const double* d_local, int n_local, double* d_all) {
+extern "C" int plsvo_pack_pose_records(plsvo_ctx* c, plsvo_pose_record* d_dst, int* n_out) {
+  CTX_CHECK(c);
+  if (!d_dst) return fail(c, PLSVO_E_INVALID, "pack_pose_records: null destination");
+  const AlignStateDev* ast = nullptr; const PoseStateDev* pst = nullptr; int n = 0;
+  if (c->ch_staged && c->a_staged && c->a_n == c->ch_n) {   // the resident frame step: its own pose-optimisation state
+    ast = c->a_d_state.as<AlignStateDev>(); pst = c->ch_d_state.as<PoseStateDev>(); n = c->ch_n;
+  } else {
+    if (c->a_staged) { ast = c->a_d_state.as<AlignStateDev>(); n = c->a_n; }
+    if (c->p_staged) {
+      if (ast && c->p_n != n) return fail(c, PLSVO_E_STATE, "pack_pose_records: the staged alignment and pose-optimisation batches differ in size");
+      pst = c->p_d_state.as<PoseStateDev>(); n = c->p_n;
+    }
+  }
+  if (!ast && !pst) return fail(c, PLSVO_E_STATE, "pack_pose_records: no staged batch");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, launch_pack_pose_records(ast, pst, n, d_dst, c->stream));
+  if (n_out) *n_out = n;
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_fetch_pose_records(plsvo_ctx* c, int n, plsvo_pose_record* out) {
+  CTX_CHECK(c);
+  if (!out || n <= 0) return fail(c, PLSVO_E_INVALID, "fetch_pose_records: bad arguments");
+  HIP_TRY(c, c->rec_d.ensure((size_t)n * sizeof(plsvo_pose_record)));
+  int n_packed = 0;
+  const int rc = plsvo_pack_pose_records(c, c->rec_d.as<plsvo_pose_record>(), &n_packed);
+  if (rc) return rc;
+  if (n_packed != n) return fail(c, PLSVO_E_INVALID, "fetch_pose_records: n does not match the resident batch");
+  HIP_TRY(c, hipMemcpyAsync(out, c->rec_d.p, (size_t)n * sizeof(plsvo_pose_record), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_gather_poses(plsvo_ctx* c, void* rccl_comm, const plsvo_pose_record* d_local, int n_local, plsvo_pose_record* d_all) {
   CTX_CHECK(c);
   if (!rccl_comm || !d_local || !d_all || n_local <= 0) return fail(c, PLSVO_E_INVALID, "gather_poses: bad arguments");
   HIP_TRY(c, hipSetDevice(c->device));
-  ncclResult_t r = ncclAllGather(d_local, d_all, (size_t)n_local * 7, ncclDouble, reinterpret_cast<ncclComm_t>(rccl_comm), c->stream);
+  static_assert(sizeof(plsvo_pose_record) == 96, "plsvo_pose_record is a 96-byte wire record");
+  ncclResult_t r = ncclAllGather(d_local, d_all, (size_t)n_local * (sizeof(plsvo_pose_record) / sizeof(double)), ncclDouble,
+                                 reinterpret_cast<ncclComm_t>(rccl_comm), c->stream);
   if (r != ncclSuccess) return fail(c, PLSVO_E_RCCL, std::string("ncclAllGather: ") + ncclGetErrorString(r));
   return PLSVO_OK;
 }

@@ -37,9 +37,40 @@ def rank_seeds(rank, world, streams_per_rank, base_seed=1234):
     return [stream_seed(g, base_seed) for g in stream_block(rank, world, streams_per_rank)]
 
 
+def records_to_tensor(records, device="cpu"):
+    """numpy structured array of plsvo_pose_record (pl-svo_amd/abi.py::POSE_RECORD_DTYPE, 96 B each) -> uint8 tensor [n, 96]: the shape
+    the pose all-gather moves (pose + n_tracked, num_obs_pt, num_obs_ls, status per stream)"""
+    import numpy as np
+    from . import abi
+    r = np.ascontiguousarray(records, dtype=abi.POSE_RECORD_DTYPE)
+    return torch.from_numpy(r.view(np.uint8).reshape(r.shape[0], abi.POSE_RECORD_BYTES).copy()).to(device)
+
+
+def tensor_to_records(t):
+    """uint8 tensor [n, 96] (host or device) -> numpy structured array of plsvo_pose_record"""
+    import numpy as np
+    from . import abi
+    a = np.ascontiguousarray(t.detach().cpu().numpy())
+    return a.reshape(-1).view(abi.POSE_RECORD_DTYPE).copy()
+
+
+def lost_streams(records, min_tracked=0, min_obs=0):
+    """global indices (rank-major) of the streams a gathered record table marks as failed: the alignment's solver stopped on NaN or
+    reported a device error, the pose optimiser had nothing to optimise, or the counts fall below the caller's thresholds (what
+    src/frame_handler_mono.cpp:272-274, :327-335 test: img_align_n_tracked, sfba_n_edges_final = num_obs_pt + num_obs_ls)"""
+    import numpy as np
+    from . import abi
+    r = records
+    st = r["status"]
+    bad = (st & (abi.REC_ALIGN_STOP | abi.REC_ALIGN_ERROR | abi.REC_POSEOPT_EMPTY)) != 0
+    bad |= ((st & abi.REC_ALIGN) != 0) & (r["n_tracked"] < min_tracked)
+    bad |= ((st & abi.REC_POSEOPT) != 0) & ((r["num_obs_pt"] + r["num_obs_ls"]) < min_obs)
+    return [int(i) for i in np.nonzero(bad)[0]]
+
+
 def gather_poses(local_poses, out=None):
-    """All-gather [n_local, 7] pose records -> [world * n_local, 7], rank-major.  Works un-initialised
-    (single process) by returning the local tensor."""
+    """All-gather [n_local, K] pose records -> [world * n_local, K], rank-major (K = 96 bytes of plsvo_pose_record as uint8; any 2-D
+    tensor works).  Works un-initialised (single process) by returning the local tensor."""
     if world_size() == 1:
         if out is not None:
             out.copy_(local_poses)

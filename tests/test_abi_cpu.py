@@ -39,7 +39,8 @@ def test_ctypes_structs_match_the_c_header(P, tmp_path):
                "plsvo_structopt_in": P.abi.StructOptIn, "plsvo_structopt_out": P.abi.StructOptOut,
                "plsvo_match_in": P.abi.MatchIn, "plsvo_match_out": P.abi.MatchOut, "plsvo_reproject_in": P.abi.ReprojectIn,
                "plsvo_reproject_out": P.abi.ReprojectOut, "plsvo_seeds_in": P.abi.SeedsIn, "plsvo_seeds_out": P.abi.SeedsOut,
-               "plsvo_chain_in": P.abi.ChainIn, "plsvo_chain_params": P.abi.ChainParams, "plsvo_chain_out": P.abi.ChainOut}
+               "plsvo_chain_in": P.abi.ChainIn, "plsvo_chain_params": P.abi.ChainParams, "plsvo_chain_out": P.abi.ChainOut,
+               "plsvo_pose_record": P.abi.PoseRecord}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, ct in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -52,6 +53,7 @@ def test_ctypes_structs_match_the_c_header(P, tmp_path):
     subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     got = dict(l.split() for l in out.strip().splitlines())
+    assert int(got["plsvo_pose_record"]) == 96 == P.abi.POSE_RECORD_DTYPE.itemsize   # the wire record of the pose all-gather
     for cname, ct in structs.items():
         assert int(got[cname]) == C.sizeof(ct), cname
         for fname, _ in ct._fields_:

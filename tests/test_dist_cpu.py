@@ -20,6 +20,20 @@ def _free_port():
     return p
 
 
+def _oracle_records(P, D, ob, block):
+    """plsvo_pose_record of every stream of `block`, from the oracle (stream 4 has NO observation: its record must say so at every rank)"""
+    rec = np.zeros(len(block), dtype=P.abi.POSE_RECORD_DTYPE)
+    for i, g in enumerate(block):
+        fr = P.synth.make_poseopt_frame(D.stream_seed(g), 0 if g == 4 else 30, 0 if g == 4 else 10)
+        res, _ = ob.pose_optimize(P.poseopt_job_from_frame(fr))
+        rec[i]["T_f_w"] = res.T
+        rec[i]["n_tracked"] = 100 + g
+        rec[i]["num_obs_pt"], rec[i]["num_obs_ls"], rec[i]["error_final"] = res.num_obs_pt, res.num_obs_ls, res.error_final
+        rec[i]["status"] = P.abi.REC_ALIGN | P.abi.REC_POSEOPT | (P.abi.REC_POSEOPT_EMPTY if (res.status & 1) else 0)
+        rec[i]["stream"] = i
+    return rec
+
+
 def _worker(rank, world, port, n_local, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -32,12 +46,8 @@ def _worker(rank, world, port, n_local, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         # each rank solves its own block of streams (the CPU oracle stands in for the HIP path here)
-        poses = []
-        for g in D.stream_block(rank, world, n_local):
-            fr = P.synth.make_poseopt_frame(D.stream_seed(g), 30, 10)
-            res, _ = ob.pose_optimize(P.poseopt_job_from_frame(fr))
-            poses.append(res.T)
-        local = torch.tensor(np.array(poses), dtype=torch.float64)
+        local = D.records_to_tensor(_oracle_records(P, D, ob, D.stream_block(rank, world, n_local)))
+        assert local.dtype == torch.uint8 and tuple(local.shape) == (n_local, 96)
         allp = D.gather_poses(local)
         q.put((rank, allp.numpy().copy()))
     finally:
@@ -62,14 +72,14 @@ def test_two_rank_gather_equals_concatenation():
     P = importlib.import_module("pl-svo_amd")
     D = importlib.import_module("pl-svo_amd.dist")
     from oracle import binding as ob
-    expect = []
-    for g in range(world * n_local):
-        fr = P.synth.make_poseopt_frame(D.stream_seed(g), 30, 10)
-        expect.append(ob.pose_optimize(P.poseopt_job_from_frame(fr))[0].T)
-    expect = np.array(expect)
+    expect = np.concatenate([_oracle_records(P, D, ob, D.stream_block(r, world, n_local)) for r in range(world)])
     for r in range(world):
-        assert got[r].shape == (world * n_local, 7)
-        assert np.array_equal(got[r], expect), "gathered table must equal the rank-major concatenation, bit for bit"
+        assert got[r].shape == (world * n_local, 96)
+        rec = D.tensor_to_records(torch.from_numpy(got[r]))
+        assert rec.tobytes() == expect.tobytes(), "gathered table must equal the rank-major concatenation, bit for bit"
+        # every rank sees WHICH stream failed (the record carries the counts and the status, not the pose alone)
+        assert D.lost_streams(rec) == [4] and D.lost_streams(rec, min_tracked=102) == [0, 1, 4]
+        assert list(rec["stream"]) == [0, 1, 2] * world and np.all(rec["num_obs_pt"][[0, 1, 2, 3, 5]] > 0)
 
 
 def test_sharding_helpers():

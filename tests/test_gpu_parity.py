@@ -959,7 +959,7 @@ def test_gather_poses_over_a_single_rank_rccl_communicator(P, gpu_ctx):
     rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
     assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
     try:
-        local = torch.arange(5 * 7, dtype=torch.float64, device="cuda:0").reshape(5, 7) * 0.25
+        local = (torch.arange(5 * 96, dtype=torch.int32, device="cuda:0") % 251).to(torch.uint8).reshape(5, 96)   # five 96-byte records
         out = torch.zeros_like(local)
         torch.cuda.synchronize()
         gpu_ctx.gather_poses(comm.value, local.data_ptr(), 5, out.data_ptr())
@@ -983,7 +983,8 @@ def test_config4_sharded_streams_and_pose_gather(P, ob):
     D = P.dist
     world, B, W, H = 8, 8, 640, 480
     dev = torch.device("cuda", 0)
-    table = torch.zeros((world * B, 7), dtype=torch.float64, device=dev)
+    table = torch.zeros((world * B, 96), dtype=torch.uint8, device=dev)      # world * B plsvo_pose_record
+    local = torch.zeros((B, 96), dtype=torch.uint8, device=dev)
     align_T = np.zeros((world * B, 7))
     stream = torch.cuda.Stream(dev)
     ctxs, comms = [], []
@@ -1007,8 +1008,9 @@ def test_config4_sharded_streams_and_pose_gather(P, ob):
                 c.poseopt_stage(pjobs)
                 c.align_run()
                 c.poseopt_run()
-                # the shard's block of the table: all-gather of n_local * 7 doubles straight from the library's pose buffer
-                c.gather_poses(comm, c.poseopt_poses_dev(), B, table.data_ptr() + r * B * 7 * 8)
+                # the shard's block of the table: its streams' 96-byte records packed on the device, then all-gathered
+                assert c.pack_pose_records(local.data_ptr()) == B
+                c.gather_poses(comm, local.data_ptr(), B, table.data_ptr() + r * B * 96)
                 c.synchronize()
                 ares, pres = c.align_fetch(), c.poseopt_fetch()
                 pyrs = [(c.download_pyramid(2 * i), c.download_pyramid(2 * i + 1)) for i in range(B)]
@@ -1024,12 +1026,20 @@ def test_config4_sharded_streams_and_pose_gather(P, ob):
                     assert ok3 and ang3 < 1e-9, f"stream {g}: pose-opt rot {ang3:.2e} trans {tr3:.2e}"
                     assert np.array_equal(pres[i].pt_keep, po.pt_keep) and np.array_equal(pres[i].seg_keep, po.seg_keep), g
                     align_T[g] = ares[i].T
-                    # the gathered record IS the pose the shard fetched
-                    assert np.array_equal(table[g].cpu().numpy(), np.asarray(pres[i].T)), g
+                    # the gathered record IS what the shard fetched: pose, SparseImgAlign::run's return value, the surviving observations
+                    rec = D.tensor_to_records(table[g:g + 1])[0]
+                    assert np.array_equal(rec["T_f_w"], np.asarray(pres[i].T)), g
+                    assert int(rec["n_tracked"]) == int(ares[i].n_tracked) == int(ro.n_tracked) and int(rec["stream"]) == i, g
+                    assert int(rec["num_obs_pt"]) == int(pres[i].num_obs_pt) == int(po.num_obs_pt), g
+                    assert int(rec["num_obs_ls"]) == int(pres[i].num_obs_ls) == int(po.num_obs_ls) and rec["error_final"] == pres[i].error_final, g
+                    assert int(rec["status"]) == (P.abi.REC_ALIGN | P.abi.REC_POSEOPT), g
         torch.cuda.synchronize()
         # rank-major concatenation: block r of the table holds shard r's streams, in seed order, nothing else touched
-        t = table.cpu().numpy()
+        recs = D.tensor_to_records(table)
+        t = recs["T_f_w"]
         assert np.all(np.isfinite(t)) and np.all(np.abs(np.linalg.norm(t[:, :4], axis=1) - 1.0) < 1e-12)
+        assert D.lost_streams(recs) == [] and list(recs["stream"]) == list(range(B)) * world
+        assert D.lost_streams(recs, min_tracked=10 ** 6) == list(range(world * B))   # the thresholds the host applies (frame_handler_mono.cpp:272-274)
     finally:
         for comm in comms:
             P.rccl.comm_destroy(comm)

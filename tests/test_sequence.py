@@ -151,6 +151,13 @@ def test_resident_chain_applies_the_reprojection_grid_rule(P, ob, gpu_ctx, seqm)
     order = np.random.default_rng(5).permutation(n_cols * n_rows).astype(np.int32)
     res = gpu_ctx.frame_step_batch(jobs, cam, n_pyr_levels=3, cell_size=cell_size, cell_rule=True, max_fts=max_fts, cell_order=order)
     free = gpu_ctx.frame_step_batch(jobs, cam, n_pyr_levels=3, cell_size=cell_size, cell_rule=False)
+    # the records a rank would publish for the resident step (plsvo_pack_pose_records / plsvo_fetch_pose_records): the pose the step ends with, run()'s return value,
+    # the optimiser's surviving observations -- straight from the device state, equal to what the fetch returned
+    recs = gpu_ctx.fetch_pose_records(len(jobs))
+    for s, f in enumerate(free):
+        assert np.array_equal(recs[s]["T_f_w"], np.asarray(f.pose.T)) and int(recs[s]["n_tracked"]) == int(f.align.n_tracked)
+        assert (int(recs[s]["num_obs_pt"]), int(recs[s]["num_obs_ls"])) == (int(f.pose.num_obs_pt), int(f.pose.num_obs_ls))
+        assert int(recs[s]["status"]) == (abi.REC_ALIGN | abi.REC_POSEOPT) and int(recs[s]["stream"]) == s
     for s, (r, f, seq, cj) in enumerate(zip(res, free, seqs, jobs)):
         n_pts = cj.n_cand_pt
         assert np.array_equal(r.found, f.found) and np.array_equal(r.px, f.px)        # the rule selects, it does not change the matching
