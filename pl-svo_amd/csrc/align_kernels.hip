@@ -39,6 +39,7 @@
 #include "plsvo_math.hpp"
 #include "plsvo_wave.hpp"
 #include "align_refpatch.hpp"
+#include "robust_weight.hpp"
 
 namespace plsvo_hip {
 
@@ -76,20 +77,12 @@ __device__ __forceinline__ void load_row7(const uint8_t* img, int pitch, int x, 
   o7[6] = (float)((w1 >> 16) & 0xffu);
 }
 
-// (float)(1.0 / (1.0 + (double)a)) for a float a >= 0 -- the reference's robust weight
-// (src/sparse_img_align.cpp:479) -- without a double division: 1 + a is split exactly into s_hi + s_lo
-// (two-sum), y0 = rcp(s_hi), the exact residual e = 1 - s_hi*y0 comes from one fma, and
-// y0 + y0*(e - s_lo*y0) is the quotient to ~1e-14 relative before the final rounding, i.e. the correctly
-// rounded float except when the quotient sits within ~1e-7 ulp of a rounding boundary.
-__device__ __forceinline__ float robust_weight(float a) {
-  const float s_hi = __fadd_rn(1.0f, a);
-  const float bv = __fsub_rn(s_hi, 1.0f);
-  const float s_lo = __fadd_rn(__fsub_rn(1.0f, __fsub_rn(s_hi, bv)), __fsub_rn(a, bv));  // exact: (1 + a) - s_hi
-  const float y0 = __builtin_amdgcn_rcpf(s_hi);
-  const float e = __fmaf_rn(-s_hi, y0, 1.0f);
-  const float c = __fmaf_rn(-s_lo, y0, e);
-  return __fmaf_rn(y0, c, y0);
-}
+// robust weight of a point pixel: robust_weight.hpp (the reference's (float)(1.0 / (1.0 + (double)|res|)) bit for bit)
+#ifdef PLSVO_WEIGHT_F32   // A/B only: the float-only form of rounds 1-2 (not bit-exact on ~1e-7 of the inputs)
+__device__ __forceinline__ float robust_weight(float a) { return robust_weight_f32(a); }
+#else
+__device__ __forceinline__ float robust_weight(float a) { return robust_weight_f64(a); }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // PLSVO_BYTE_CACHE (experiment build, `make byte_cache`): the per-slot cache of the reference patch holds the 7x7 window of image BYTES

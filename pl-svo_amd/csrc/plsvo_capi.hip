@@ -1227,7 +1227,8 @@ extern "C" int plsvo_chain_stage(plsvo_ctx* c, int n, const plsvo_chain_in* in, 
       if (ty == PLSVO_FTR_EDGELET) any_edgelet = true; else if (ty != PLSVO_FTR_CORNER) return fail(c, PLSVO_E_INVALID, "chain_stage: unknown feature type");
       if (ty == PLSVO_FTR_EDGELET && !a.ref_grad) return fail(c, PLSVO_E_INVALID, "chain_stage: edgelets without ref_grad");
       rtype.push_back(ty);
-      rgrad.push_back(a.ref_grad ? a.ref_grad[2 * k] : 0.0); rgrad.push_back(a.ref_grad ? a.ref_grad[2 * k + 1] : 0.0);
+      const bool has_grad = a.ref_grad && k < a.n_cand_pt;   // ref_type / ref_grad are sized by the POINT candidates (header); end points: 0
+      rgrad.push_back(has_grad ? a.ref_grad[2 * k] : 0.0); rgrad.push_back(has_grad ? a.ref_grad[2 * k + 1] : 0.0);
       rlevel.push_back(a.ref_level[k]);
       active.push_back(a.active ? (a.active[k] ? 1 : 0) : 1);
       if (a.active) any_active = true;
