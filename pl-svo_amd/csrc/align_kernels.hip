@@ -84,43 +84,6 @@ __device__ __forceinline__ float robust_weight(float a) { return robust_weight_f
 __device__ __forceinline__ float robust_weight(float a) { return robust_weight_f64(a); }
 #endif
 
-// ------------------------------------------------------------------------------------------------
-// PLSVO_BYTE_CACHE (experiment build, `make byte_cache`): the per-slot cache of the reference patch holds the 7x7 window of image BYTES
-// and the two sub-pixel fractions (one 64-B record: 7 rows of 8 B, then su, sv) instead of 3 x 16 floats of interpolated intensity and
-// gradient (192 B).  Every iteration rebuilds ref / dx / dy from the record with the very operations the precompute used, so the values
-// -- and every result -- are bit-identical; per patch-iteration the kernel streams 64 B instead of 192 B and pays ~200 more float
-// operations per lane.  The record lives in the cache_ref array (16 floats = 64 B per slot); cache_dx / cache_dy are not touched.
-// ------------------------------------------------------------------------------------------------
-#ifndef PLSVO_BYTE_CACHE
-#define PLSVO_BYTE_CACHE 0
-#endif
-// PLSVO_TIE_RECOMPUTE (experiment build, `make tie_recompute`): a near tie whose per-pixel terms were NOT kept (HBM planes are written only
-// while the solver is armed: 19 of 2083 near ties over 1000 emulated config-2 frames, 4 of which then leave the oracle's path -- among
-// them the sweep's worst error, 1.6e-3 of the inter-frame translation) re-runs the pixel arithmetic of the point patches for the
-// missing iteration(s) -- stage 1: this iteration's pose, stage 2: the previous one's (old_model_) -- writes the planes, and only then
-// decides.  Nothing changes on the path every other iteration takes; with the switch off the stage loop folds away.
-#ifndef PLSVO_TIE_RECOMPUTE
-#define PLSVO_TIE_RECOMPUTE 0
-#endif
-template <bool TILED>
-__device__ __forceinline__ uint2 load_row8_raw(const uint8_t* img, int pitch, int x, int y) {   // bytes [x, x+8) of row y (same requests as load_row7)
-  uint32_t d0, d1, d2, sh;
-  if constexpr (TILED) {
-    const int a = x & ~3;
-    sh = (uint32_t)(x & 3);
-    const int row = tiled_row_offset(pitch, y);
-    d0 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a)));
-    d1 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a + 4)));
-    d2 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a + 8)));
-  } else {
-    const int off = y * pitch + x, a = off & ~3;
-    sh = (uint32_t)(off & 3);
-    d0 = *reinterpret_cast<const uint32_t*>(img + a);
-    d1 = *reinterpret_cast<const uint32_t*>(img + a + 4);
-    d2 = *reinterpret_cast<const uint32_t*>(img + a + 8);
-  }
-  return make_uint2(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh));
-}
 // optional per-phase timing (compile with -DPLSVO_TIMING): thread 0 accumulates s_memtime deltas
 #ifdef PLSVO_TIMING
 #define TICK(slot) do { if (tid == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); s_time[slot] += t__ - s_tlast; s_tlast = t__; } } while (0)
@@ -136,25 +99,11 @@ __device__ __forceinline__ void block_sync() {
   if constexpr (T == 64) wave_lds_fence(); else __syncthreads();
 }
 
-// store of one patch row of chi2 terms (written every iteration, read on near ties only)
-#ifndef PLSVO_CHI_NT
-#define PLSVO_CHI_NT 0
-#endif
 // launch shapes up to this many threads per frame read the tiled pyramid mirror, larger ones the row-major slab (load_row7).
 // Measured: 64 threads (32768 frames, the chip saturated) -7 % launch time tiled; 128 threads (8192 frames) +4 % tiled; 512 +12 % per pass.
-#ifndef PLSVO_TILED_MAX_T
-#define PLSVO_TILED_MAX_T 64
-#endif
+constexpr int kTiledMaxThreads = 64;
 // half-width of the near-tie band, in units of sqrt(n_meas) * 2^-24 (one sigma of the reference's float sum is ~0.25 of that)
-#ifndef PLSVO_CHI_BAND
-#define PLSVO_CHI_BAND 1.5f
-#endif
-#if PLSVO_CHI_NT
-typedef float plsvo_f4 __attribute__((ext_vector_type(4)));
-#define PLSVO_CHI_STORE(ptr, val) __builtin_nontemporal_store(plsvo_f4{ (val).x, (val).y, (val).z, (val).w }, reinterpret_cast<plsvo_f4*>(ptr))
-#else
-#define PLSVO_CHI_STORE(ptr, val) (*(ptr) = (val))
-#endif
+constexpr float kChiBand = 1.5f;
 
 // LDS layout shared by the kernel and the host-side size helper: the tables end at this offset, the 4 KB window follows
 __host__ __device__ inline size_t align_chi_window_offset(int threads, int cap, int scap) {
@@ -348,9 +297,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     s_pose[26] = st->chi2; s_pose[28] = 0.0; s_pose[29] = 0.0; s_pose[31] = 0.0;
     for (int k = 0; k < 32; ++k) s_tot[k] = 0.0;
     s_ctl[1] = st->stop; s_ctl[3] = 0; s_ctl[6] = 0; s_ctl[9] = 0;
-#if PLSVO_TIE_RECOMPUTE
     s_ctl[10] = 0;
-#endif
   }
   if (b.chi_lds_pts > 0) {   // LDS planes: the slots between the last point and the next multiple of 4 are read by the exact sums: +0
     const int tail0 = job.n_pts * 16, tail1 = ((job.n_pts + 3) & ~3) * 16;
@@ -365,7 +312,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     //  which would force the whole argument struct into scratch memory)
     const int W = job.width >> level, Hh = job.height >> level;
     // throughput shapes read the tiled mirror of the pyramids, latency shapes the row-major slab (load_row7)
-    constexpr bool kTiled = T <= PLSVO_TILED_MAX_T;
+    constexpr bool kTiled = T <= kTiledMaxThreads;
     const unsigned int lvl_off = kTiled ? pyr_tiled_level_offset(job.width, job.height, level) : pyr_level_offset(job.width, job.height, level);
     const uint8_t* const pyr_base = kTiled ? b.pyr.tbase : b.pyr.base;
     const unsigned long long pyr_slot = kTiled ? b.pyr.tslot_bytes : b.pyr.slot_bytes;
@@ -457,16 +404,6 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       if (p < n_slots && s_meta[p].x != SLOT_HOLE) {
         const float u = b.patch_uvref[2 * (pbase + p)], v = b.patch_uvref[2 * (pbase + p) + 1];
         const PatchW pw = patch_weights(u, v);
-#if PLSVO_BYTE_CACHE
-        {   // lane `row` of the slot's four writes record rows `row` and `row + 4` (image rows vi-3+.., columns ui-3 .. ui+3); lane 3 the fractions
-          unsigned char* const rec = reinterpret_cast<unsigned char*>(b.cache_ref) + ((pbase + p) << 6);
-          const int cx = pw.ui - 3, ry = pw.vi - 3 + row;
-          *reinterpret_cast<uint2*>(rec + 8 * row) = load_row8_raw<kTiled>(ref_img, pitch, cx, ry);
-          if (row < 3) *reinterpret_cast<uint2*>(rec + 8 * (row + 4)) = load_row8_raw<kTiled>(ref_img, pitch, cx, ry + 4);
-          else *reinterpret_cast<float2*>(rec + 56) = make_float2(u - floorf(u), v - floorf(v));
-          continue;
-        }
-#endif
         // patch row `row` sits on image row vi-2+row; the stencil needs image rows -1..+2 around it
         const int r0 = pw.vi - 2 + row - 1;
         const int c0 = pw.ui - 2 - 1;
@@ -491,24 +428,19 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     const double f_sel = half ? job.fy : job.fx, c_sel = half ? job.cy : job.cx;
 
     for (int iter = 0; iter < job.n_iter; ++iter) {
-#if PLSVO_TIE_RECOMPUTE
+     // A near tie whose per-pixel terms were NOT kept (HBM planes are written only while the solver is armed: 471 of 69 631 near ties
+     // of a 32768-frame step; over 1000 seeds 4 of 19 such ties went the other way, among them the sweep's worst error, 1.6e-3 of the
+     // inter-frame translation) re-runs the pixel arithmetic of the point patches for the missing iteration(s) -- stage 1: this
+     // iteration's pose, stage 2: the previous one's (old_model_) -- writes the planes, and only then decides.  Nothing changes on the
+     // path every other iteration takes (measured on MI355X: +0.9 % launch time, both tie cases follow the oracle).
      int redo_mask = 0;   // bit 0 = this iteration's terms are missing, bit 1 = the previous iteration's (workgroup-uniform)
      for (int stage = 0; stage < 3; ++stage) {   // 0: the iteration proper; 1, 2: terms-only re-runs of a near tie (rare)
       if (stage > 0 && !(redo_mask & stage)) continue;
       const bool terms_only = stage > 0;
       const int last_stage = (redo_mask & 2) ? 2 : ((redo_mask & 1) ? 1 : 0);
-#else
-     {
-      constexpr int stage = 0, last_stage = 0;
-      constexpr bool terms_only = false;
-#endif
       // this lane's share of the pose: the row of R (and t) of its image coordinate, and the depth row (stage 2: of the previous
       // iteration's pose, whose rotation matrix thread 0 left in s_red -- free between the reduction and the next pass)
-#if PLSVO_TIE_RECOMPUTE
       const double* const pose_rt = (stage == 2) ? s_red : s_pose;
-#else
-      const double* const pose_rt = s_pose;
-#endif
       const double Ra = pose_rt[3 * half], Rb = pose_rt[3 * half + 1], Rc = pose_rt[3 * half + 2], ta = pose_rt[9 + half];
       const double Rz0 = pose_rt[6], Rz1 = pose_rt[7], Rz2 = pose_rt[8], tz = pose_rt[11];
 
@@ -516,11 +448,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       // when two successive chi2 values can come within the rounding noise of the reference's sums (99 % of the near ties of 60
       // config-2 frames had both iterations armed; 64 % of all iterations are).  LDS planes (small batches) are always written.
       const bool store_chi = terms_only || b.chi_lds_pts > 0 || s_ctl[7] != 0;
-#if PLSVO_TIE_RECOMPUTE
       const int chi_par = (stage == 2) ? ((iter & 1) ^ 1) : (iter & 1);
-#else
-#define chi_par (iter & 1)
-#endif
       float* const chi_it = b.chi_terms + (size_t)chi_par * b.chi_plane + (size_t)job.pt_off * 16;   // this iteration's plane of the points' chi2 terms (stage 2: the previous iteration's)
 
       double acc[32];   // 0..20 H (upper, row-major), 21..26 Jres, 27 chi2, 28 n_meas, 29 evals, 30 evals of point patches whose chi2 terms went to HBM, 31 unused
@@ -531,27 +459,18 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       for (int pass = (long_lines && !terms_only) ? 0 : 1; pass < 2; ++pass) {
         const bool write_abs = (!long_lines || pass == 0) && !terms_only;
         const bool accumulate = pass == 1 && !terms_only;
-#if PLSVO_TIE_RECOMPUTE
         const int n_rounds_slots = terms_only ? min(n_slots, job.n_pts) : n_slots;   // a terms-only re-run visits the point slots only
-#else
-#define n_rounds_slots n_slots
-#endif
-        // Three stages per slot, software-pipelined over the rounds of the pass (PLSVO_PIPELINE = depth):
+        // Three stages per slot, software-pipelined over the rounds of the pass:
         //   stage A  table entry + 3-D point                      (does not depend on the pose)
         //   stage B  warp + project the point, gather the 5x5 window of the current image (needs A)
         //   stage C  cached reference patch rows 2h, 2h+1 -> residuals, patch sums, line weights, expansion (needs B)
-        // depth 1 (default): the loads of stages A and C of round r+1 are issued right after the pixel arithmetic of round r --
-        //   the registers of r's cache rows are dead there, the latency overlaps r's line weights and expansion
-        //   (measured: -2.7 % launch time at 32768 frames, nothing at small batches);
-        // depth 2: round r+1 is also projected and its image window requested before r's arithmetic (measured: 11 spilled
-        //   VGPRs, no gain over depth 1); depth 0: no pipelining.
+        // The loads of stages A and C of round r+1 are issued right after the pixel arithmetic of round r -- the registers of r's
+        // cache rows are dead there, the latency overlaps r's line weights and expansion (measured: -2.7 % launch time at 32768
+        // frames, nothing at small batches; also projecting round r+1 and requesting its window a round ahead spilled 11 VGPRs and
+        // gained nothing: DESIGN.md 3.1).
         struct SlotA { int2 meta; bool cand; double X, Y, Z; };
         struct SlotB { bool live; float u, v; int sh0, sh1, sh2; uint32_t r0a, r0b, r1a, r1b, r2a, r2b; };
-#if PLSVO_BYTE_CACHE
-        struct SlotC { uint4 q01, q23; uint2 q4; float2 sw; };
-#else
         struct SlotC { float4 vr0, vx0, vy0, vr1, vx1, vy1; };
-#endif
         auto stage_a = [&](int pb_) -> SlotA {
           SlotA f;
           const int p_ = pb_ + pair;
@@ -609,17 +528,6 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         };
         auto stage_c_loads = [&](int pb_, bool cand_) -> SlotC {
           SlotC c;
-#if PLSVO_BYTE_CACHE
-          c.q01 = make_uint4(0u, 0u, 0u, 0u); c.q23 = c.q01; c.q4 = make_uint2(0u, 0u); c.sw = make_float2(0.f, 0.f);
-          if (cand_) {
-            const unsigned char* const rec = reinterpret_cast<const unsigned char*>(b.cache_ref) + ((pbase + pb_ + pair) << 6);
-            c.q01 = *reinterpret_cast<const uint4*>(rec + 16 * half);
-            c.q23 = *reinterpret_cast<const uint4*>(rec + 16 * half + 16);
-            c.q4 = *reinterpret_cast<const uint2*>(rec + 16 * half + 32);
-            c.sw = *reinterpret_cast<const float2*>(rec + 56);
-          }
-          return c;
-#else
           c.vr0 = make_float4(0.f, 0.f, 0.f, 0.f); c.vx0 = c.vr0; c.vy0 = c.vr0; c.vr1 = c.vr0; c.vx1 = c.vr0; c.vy1 = c.vr0;
           if (cand_) {
             const size_t q = (pbase + pb_ + pair) * 4 + 2 * half;
@@ -628,36 +536,14 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
             c.vy0 = reinterpret_cast<const float4*>(b.cache_dy)[q];  c.vy1 = reinterpret_cast<const float4*>(b.cache_dy)[q + 1];
           }
           return c;
-#endif
         };
-#ifndef PLSVO_PIPELINE
-#define PLSVO_PIPELINE 1
-#endif
-#if PLSVO_PIPELINE >= 2
-        SlotA a_cur = stage_a(0);
-        SlotC c_cur = stage_c_loads(0, a_cur.cand);
-        SlotB b_cur = stage_b(a_cur);
-        SlotA a_nxt = stage_a(T / 2);
-#elif PLSVO_PIPELINE == 1
         SlotA a_nxt = stage_a(0);
         SlotC c_nxt = stage_c_loads(0, a_nxt.cand);
-#endif
         for (int pb = 0; pb < n_rounds_slots; pb += T / 2) {
           const int p = pb + pair;
-#if PLSVO_PIPELINE >= 2
-          const SlotA sa = a_cur;
-          const SlotB sb = b_cur;
-          const SlotC sc = c_cur;
-          b_cur = stage_b(a_nxt);                       // round r+1: project, request its image window
-#elif PLSVO_PIPELINE == 1
           const SlotA sa = a_nxt;
           const SlotC sc = c_nxt;
           const SlotB sb = stage_b(sa);
-#else
-          const SlotA sa = stage_a(pb);
-          const SlotC sc = stage_c_loads(pb, sa.cand);
-          const SlotB sb = stage_b(sa);
-#endif
           const int2 meta = sa.meta;
           const bool hole = meta.x == SLOT_HOLE;
           const bool is_line = !hole && meta.x < 0;
@@ -665,12 +551,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           const double X = sa.X, Y = sa.Y, Z = sa.Z;
           const float u = sb.u, v = sb.v;
           const bool live = sb.live;
-#if PLSVO_BYTE_CACHE
-          float4 vr0, vx0, vy0, vr1, vx1, vy1;
-          if (live) ref_rows_from_record(sc.q01, sc.q23, sc.q4, sc.sw.x, sc.sw.y, vr0, vx0, vy0, vr1, vx1, vy1);
-#else
           const float4 vr0 = sc.vr0, vx0 = sc.vx0, vy0 = sc.vy0, vr1 = sc.vr1, vx1 = sc.vx1, vy1 = sc.vy1;
-#endif
 
           // -- residuals and the five patch sums over this lane's two patch rows (8 pixels)
           double sA = 0, sB = 0, sC = 0, sD = 0, sE = 0, sChi = 0;
@@ -737,29 +618,21 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           sA += dpp_mov_f64<DPP_QUAD_XOR1>(sA); sB += dpp_mov_f64<DPP_QUAD_XOR1>(sB); sC += dpp_mov_f64<DPP_QUAD_XOR1>(sC);
           sD += dpp_mov_f64<DPP_QUAD_XOR1>(sD); sE += dpp_mov_f64<DPP_QUAD_XOR1>(sE); sChi += dpp_mov_f64<DPP_QUAD_XOR1>(sChi);
           sAbs += dpp_mov_f32<DPP_QUAD_XOR1>(sAbs);
-#if PLSVO_PIPELINE >= 2
-          a_cur = a_nxt;                                   // (slots beyond the table come back as holes: no loads)
-          c_cur = stage_c_loads(pb + T / 2, a_cur.cand);   // round r+1's cache rows: r's are dead now
-          a_nxt = stage_a(pb + T);                         // round r+2's table entry + 3-D point
-#elif PLSVO_PIPELINE == 1
           a_nxt = stage_a(pb + T / 2);
           c_nxt = stage_c_loads(pb + T / 2, a_nxt.cand);
-#endif
           // The chi2 terms of a POINT slot (16 floats) go to this iteration's plane of chi_terms, placed after the next round's loads
           // have been issued: the compiler cannot prove that these stores do not alias the cache arrays, and a store inside the
           // pixel arithmetic pins every later load behind it (measured +31 % launch time there, and the launch is within a few
           // per cent of the achievable HBM rate: every byte written costs its time, which is why line pixels are not stored).
-#ifndef PLSVO_CHI_NOSTORE   // (experiment switch: cost of keeping the terms)
           if ((accumulate || terms_only) && store_chi && p < job.n_pts) {
             if (b.chi_lds_pts > 0) {   // small batches: the planes are in LDS (kernel-uniform)
               float4* const chi_dst = reinterpret_cast<float4*>(s_win + (iter & 1) * b.chi_lds_pts * 16 + p * 16 + 8 * half);
               chi_dst[0] = chi_t0; chi_dst[1] = chi_t1;
             } else {
               float4* const chi_dst = reinterpret_cast<float4*>(chi_it + (unsigned)(p * 16 + 8 * half));   // wave-uniform base + 32-bit lane offset
-              PLSVO_CHI_STORE(chi_dst, chi_t0); PLSVO_CHI_STORE(chi_dst + 1, chi_t1);
+              chi_dst[0] = chi_t0; chi_dst[1] = chi_t1;
             }
           }
-#endif
 
           // -- weights: points 1; a line's samples share w / mean|res| (H) and w (Jres), :640-688
           double wh = 0.0, wj = 0.0;
@@ -845,11 +718,10 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         double old_chi2 = s_pose[26];                                          // solver chi2_
         // the reference's sequential float sums sit within ~0.25 sqrt(n) 2^-24 (one sigma) of these: inside 2 sqrt(n) 2^-24
         // (> 5 sigma of the difference of two such sums) the order of the two values is taken from the exact float sums
-        const float band = PLSVO_CHI_BAND * __fsqrt_rn((float)nm_d) * 5.9604644775390625e-8f;
+        const float band = kChiBand * __fsqrt_rn((float)nm_d) * 5.9604644775390625e-8f;
         const bool near = iter > 0 && !s_ctl[1] && !isnan(x[0]) && fabs(new_chi2 - old_chi2) <= (double)band * old_chi2;
         const bool have_terms = terms_only || b.chi_lds_pts > 0 || (s_ctl[7] != 0 && s_ctl[8] != 0);   // both iterations' terms were kept (or have just been rebuilt)
         const bool tie = near && have_terms;
-#if PLSVO_TIE_RECOMPUTE
         const bool defer = near && !have_terms;   // wave-uniform: rebuild the missing plane(s) first, decide afterwards
         if (defer && lane == 0) {
           s_ctl[10] = (s_ctl[7] != 0 ? 0 : 1) | (s_ctl[8] != 0 ? 0 : 2);
@@ -858,19 +730,12 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
             quat_to_matrix(om.q, s_red); s_red[9] = om.t[0]; s_red[10] = om.t[1]; s_red[11] = om.t[2];
           }
         }
-#else
-        constexpr bool defer = false;
-#endif
         if (tie) {   // wave-uniform
           if (b.chi_lds_pts > 0)
             exact_chi2_pair_lds((const PLSVO_LDS float*)(s_win + (iter & 1) * b.chi_lds_pts * 16), (const PLSVO_LDS float*)(s_win + ((iter & 1) ^ 1) * b.chi_lds_pts * 16),
                                 job.n_pts, job.n_seg, iter, (const PLSVO_LDS int*)s_dead, (const PLSVO_LDS float*)s_lterm, scap, (PLSVO_LDS float*)s_lterm + 2 * scap);
           else
-#if PLSVO_TIE_RECOMPUTE   // (chi_it is the plane a terms-only stage writes, not necessarily this iteration's)
             exact_chi2_pair((const PLSVO_GLOBAL float*)(b.chi_terms + (size_t)(iter & 1) * b.chi_plane + (size_t)job.pt_off * 16),
-#else
-            exact_chi2_pair((const PLSVO_GLOBAL float*)chi_it,
-#endif
                             (const PLSVO_GLOBAL float*)(b.chi_terms + (size_t)((iter & 1) ^ 1) * b.chi_plane + (size_t)job.pt_off * 16),
                             job.n_pts, job.n_seg, iter, (const PLSVO_LDS int*)s_dead, (PLSVO_LDS float*)s_win, (const PLSVO_LDS float*)s_lterm, scap,
                             (PLSVO_LDS float*)s_lterm + 2 * scap);
@@ -879,7 +744,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           old_chi2 = (double)(FB / (float)(unsigned long long)(s_pose[30] + 0.5));
         }
         if (lane == 0 && !defer) {
-          if (PLSVO_TIE_RECOMPUTE) s_ctl[10] = 0;
+          s_ctl[10] = 0;
           s_pose[27] += ev_d;
           s_pose[31] += ev_pt;
           s_pose[30] = nm_d;                                                   // n_meas_ of this iteration, for the next one's tie
@@ -922,9 +787,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       }
       TICK(5);
       block_sync<T>();
-#if PLSVO_TIE_RECOMPUTE
       if (stage == 0) redo_mask = s_ctl[10];   // (0 unless wave 0 deferred its decision)
-#endif
      }   // stages of the iteration
       if (b.log && tid == 0) {  // H and Jres of the trace come from s_tot (written by lanes 0..26 above)
         const int lc = st->log_count - 1;
@@ -964,10 +827,6 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   }
 }
 
-#if !PLSVO_TIE_RECOMPUTE
-#undef chi_par
-#undef n_rounds_slots
-#endif
 
 // LDS bytes the kernel needs for slot capacity `cap` and segment capacity `scap` (host side helper)
 size_t align_level_lds_bytes(int threads, int cap, int scap, int chi_lds_pts) { return align_lds_used(threads, cap, scap, chi_lds_pts); }
@@ -975,14 +834,8 @@ size_t align_level_lds_bytes(int threads, int cap, int scap, int chi_lds_pts) { 
 }  // namespace plsvo_hip
 extern "C" const char* plsvo_hip_build_flags(void) {
   return ""
-#if PLSVO_BYTE_CACHE
-         "byte_cache "
-#endif
 #if PLSVO_LDS_IMG
          "lds_img "
-#endif
-#if PLSVO_TIE_RECOMPUTE
-         "tie_recompute "
 #endif
       ;
 }

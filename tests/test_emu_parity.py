@@ -145,11 +145,12 @@ def test_smoke_entry_dry_run(emu_lib):
     assert out.returncode == 0 and "smoke DRY RUN on the host emulation build ok" in out.stdout, out.stdout[-1000:] + out.stderr[-2000:]
 
 
-def test_tie_recompute_variant_follows_the_oracle_where_the_default_build_cannot(emu_lib, tmp_path):
-    """Seed 4373 of config 2 at the one-wave-per-frame shape: its near tie at level 2 falls on an iteration whose per-pixel chi2 terms the
-    default build did not keep (the step before was not small yet), the decision is taken on the rounded-once sums, goes the other way
-    and the frame ends 1.6e-3 of its inter-frame translation from the oracle -- the worst of 1000 emulated seeds.  Built with
-    -DPLSVO_TIE_RECOMPUTE=1 the kernel rebuilds the missing terms first and follows the oracle (1e-9)."""
+def test_near_ties_on_unarmed_iterations_follow_the_oracle(emu_lib):
+    """Seed 4373 of config 2 at the one-wave-per-frame shape: its near tie at level 2 falls on an iteration whose per-pixel chi2 terms were
+    not kept (the step before was not small yet).  Round 3's build decided it on the rounded-once sums, went the other way and ended 1.6e-3
+    of the inter-frame translation from the oracle -- the worst of 1000 emulated seeds; the kernel now rebuilds the missing terms first
+    (stages 1 / 2 of an iteration) and follows the oracle (1e-9).  Same at config 3's benchmark shape (seed 5348: 9.5e-3 before).
+    The MI355X runs the same cases in tests/test_gpu_parity.py::test_near_tie_on_an_unarmed_iteration_follows_the_oracle."""
     import json
 
     def run(lib, threads, seed="4373", *more):
@@ -158,17 +159,10 @@ def test_tie_recompute_variant_follows_the_oracle_where_the_default_build_cannot
         assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-2000:]
         return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 
-    lib_tr = build_emu(tmp_path / "emu_tr", "", "-DPLSVO_TIE_RECOMPUTE=1")
-    for threads in (64, 128):      # 128: two waves per frame, the re-run passes go through the workgroup barriers
-        base = run(emu_lib, threads)
-        assert not base["same_path"] and base["near_ties_without_terms"] == 1 and base["inter_trans_rel"] > 1e-4      # the case is what it claims to be
-        var = run(lib_tr, threads)
-        assert var["same_path"] and var["near_ties_without_terms"] == 0 and var["decided_on_exact_sums"] == base["decided_on_exact_sums"] + 1
-        assert var["inter_trans_rel"] < 1e-7 and var["inter_rot_rad"] < 1e-9 and var["iters_device"] == var["iters_oracle"]
-    # the same at config 3's benchmark shape: seed 5348 is the worst of 600 emulated seeds there (9.5e-3 of the inter-frame translation, 8e-5 rad)
-    base, var = run(emu_lib, 128, "5348", "config3"), run(lib_tr, 128, "5348", "config3")
-    assert not base["same_path"] and base["near_ties_without_terms"] == 1 and base["inter_trans_rel"] > 1e-3
-    assert var["same_path"] and var["near_ties_without_terms"] == 0 and var["inter_trans_rel"] < 1e-7
+    for args in ((64,), (128,), (128, "5348", "config3")):      # 128: two waves per frame, the re-run passes go through the workgroup barriers
+        var = run(emu_lib, *args)
+        assert var["same_path"] and var["near_ties_without_terms"] == 0 and var["decided_on_exact_sums"] >= 2, var
+        assert var["inter_trans_rel"] < 1e-7 and var["inter_rot_rad"] < 1e-9 and var["iters_device"] == var["iters_oracle"], var
 
 
 def run_variant(lib, out_pkl):
@@ -191,14 +185,14 @@ def patched_sources(tmp_path, patch_name):
     return w / "pl-svo_amd" / "csrc"
 
 
-@pytest.mark.parametrize("variant", ["byte_cache", "lds_img", "byte_cache+lds_img", "dpp_exact_sum"])
+@pytest.mark.parametrize("variant", ["lds_img", "dpp_exact_sum"])
 def test_kernel_variants_are_bitwise_the_default_build(emu_lib, tmp_path, variant):
-    """A/B builds of align_fused_kernel that exist for speed only -- the byte-record reference-patch cache (-DPLSVO_BYTE_CACHE=1), a level
-    of the current image staged in spare LDS (-DPLSVO_LDS_IMG=1: level 3 at 64 threads per frame, levels 3 and 2 at 256), both together,
-    and the DPP form of the slot-parallel near-tie sums (tools/patches/) -- must return, bit for bit, what the default build returns: poses,
+    """A/B builds of align_fused_kernel that exist for speed only -- a level of the current image staged in spare LDS (-DPLSVO_LDS_IMG=1:
+    level 3 at 64 threads per frame, levels 3 and 2 at 256) and the DPP form of the slot-parallel near-tie sums (tools/patches/) -- must
+    return, bit for bit, what the default build returns: poses,
     counts, culled segments, every iteration's chi2 and step, the number of near ties resolved; at 64 and 256 threads per frame."""
     base = run_variant(emu_lib, tmp_path / "base.pkl")
-    flags = {"byte_cache": ["-DPLSVO_BYTE_CACHE=1"], "lds_img": ["-DPLSVO_LDS_IMG=1"], "byte_cache+lds_img": ["-DPLSVO_BYTE_CACHE=1", "-DPLSVO_LDS_IMG=1"]}
+    flags = {"lds_img": ["-DPLSVO_LDS_IMG=1"]}
     if variant in flags:
         lib = build_emu(tmp_path / "emu_variant", "", *flags[variant])
     else:

@@ -111,10 +111,49 @@ SWEEPS = [
     ("config2", 4000, 150, 640, 480, 200, 80, 4, 3, 1, 0),
     ("config3", 5000, 60, 1280, 720, 400, 150, 5, 4, 2, 0),
     # the benchmark's launch shape: one wave per frame, tiled pyramid mirror, chi2 terms in HBM planes kept only while the steps are small
-    ("config2-one-wave-per-frame", 4000, 60, 640, 480, 200, 80, 4, 3, 1, 64),
-    # config 3 at ITS benchmark shape (8192 streams -> two waves per frame: row-major slab, HBM planes, arming)
-    ("config3-two-waves-per-frame", 5000, 40, 1280, 720, 400, 150, 5, 4, 2, 128),
+    # (seeds 4300..4449: the window holds seed 4373, whose near tie falls on an iteration whose terms were not kept)
+    ("config2-one-wave-per-frame", 4300, 150, 640, 480, 200, 80, 4, 3, 1, 64),
+    # config 3 at ITS benchmark shape (8192 streams -> two waves per frame: row-major slab, HBM planes, arming); the window holds seed 5348
+    ("config3-two-waves-per-frame", 5320, 40, 1280, 720, 400, 150, 5, 4, 2, 128),
 ]
+
+
+TIE_CASES = [
+    # seed, threads per frame, (W, H, points, segments, pyramid images, max_level, min_level): frames on which a near tie of the solver's
+    # `new_chi2 > chi2_` decision falls on an iteration whose per-pixel chi2 terms were not kept (HBM planes are written only while the
+    # steps are small).  Round 3's build decided those on the rounded-once sums and left the oracle's path: 1.6e-3 / 9.5e-3 of the
+    # inter-frame translation, 1.9e-4 / 3.2e-4 on T_f_w -- outside the bar.  The kernel now rebuilds the missing terms before deciding.
+    (4373, 64, (640, 480, 200, 80, 4, 3, 1)),
+    (5348, 128, (1280, 720, 400, 150, 5, 4, 2)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", TIE_CASES, ids=[f"seed{c[0]}-{c[1]}threads" for c in TIE_CASES])
+def test_near_tie_on_an_unarmed_iteration_follows_the_oracle(P, ob, gpu_ctx, case):
+    """The two frames the 1000-seed sweeps found at the launch shapes the benchmark runs (config 2 at one wave per frame, config 3 at two):
+    same Gauss-Newton path as the oracle, record for record, the bar of BASELINE.json on T_f_w AND on T_cur_from_ref, and no near tie
+    decided without the reference's float sums (src/sparse_img_align.cpp:171,192,484,683 + the vikit loop)."""
+    seed, threads, (W, H, npts, nseg, nlev, maxl, minl) = case
+    st, ref, cur, job = Hh.make_case(ob, seed, W, H, npts, nseg, nlev, maxl, minl)
+    res_o, log_o = ob.sparse_align(job, ref, cur, max_log=200)
+    gpu_ctx.set_launch_shapes(align_threads=threads)
+    try:
+        gpu_ctx.config_pyramids(2, W, H, nlev)
+        gpu_ctx.upload_pyramid(0, ref)
+        gpu_ctx.upload_pyramid(1, cur)
+        gpu_ctx.align_set_trace(200)
+        res_d = gpu_ctx.sparse_align(job)
+        log_d = gpu_ctx.align_fetch_trace(0)
+        iters, ties, unarmed = gpu_ctx.align_chi2_ties()
+    finally:
+        gpu_ctx.set_launch_shapes(align_threads=0)
+    assert Hh.same_path(log_o, log_d), (res_o.iters_per_level[:5], res_d.iters_per_level[:5])
+    assert unarmed == 0 and ties >= 2            # both frames have a near tie on an armed AND on an unarmed iteration
+    ang, tr, ok = Hh.pose_close(Hh.frame_pose(res_d.T, st), Hh.frame_pose(res_o.T, st))
+    ang2, tr2, ok2 = Hh.pose_close(res_d.T, res_o.T)
+    assert ok and ok2 and ang2 < 1e-8 and tr2 < 1e-7, (ang, tr, ang2, tr2)
+    assert res_d.n_meas == res_o.n_meas and res_d.iters_per_level == res_o.iters_per_level and np.array_equal(res_d.seg_alive, res_o.seg_alive)
 
 
 @pytest.mark.parametrize("sweep", SWEEPS, ids=[c[0] for c in SWEEPS])
@@ -197,12 +236,7 @@ def _seed_sweep_body(P, ob, gpu_ctx, tag, seed0, n_seeds, W, H, npts, nseg, nlev
                     gaps = [abs(info["new_chi2"][i] - info["prev_chi2"][i]) / info["prev_chi2"][i] for i in range(2)] if k_ >= 1 else [1.0, 1.0]
                     info["kind"], info["chi2_gap_rel"] = "chi2 within 4 float ulps", gaps
                     if not max(gaps) <= 4 * 1.2e-7:
-                        # one-wave-per-frame launches keep the per-pixel terms only while the solver's steps are small: a near tie met
-                        # before that (0.7 % of them) is decided on the exactly-rounded sums, like every near tie was in round 2
-                        if unarmed > 0 and max(gaps) <= 1e-5:
-                            info["kind"] = "near tie met before the per-pixel terms were kept"
-                        else:
-                            failures.append({"seed": seed, "what": "paths part on a chi2 comparison that is not a last-bit tie", "info": info})
+                        failures.append({"seed": seed, "what": "paths part on a chi2 comparison that is not a last-bit tie", "info": info})
                 else:
                     info["kind"] = "||x|| within 2 % of eps"
                     if not all(abs(v - 1e-6) < 2e-8 for v in info["x_norm"]):
@@ -221,6 +255,7 @@ def _seed_sweep_body(P, ob, gpu_ctx, tag, seed0, n_seeds, W, H, npts, nseg, nlev
     json.dump(out, open(os.path.join(root, "gpurun_out", f"parity_seed_sweep_{tag}.json"), "w"), indent=1)
     print(json.dumps(out))
     assert not failures, failures
+    assert unarmed == 0, unarmed      # every near tie was decided on the reference's float sums (missing terms are rebuilt first)
     assert len(different) <= max(2, n_seeds // 25), different     # measured: 2 of 150 (config 2), 1 of 60 (config 3)
 
 
