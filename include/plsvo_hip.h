@@ -70,7 +70,7 @@ void plsvo_hip_destroy(plsvo_ctx* ctx);
  * differ with fewer than three point observations.  Takes effect at the next *_stage call. */
 #define PLSVO_OPT_LDLT_FLAVOUR 1
 /* Launch shapes (threads per frame) of the two hot kernels: 0 = chosen from the batch size (default), or a fixed 64 / 128 / 256 / 512
- * (alignment), 64 / 256 / 512 (pose optimiser).  For tests and measurements: every shape computes the same thing. */
+ * (alignment), 16 / 64 / 256 / 512 (pose optimiser; 16 = a 16-lane row per frame, four frames per wave: the large-batch shape).  For tests and measurements: every shape computes the same thing. */
 #define PLSVO_OPT_ALIGN_THREADS 2
 #define PLSVO_OPT_POSEOPT_THREADS 3
 int plsvo_hip_set_option(plsvo_ctx* ctx, int option, int value);
@@ -573,8 +573,9 @@ typedef struct plsvo_pose_record {
 } plsvo_pose_record;
 
 /* Writes one record per stream of the resident batch into device memory (d_dst: n records), enqueued on the ctx stream after the
- * launches that produce them: the resident frame step (plsvo_chain_stage) if one is staged, else the staged alignment and / or
- * pose-optimisation batches (which must then have the same number of jobs).  *n_out (may be NULL) receives the record count. */
+ * launches that produce them: the resident frame step (plsvo_chain_stage) if one is staged, else the staged alignment and
+ * pose-optimisation batches that have run -- both when they have the same number of jobs (one job of each per stream), otherwise the
+ * one that ran last.  *n_out (may be NULL) receives the record count. */
 int plsvo_pack_pose_records(plsvo_ctx* ctx, plsvo_pose_record* d_dst, int* n_out);
 /* The same records in host memory (out: n records, n = the resident batch's size): packs into a ctx-owned device buffer, copies,
  * synchronises the ctx stream.  For a single-process host that wants the table without a communicator. */

@@ -134,6 +134,7 @@ struct plsvo_ctx {
   PoseBatchDev ch_pose{};
   DevBuf ch_d_state, ch_d_ptkeep, ch_d_segkeep, ch_d_s32, ch_d_s64, ch_d_poses;
   DevBuf rec_d;   // plsvo_fetch_pose_records
+  unsigned long long run_seq = 0, a_run_seq = 0, p_run_seq = 0;   // which resident batch ran last (plsvo_pack_pose_records)
 
   // structure optimisation (one-shot batches)
   DevBuf s_d_in, s_d_out;
@@ -227,7 +228,7 @@ static int create_ctx(int device_id, void* stream, bool use_given_stream, plsvo_
   if (const char* s = getenv("PLSVO_LDS_LIMIT")) c->lds_per_block = (size_t)atol(s);
   if (const char* s = getenv("PLSVO_ALIGN_THREADS")) { const int v = atoi(s); if (v == 64 || v == 128 || v == 256 || v == 512) c->env_align_threads = v; }
   if (const char* s = getenv("PLSVO_ALIGN_LDS_PAD")) c->env_align_lds_pad = std::max(0, atoi(s));
-  if (const char* s = getenv("PLSVO_POSEOPT_THREADS")) { const int v = atoi(s); if (v == 64 || v == 256 || v == 512) c->env_poseopt_threads = v; }
+  if (const char* s = getenv("PLSVO_POSEOPT_THREADS")) { const int v = atoi(s); if (v == 16 || v == 64 || v == 256 || v == 512) c->env_poseopt_threads = v; }
   if (const char* s = getenv("PLSVO_ALIGN_PER_LEVEL")) c->env_align_per_level = atoi(s) != 0;
   c->env_align_no_lpt = getenv("PLSVO_ALIGN_NO_LPT") != nullptr;
   c->env_host_timing = getenv("PLSVO_HOST_TIMING") != nullptr;
@@ -265,7 +266,7 @@ extern "C" int plsvo_hip_set_option(plsvo_ctx* c, int option, int value) {
     return PLSVO_OK;
   }
   if (option == PLSVO_OPT_POSEOPT_THREADS) {
-    if (value != 0 && value != 64 && value != 256 && value != 512) return fail(c, PLSVO_E_INVALID, "set_option: pose-optimiser launch shape is 0 (automatic), 64, 256 or 512 threads per frame");
+    if (value != 0 && value != 16 && value != 64 && value != 256 && value != 512) return fail(c, PLSVO_E_INVALID, "set_option: pose-optimiser launch shape is 0 (automatic), 16 (a 16-lane row per frame, four frames per wave), 64, 256 or 512 threads per frame");
     c->env_poseopt_threads = value;
     return PLSVO_OK;
   }
@@ -603,7 +604,7 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) c->a_cap[l] = caps[l];
   c->a_scap = 4;
   for (int j = 0; j < n; ++j) c->a_scap = std::max(c->a_scap, in[j].n_seg);
-  c->a_staged = true;
+  c->a_staged = true; c->a_run_seq = 0;
   return PLSVO_OK;
 }
 
@@ -691,6 +692,7 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
       prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
     }
   }
+  c->a_run_seq = ++c->run_seq;
   return PLSVO_OK;
 }
 
@@ -899,7 +901,7 @@ extern "C" int plsvo_poseopt_stage(plsvo_ctx* c, int n, const plsvo_poseopt_in* 
   b.log_cap = c->p_trace_cap; b.n_jobs = n;
   c->p_jobs.swap(jobs);
   c->p_n = n; c->p_total_pt = (int)npt; c->p_total_seg = (int)nsg;
-  c->p_staged = true;
+  c->p_staged = true; c->p_run_seq = 0;
   return PLSVO_OK;
 }
 
@@ -908,13 +910,15 @@ extern "C" int plsvo_poseopt_run(plsvo_ctx* c) {
   RoctxRange range("pose_optimizer");
   if (!c->p_staged) return fail(c, PLSVO_E_STATE, "poseopt_run: no staged batch");
   HIP_TRY(c, hipSetDevice(c->device));
-  // one wave per frame for large batches (8 frames per CU), four waves per frame when there are too few frames to fill the
-  // chip (the Gauss-Newton loop of one frame is then ~2x shorter); PLSVO_POSEOPT_THREADS overrides (experiments only)
+  // a 16-lane row per frame, four frames per wave, for large batches (the serial solve + update of four frames share one instruction
+  // stream: poseopt_kernels.hip); four waves per frame when there are too few frames to fill the chip (the Gauss-Newton loop of one
+  // frame is then ~2x shorter); PLSVO_POSEOPT_THREADS / PLSVO_OPT_POSEOPT_THREADS override (tests and measurements)
   const int cus = c->cu_count > 0 ? c->cu_count : 256;
-  int threads = c->p_n <= 2 * cus ? 256 : 64;
+  int threads = c->p_n <= 2 * cus ? 256 : 16;
   if (c->env_poseopt_threads) threads = c->env_poseopt_threads;
   EventPair ep{}; prof_begin(c, PLSVO_K_POSEOPT, &ep);
   HIP_TRY(c, launch_pose_opt(c->p_b, c->p_d_poses.as<double>(), threads, c->stream));
+  c->p_run_seq = ++c->run_seq;
   prof_end(c, PLSVO_K_POSEOPT, &ep);
   return PLSVO_OK;
 }
@@ -1324,7 +1328,7 @@ extern "C" int plsvo_chain_run(plsvo_ctx* c) {
     HIP_TRY(c, launch_chain_select(c->ch_b, c->stream));
     prof_end(c, PLSVO_K_MATCH, &ep); }
   const int cus = c->cu_count > 0 ? c->cu_count : 256;
-  int threads = c->ch_n <= 2 * cus ? 256 : 64;
+  int threads = c->ch_n <= 2 * cus ? 256 : 16;
   if (c->env_poseopt_threads) threads = c->env_poseopt_threads;
   EventPair ep{}; prof_begin(c, PLSVO_K_POSEOPT, &ep);
   HIP_TRY(c, launch_pose_opt(c->ch_pose, c->ch_d_poses.as<double>(), threads, c->stream));
@@ -1524,13 +1528,13 @@ extern "C" int plsvo_pack_pose_records(plsvo_ctx* c, plsvo_pose_record* d_dst, i
   if (c->ch_staged && c->a_staged && c->a_n == c->ch_n) {   // the resident frame step: its own pose-optimisation state
     ast = c->a_d_state.as<AlignStateDev>(); pst = c->ch_d_state.as<PoseStateDev>(); n = c->ch_n;
   } else {
-    if (c->a_staged) { ast = c->a_d_state.as<AlignStateDev>(); n = c->a_n; }
-    if (c->p_staged) {
-      if (ast && c->p_n != n) return fail(c, PLSVO_E_STATE, "pack_pose_records: the staged alignment and pose-optimisation batches differ in size");
-      pst = c->p_d_state.as<PoseStateDev>(); n = c->p_n;
-    }
+    // both batches when they describe the same streams (same size); otherwise the one that ran last
+    const bool use_a = c->a_staged && c->a_run_seq > 0, use_p = c->p_staged && c->p_run_seq > 0;
+    const bool both = use_a && use_p && c->a_n == c->p_n;
+    if (use_a && (both || !use_p || c->a_run_seq > c->p_run_seq)) { ast = c->a_d_state.as<AlignStateDev>(); n = c->a_n; }
+    if (use_p && (both || !use_a || c->p_run_seq > c->a_run_seq)) { pst = c->p_d_state.as<PoseStateDev>(); n = c->p_n; }
   }
-  if (!ast && !pst) return fail(c, PLSVO_E_STATE, "pack_pose_records: no staged batch");
+  if (!ast && !pst) return fail(c, PLSVO_E_STATE, "pack_pose_records: no staged batch has run");
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, launch_pack_pose_records(ast, pst, n, d_dst, c->stream));
   if (n_out) *n_out = n;

@@ -108,6 +108,126 @@ __device__ __forceinline__ float norm2_f32(float a, float b) {
   return sqrtf(p + q);
 }
 
+// ---- per-feature arithmetic, shared by the workgroup-per-frame kernel and the row-per-frame kernel ----------------------------------
+// P[0..8] = R (row-major), P[9..11] = t of the current model.
+
+// one feature of a Gauss-Newton iteration (src/pose_optimizer.cpp:107-166 / :473-533): residual, Jacobian, Tukey weight, accumulation
+// into acc (0..20 A upper row-major, 21..26 b, 27 chi2, 28 #points, 29 #segments)
+__device__ __forceinline__ void popt_accumulate_feature(const PoseBatchDev& b, const PoseJobDev& job, int f, const double (&P)[12], double scale_pt,
+                                                        double scale_ls, bool first_iter, double* init_vec, double* acc) {
+  const int np = job.n_pts;
+  const double R0 = P[0], R1 = P[1], R2 = P[2], R3 = P[3], R4 = P[4], R5 = P[5], R6 = P[6], R7 = P[7], R8 = P[8], t0 = P[9], t1 = P[10], t2 = P[11];
+  double J[12], e0, e1, weight, cnt_pt, cnt_ls;   // (the two counters are added at the common tail: `acc[28 + is_segment] += 1` would be a dynamically indexed private array, i.e. scratch)
+  if (f < np) {
+    const int i = job.pt_off + f;
+    if (!b.pt_keep[i]) return;
+    const double x = b.pt_pos[3 * i], y = b.pt_pos[3 * i + 1], z = b.pt_pos[3 * i + 2];
+    const double xyz[3] = { R0 * x + R1 * y + R2 * z + t0, R3 * x + R4 * y + R5 * z + t1, R6 * x + R7 * y + R8 * z + t2 };
+    jacobian_xyz2uv(xyz, J);
+    const double fz = b.pt_f[3 * i + 2];
+    e0 = b.pt_f[3 * i] / fz - xyz[0] / xyz[2];
+    e1 = b.pt_f[3 * i + 1] / fz - xyz[1] / xyz[2];
+    const double sic = 1.0 / (double)(1 << b.pt_level[i]);
+    e0 *= sic; e1 *= sic;
+    if (first_iter) init_vec[f] = e0 * e0 + e1 * e1;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) J[k] *= sic;
+    weight = (double)tukey_weight((float)(sqrt(e0 * e0 + e1 * e1) / scale_pt));
+    cnt_pt = 1.0; cnt_ls = 0.0;
+  } else {
+    const int s = job.seg_off + (f - np);
+    if (!b.seg_keep[s]) return;
+    double Js[12], Je[12];
+    const double sx = b.seg_spos[3 * s], sy = b.seg_spos[3 * s + 1], sz = b.seg_spos[3 * s + 2];
+    const double ex = b.seg_epos[3 * s], ey = b.seg_epos[3 * s + 1], ez = b.seg_epos[3 * s + 2];
+    const double xs[3] = { R0 * sx + R1 * sy + R2 * sz + t0, R3 * sx + R4 * sy + R5 * sz + t1, R6 * sx + R7 * sy + R8 * sz + t2 };
+    const double xe[3] = { R0 * ex + R1 * ey + R2 * ez + t0, R3 * ex + R4 * ey + R5 * ez + t1, R6 * ex + R7 * ey + R8 * ez + t2 };
+    jacobian_xyz2uv(xs, Js);
+    jacobian_xyz2uv(xe, Je);
+    const double l0 = b.seg_line[3 * s], l1 = b.seg_line[3 * s + 1], l2 = b.seg_line[3 * s + 2];
+    const float ds = (float)(l0 * (xs[0] / xs[2]) + l1 * (xs[1] / xs[2]) + l2 * 1.0);
+    const float de = (float)(l0 * (xe[0] / xe[2]) + l1 * (xe[1] / xe[2]) + l2 * 1.0);
+    const double sic = 1.0 / (double)(1 << b.seg_level[s]);
+    e0 = (double)ds * sic; e1 = (double)de * sic;
+    if (first_iter) init_vec[f] = e0 * e0 + e1 * e1;
+    const double en = sqrt(e0 * e0 + e1 * e1);
+    const double ks = sic * (double)ds / en;  // same factor for both rows (:156-157)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      J[c] = l0 * (Js[c] * ks) + l1 * (Js[6 + c] * ks);
+      J[6 + c] = l0 * (Je[c] * ks) + l1 * (Je[6 + c] * ks);
+    }
+    weight = (double)tukey_weight((float)(en / scale_ls));
+    cnt_pt = 0.0; cnt_ls = 1.0;
+  }
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int jj = i; jj < 6; ++jj) { acc[k] += (J[i] * J[jj] + J[6 + i] * J[6 + jj]) * weight; ++k; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) acc[21 + i] -= (J[i] * e0 + J[6 + i] * e1) * weight;
+  acc[27] += (e0 * e0 + e1 * e1) * weight;
+  acc[28] += cnt_pt; acc[29] += cnt_ls;
+}
+
+// the float error of a feature in the scale pass (:57-87): points sqrt(e0^2 + e1^2) scaled by the level, lines the un-scaled float norm
+__device__ __forceinline__ float popt_scale_error(const PoseBatchDev& b, const PoseJobDev& job, int f, const double (&P)[12]) {
+  const int np = job.n_pts;
+  const double R0 = P[0], R1 = P[1], R2 = P[2], R3 = P[3], R4 = P[4], R5 = P[5], R6 = P[6], R7 = P[7], R8 = P[8], t0 = P[9], t1 = P[10], t2 = P[11];
+  if (f < np) {
+    const int i = job.pt_off + f;
+    const double x = b.pt_pos[3 * i], y = b.pt_pos[3 * i + 1], z = b.pt_pos[3 * i + 2];
+    const double xc = R0 * x + R1 * y + R2 * z + t0, yc = R3 * x + R4 * y + R5 * z + t1, zc = R6 * x + R7 * y + R8 * z + t2;
+    const double fz = b.pt_f[3 * i + 2];
+    double e0 = b.pt_f[3 * i] / fz - xc / zc, e1 = b.pt_f[3 * i + 1] / fz - yc / zc;
+    const double sic = 1.0 / (double)(1 << b.pt_level[i]);
+    e0 *= sic; e1 *= sic;
+    return (float)sqrt(e0 * e0 + e1 * e1);
+  }
+  const int s = job.seg_off + (f - np);
+  const double sx = b.seg_spos[3 * s], sy = b.seg_spos[3 * s + 1], sz = b.seg_spos[3 * s + 2];
+  const double ex = b.seg_epos[3 * s], ey = b.seg_epos[3 * s + 1], ez = b.seg_epos[3 * s + 2];
+  const double xs0 = R0 * sx + R1 * sy + R2 * sz + t0, xs1 = R3 * sx + R4 * sy + R5 * sz + t1, xs2 = R6 * sx + R7 * sy + R8 * sz + t2;
+  const double xe0 = R0 * ex + R1 * ey + R2 * ez + t0, xe1 = R3 * ex + R4 * ey + R5 * ez + t1, xe2 = R6 * ex + R7 * ey + R8 * ez + t2;
+  const double l0 = b.seg_line[3 * s], l1 = b.seg_line[3 * s + 1], l2 = b.seg_line[3 * s + 2];
+  const float es = (float)(l0 * (xs0 / xs2) + l1 * (xs1 / xs2) + l2 * 1.0);   // not scaled by the level (:84-87)
+  const float ee = (float)(l0 * (xe0 / xe2) + l1 * (xe1 / xe2) + l2 * 1.0);
+  return norm2_f32(es, ee);
+}
+
+// the cull of one feature (:201-242): clears its keep flag when the error exceeds the threshold, returns the squared error;
+// deleted = 1 (point) / 2 (segment) / 0
+__device__ __forceinline__ double popt_cull_feature(const PoseBatchDev& b, const PoseJobDev& job, int f, const double (&P)[12], double thr_pt, double thr_ls,
+                                                    int& deleted) {
+  const int np = job.n_pts;
+  const double R0 = P[0], R1 = P[1], R2 = P[2], R3 = P[3], R4 = P[4], R5 = P[5], R6 = P[6], R7 = P[7], R8 = P[8], t0 = P[9], t1 = P[10], t2 = P[11];
+  double e0, e1;
+  deleted = 0;
+  if (f < np) {
+    const int i = job.pt_off + f;
+    const double x = b.pt_pos[3 * i], y = b.pt_pos[3 * i + 1], z = b.pt_pos[3 * i + 2];
+    const double xc = R0 * x + R1 * y + R2 * z + t0, yc = R3 * x + R4 * y + R5 * z + t1, zc = R6 * x + R7 * y + R8 * z + t2;
+    const double fz = b.pt_f[3 * i + 2];
+    e0 = b.pt_f[3 * i] / fz - xc / zc; e1 = b.pt_f[3 * i + 1] / fz - yc / zc;
+    const double sic = 1.0 / (double)(1 << b.pt_level[i]);
+    e0 *= sic; e1 *= sic;
+    if (sqrt(e0 * e0 + e1 * e1) > thr_pt) { b.pt_keep[i] = 0; deleted = 1; }
+  } else {
+    const int s = job.seg_off + (f - np);
+    const double sx = b.seg_spos[3 * s], sy = b.seg_spos[3 * s + 1], sz = b.seg_spos[3 * s + 2];
+    const double ex = b.seg_epos[3 * s], ey = b.seg_epos[3 * s + 1], ez = b.seg_epos[3 * s + 2];
+    const double xs0 = R0 * sx + R1 * sy + R2 * sz + t0, xs1 = R3 * sx + R4 * sy + R5 * sz + t1, xs2 = R6 * sx + R7 * sy + R8 * sz + t2;
+    const double xe0 = R0 * ex + R1 * ey + R2 * ez + t0, xe1 = R3 * ex + R4 * ey + R5 * ez + t1, xe2 = R6 * ex + R7 * ey + R8 * ez + t2;
+    const double l0 = b.seg_line[3 * s], l1 = b.seg_line[3 * s + 1], l2 = b.seg_line[3 * s + 2];
+    const double sic = 1.0 / (double)(1 << b.seg_level[s]);
+    e0 = (l0 * (xs0 / xs2) + l1 * (xs1 / xs2) + l2 * 1.0) * sic;     // doubles here, no float truncation (:229)
+    e1 = (l0 * (xe0 / xe2) + l1 * (xe1 / xe2) + l2 * 1.0) * sic;
+    if (sqrt(e0 * e0 + e1 * e1) > thr_ls) { b.seg_keep[s] = 0; deleted = 2; }
+  }
+  return e0 * e0 + e1 * e1;
+}
+
 template <int PO_T>
 __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseStateDev* st, int job_id, double* s_red,
                              double* s_pose, int* s_ctl, int n_iter, int phase, double scale_pt, double scale_ls,
@@ -118,61 +238,10 @@ __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseS
     double acc[32];   // 0..20 A (upper, row-major), 21..26 b, 27 chi2, 28 #points, 29 #segments, 30..31 unused
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.0;
-    const double R0 = s_pose[0], R1 = s_pose[1], R2 = s_pose[2], R3 = s_pose[3], R4 = s_pose[4], R5 = s_pose[5],
-                 R6 = s_pose[6], R7 = s_pose[7], R8 = s_pose[8], t0 = s_pose[9], t1 = s_pose[10], t2 = s_pose[11];
-    for (int f = tid; f < nf; f += PO_T) {
-      double J[12], e0, e1, weight;
-      if (f < np) {
-        const int i = job.pt_off + f;
-        if (!b.pt_keep[i]) continue;
-        const double x = b.pt_pos[3 * i], y = b.pt_pos[3 * i + 1], z = b.pt_pos[3 * i + 2];
-        const double xyz[3] = { R0 * x + R1 * y + R2 * z + t0, R3 * x + R4 * y + R5 * z + t1, R6 * x + R7 * y + R8 * z + t2 };
-        jacobian_xyz2uv(xyz, J);
-        const double fz = b.pt_f[3 * i + 2];
-        e0 = b.pt_f[3 * i] / fz - xyz[0] / xyz[2];
-        e1 = b.pt_f[3 * i + 1] / fz - xyz[1] / xyz[2];
-        const double sic = 1.0 / (double)(1 << b.pt_level[i]);
-        e0 *= sic; e1 *= sic;
-        if (iter == 0) init_vec[f] = e0 * e0 + e1 * e1;
+    double P[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) J[k] *= sic;
-        weight = (double)tukey_weight((float)(sqrt(e0 * e0 + e1 * e1) / scale_pt));
-        acc[28] += 1.0;
-      } else {
-        const int s = job.seg_off + (f - np);
-        if (!b.seg_keep[s]) continue;
-        double Js[12], Je[12];
-        const double sx = b.seg_spos[3 * s], sy = b.seg_spos[3 * s + 1], sz = b.seg_spos[3 * s + 2];
-        const double ex = b.seg_epos[3 * s], ey = b.seg_epos[3 * s + 1], ez = b.seg_epos[3 * s + 2];
-        const double xs[3] = { R0 * sx + R1 * sy + R2 * sz + t0, R3 * sx + R4 * sy + R5 * sz + t1, R6 * sx + R7 * sy + R8 * sz + t2 };
-        const double xe[3] = { R0 * ex + R1 * ey + R2 * ez + t0, R3 * ex + R4 * ey + R5 * ez + t1, R6 * ex + R7 * ey + R8 * ez + t2 };
-        jacobian_xyz2uv(xs, Js);
-        jacobian_xyz2uv(xe, Je);
-        const double l0 = b.seg_line[3 * s], l1 = b.seg_line[3 * s + 1], l2 = b.seg_line[3 * s + 2];
-        const float ds = (float)(l0 * (xs[0] / xs[2]) + l1 * (xs[1] / xs[2]) + l2 * 1.0);
-        const float de = (float)(l0 * (xe[0] / xe[2]) + l1 * (xe[1] / xe[2]) + l2 * 1.0);
-        const double sic = 1.0 / (double)(1 << b.seg_level[s]);
-        e0 = (double)ds * sic; e1 = (double)de * sic;
-        if (iter == 0) init_vec[f] = e0 * e0 + e1 * e1;
-        const double en = sqrt(e0 * e0 + e1 * e1);
-        const double ks = sic * (double)ds / en;  // same factor for both rows (:156-157)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          J[c] = l0 * (Js[c] * ks) + l1 * (Js[6 + c] * ks);
-          J[6 + c] = l0 * (Je[c] * ks) + l1 * (Je[6 + c] * ks);
-        }
-        weight = (double)tukey_weight((float)(en / scale_ls));
-        acc[29] += 1.0;
-      }
-      int k = 0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int jj = i; jj < 6; ++jj) { acc[k] += (J[i] * J[jj] + J[6 + i] * J[6 + jj]) * weight; ++k; }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) acc[21 + i] -= (J[i] * e0 + J[6 + i] * e1) * weight;
-      acc[27] += (e0 * e0 + e1 * e1) * weight;
-    }
+    for (int k = 0; k < 12; ++k) P[k] = s_pose[k];
+    for (int f = tid; f < nf; f += PO_T) popt_accumulate_feature(b, job, f, P, scale_pt, scale_ls, iter == 0, init_vec, acc);
     {
       double out2[2];
       row_reduce_scatter32(acc, out2);
@@ -275,30 +344,10 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* 
 
   // ---- scale pass :57-95 ----
   {
-    const double R0 = s_pose[0], R1 = s_pose[1], R2 = s_pose[2], R3 = s_pose[3], R4 = s_pose[4], R5 = s_pose[5],
-                 R6 = s_pose[6], R7 = s_pose[7], R8 = s_pose[8], t0 = s_pose[9], t1 = s_pose[10], t2 = s_pose[11];
-    for (int f = tid; f < nf; f += PO_T) {
-      if (f < np) {
-        const int i = job.pt_off + f;
-        const double x = b.pt_pos[3 * i], y = b.pt_pos[3 * i + 1], z = b.pt_pos[3 * i + 2];
-        const double xc = R0 * x + R1 * y + R2 * z + t0, yc = R3 * x + R4 * y + R5 * z + t1, zc = R6 * x + R7 * y + R8 * z + t2;
-        const double fz = b.pt_f[3 * i + 2];
-        double e0 = b.pt_f[3 * i] / fz - xc / zc, e1 = b.pt_f[3 * i + 1] / fz - yc / zc;
-        const double sic = 1.0 / (double)(1 << b.pt_level[i]);
-        e0 *= sic; e1 *= sic;
-        errs[f] = (float)sqrt(e0 * e0 + e1 * e1);
-      } else {
-        const int s = job.seg_off + (f - np);
-        const double sx = b.seg_spos[3 * s], sy = b.seg_spos[3 * s + 1], sz = b.seg_spos[3 * s + 2];
-        const double ex = b.seg_epos[3 * s], ey = b.seg_epos[3 * s + 1], ez = b.seg_epos[3 * s + 2];
-        const double xs0 = R0 * sx + R1 * sy + R2 * sz + t0, xs1 = R3 * sx + R4 * sy + R5 * sz + t1, xs2 = R6 * sx + R7 * sy + R8 * sz + t2;
-        const double xe0 = R0 * ex + R1 * ey + R2 * ez + t0, xe1 = R3 * ex + R4 * ey + R5 * ez + t1, xe2 = R6 * ex + R7 * ey + R8 * ez + t2;
-        const double l0 = b.seg_line[3 * s], l1 = b.seg_line[3 * s + 1], l2 = b.seg_line[3 * s + 2];
-        const float es = (float)(l0 * (xs0 / xs2) + l1 * (xs1 / xs2) + l2 * 1.0);   // not scaled by the level (:84-87)
-        const float ee = (float)(l0 * (xe0 / xe2) + l1 * (xe1 / xe2) + l2 * 1.0);
-        errs[f] = norm2_f32(es, ee);
-      }
-    }
+    double P[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) P[k] = s_pose[k];
+    for (int f = tid; f < nf; f += PO_T) errs[f] = popt_scale_error(b, job, f, P);
   }
   __syncthreads();
   PTICK(0);
@@ -331,32 +380,13 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* 
   const double thr_ls = thr_pt * scale_ls / scale_pt;
   int del_pt = 0, del_ls = 0;
   {
-    const double R0 = s_pose[0], R1 = s_pose[1], R2 = s_pose[2], R3 = s_pose[3], R4 = s_pose[4], R5 = s_pose[5],
-                 R6 = s_pose[6], R7 = s_pose[7], R8 = s_pose[8], t0 = s_pose[9], t1 = s_pose[10], t2 = s_pose[11];
+    double P[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) P[k] = s_pose[k];
     for (int f = tid; f < nf; f += PO_T) {
-      double e0, e1;
-      if (f < np) {
-        const int i = job.pt_off + f;
-        const double x = b.pt_pos[3 * i], y = b.pt_pos[3 * i + 1], z = b.pt_pos[3 * i + 2];
-        const double xc = R0 * x + R1 * y + R2 * z + t0, yc = R3 * x + R4 * y + R5 * z + t1, zc = R6 * x + R7 * y + R8 * z + t2;
-        const double fz = b.pt_f[3 * i + 2];
-        e0 = b.pt_f[3 * i] / fz - xc / zc; e1 = b.pt_f[3 * i + 1] / fz - yc / zc;
-        const double sic = 1.0 / (double)(1 << b.pt_level[i]);
-        e0 *= sic; e1 *= sic;
-        if (sqrt(e0 * e0 + e1 * e1) > thr_pt) { b.pt_keep[i] = 0; ++del_pt; }
-      } else {
-        const int s = job.seg_off + (f - np);
-        const double sx = b.seg_spos[3 * s], sy = b.seg_spos[3 * s + 1], sz = b.seg_spos[3 * s + 2];
-        const double ex = b.seg_epos[3 * s], ey = b.seg_epos[3 * s + 1], ez = b.seg_epos[3 * s + 2];
-        const double xs0 = R0 * sx + R1 * sy + R2 * sz + t0, xs1 = R3 * sx + R4 * sy + R5 * sz + t1, xs2 = R6 * sx + R7 * sy + R8 * sz + t2;
-        const double xe0 = R0 * ex + R1 * ey + R2 * ez + t0, xe1 = R3 * ex + R4 * ey + R5 * ez + t1, xe2 = R6 * ex + R7 * ey + R8 * ez + t2;
-        const double l0 = b.seg_line[3 * s], l1 = b.seg_line[3 * s + 1], l2 = b.seg_line[3 * s + 2];
-        const double sic = 1.0 / (double)(1 << b.seg_level[s]);
-        e0 = (l0 * (xs0 / xs2) + l1 * (xs1 / xs2) + l2 * 1.0) * sic;     // doubles here, no float truncation (:229)
-        e1 = (l0 * (xe0 / xe2) + l1 * (xe1 / xe2) + l2 * 1.0) * sic;
-        if (sqrt(e0 * e0 + e1 * e1) > thr_ls) { b.seg_keep[s] = 0; ++del_ls; }
-      }
-      vec[2 * nf + f] = e0 * e0 + e1 * e1;
+      int deleted;
+      vec[2 * nf + f] = popt_cull_feature(b, job, f, P, thr_pt, thr_ls, deleted);
+      del_pt += deleted == 1; del_ls += deleted == 2;
       vec[nf + f] = __longlong_as_double(0x7ff0000000000000LL);  // +inf sentinel for the refinement's init entries
     }
   }
@@ -405,8 +435,336 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* 
   }
 }
 
+// ================================================================================================================================
+// Large batches: ONE 16-LANE DPP ROW PER FRAME, four frames per wave (pose_opt_rows_kernel).
+//
+// A frame is a few hundred features and a chain of serial steps (reduce -> 6x6 solve -> SE3 update -> medians): with a whole wave per
+// frame the wave-cooperative solve and the update on lane 0 issue ~1400 wave-instructions per Gauss-Newton iteration for ONE frame --
+// more than the feature pass itself (five 64-lane rounds) -- and the launch is bound by VALU issue, not by memory or occupancy
+// (measured: 2.0 ms per 32768 frames at 198 VGPRs, two waves per SIMD).  Here a wave carries four frames:
+//   * features: lane rl of a row takes features rl, rl + 16, ... of ITS frame (18 rounds for 280 features, 97 % of the lanes busy);
+//   * reduction: row_reduce_scatter32 is a butterfly INSIDE the 16-lane DPP rows -- its result is already the per-frame total, no
+//     cross-row combine, no workgroup barrier anywhere in the kernel;
+//   * solve + update: lane 0 of every row solves its frame's 6x6 system serially in registers (lane_solve6: Eigen's pivot order is the
+//     original diagonal sorted once, so the matrix is gathered from LDS already permuted and eliminated with static indices -- nothing
+//     indexed at run time, no scratch) and applies the update: four frames per instruction stream instead of one;
+//   * medians: radix select per row over a 256-bin LDS histogram per frame, bins scanned with row-level DPP shifts.
+// Rows of a wave run in lock step: a loop runs to the largest trip count of its four frames (same feature counts in practice; the
+// Gauss-Newton loops differ by an iteration or two).
+// ================================================================================================================================
+#define DPP_ROW_SHR_(n) (0x110 + (n))
+template <int N>
+__device__ __forceinline__ int row_shr_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR_(N), 0xf, 0xf, true); }   // lanes without a source receive 0
+// inclusive prefix sum over the 16 lanes of a row
+__device__ __forceinline__ int row_scan_incl_i32(int v) {
+  v += row_shr_i32<1>(v); v += row_shr_i32<2>(v); v += row_shr_i32<4>(v); v += row_shr_i32<8>(v);
+  return v;
+}
+// sum over the 16 lanes of a row, result in every lane of the row
+__device__ __forceinline__ int row_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, DPP_QUAD_XOR1, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, DPP_QUAD_XOR2, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_HALF_MIRROR, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_MIRROR, 0xf, 0xf, true);
+  return v;
+}
+
+struct PoseRowLds {        // per frame (row) of the workgroup
+  double pose[32];         // 0..8 R, 9..11 t, 12..18 model, 19..25 T_old, 26 chi2, 27 point-iterations, 28 line-iterations
+  double tot[32];          // totals of the last iteration: 21 A, 6 b, chi2, #points, #segments
+  double lu[36];           // covariance: LU factors
+  double x[8];             // lane_solve6: un-permuted result
+  int perm[8];
+  int ctl[8];              // 0 break, 1 / 2 iterations of the two loops
+  int sel[8];              // radix select: chosen bin, rank inside it, its count, (4,5) the surviving value
+  int hist[PO_BINS];
+};
+
+// k-th smallest (0-based) of n non-negative IEEE values given as unsigned bit patterns of BITS bits, by the 16 lanes of ONE ROW; every
+// row of the wave calls it together (`active`: this row takes part).  get(i) returns the pattern of element i.
+template <int BITS, typename U, typename GET>
+__device__ __forceinline__ U row_radix_select(GET get, int n, int k, bool active, int* hist, int* sel) {
+  static_assert(PO_RADIX_BITS == 8 && BITS % 8 == 0, "16 lanes x 16 bins");
+  const int rl = threadIdx.x & 15;
+  U prefix = 0, mask = 0, result = 0;
+  bool done = !active;
+  for (int shift = BITS - 8; shift >= 0; shift -= 8) {
+    if (!__any(!done)) break;
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) *reinterpret_cast<uint4*>(hist + rl * 16 + j) = make_uint4(0u, 0u, 0u, 0u);
+    wave_lds_fence();
+    if (!done) for (int i = rl; i < n; i += 16) {
+      const U v = get(i);
+      if ((v & mask) == prefix) atomicAdd(&hist[(int)((v >> shift) & (U)255)], 1);
+    }
+    wave_lds_fence();
+    int loc[16], local = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) {
+      const uint4 h4 = *reinterpret_cast<const uint4*>(hist + rl * 16 + j);
+      loc[j] = (int)h4.x; loc[j + 1] = (int)h4.y; loc[j + 2] = (int)h4.z; loc[j + 3] = (int)h4.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) local += loc[j];
+    int cum = row_scan_incl_i32(local) - local;
+    if (!done) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (k >= cum && k < cum + loc[j]) { sel[0] = rl * 16 + j; sel[1] = k - cum; sel[2] = loc[j]; }
+        cum += loc[j];
+      }
+    }
+    wave_lds_fence();
+    bool single = false;
+    if (!done) {
+      prefix |= ((U)(unsigned)sel[0]) << shift;
+      mask |= ((U)255) << shift;
+      k = sel[1];
+      single = sel[2] == 1 && shift > 0;   // one candidate left: it is the answer, the remaining digits need no histogram
+      if (single) for (int i = rl; i < n; i += 16) {
+        const U v = get(i);
+        if ((v & mask) == prefix) { sel[4] = (int)(unsigned)(v & (U)0xffffffffu); sel[5] = (int)(unsigned)((unsigned long long)v >> 32); }
+      }
+    }
+    wave_lds_fence();
+    if (single) { result = (U)(((unsigned long long)(unsigned)sel[5] << 32) | (unsigned long long)(unsigned)sel[4]); done = true; }
+    wave_lds_fence();   // sel is rewritten by the next pass
+  }
+  return done ? result : prefix;
+}
+
+// H x = rhs for a symmetric 6x6 H by ONE LANE: the arithmetic of wave_solve6_core (Gauss-Jordan in the pivot order of Eigen's LDLT, the
+// zero-pivot rule selected by `flavour`, NaN / Inf propagation -- see there) with the system held in this lane's registers.  Eigen's
+// order is the original |diagonal| sorted once (selection sort with Eigen's own transpositions: first maximum wins, numbers beat NaN),
+// so the 27 inputs are gathered from LDS already permuted and every index below is a compile-time constant.  Columns already
+// eliminated are dead (they never reach x) and are not updated.  tot: 21 A (upper, row-major) + 6 b in LDS; xs: 6 doubles of LDS.
+__device__ __forceinline__ void lane_solve6(const double* tot, double* xs, double* x, int flavour) {
+  double key[6]; int idx[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { key[i] = fabs(tot[sym6_index(i, i)]); idx[i] = i; }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    double bk = key[k]; int bi = idx[k], bp = k;
+#pragma unroll
+    for (int j = k + 1; j < 6; ++j) {
+      const bool better = key[j] > bk || (bk != bk && key[j] == key[j]);
+      if (better) { bk = key[j]; bi = idx[j]; bp = j; }
+    }
+    const double ok_ = key[k]; const int oi = idx[k];
+#pragma unroll
+    for (int j = k + 1; j < 6; ++j) if (bp == j) { key[j] = ok_; idx[j] = oi; }
+    key[k] = bk; idx[k] = bi;
+  }
+  double M[6][6], r[6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) M[a][c] = tot[sym6_index(idx[a], idx[c])];
+    r[a] = tot[21 + idx[a]];
+  }
+  unsigned zero_piv = 0u;
+  const double cutoff = flavour == 330 ? 0.0 : fabs(2.220446049250313e-16 * key[0]);
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+    const double piv = M[p][p];
+    // Eigen 3.2: stop at "biggest_in_corner < cutoff"; no scaling unless |pivot| > cutoff; D^+ drops |d| <= max|D| eps
+    if (!(key[p] < cutoff) && fabs(piv) > cutoff) {
+      const double rinv = fast_rcp(piv);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        if (i == p) continue;
+        const double f = M[i][p];
+#pragma unroll
+        for (int j = p + 1; j < 6; ++j) M[i][j] = fma(-(f * M[p][j]), rinv, M[i][j]);
+        r[i] = fma(-(f * r[p]), rinv, r[i]);
+      }
+    } else {
+      zero_piv |= 1u << p;
+    }
+  }
+  const double tolerance = 1.0 / 1.7976931348623157e308;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const double dgi = M[a][a], m = r[a];
+    double xi = (((zero_piv >> a) & 1u) || !(fabs(dgi) > tolerance)) ? ((dgi != dgi || m != m) ? (m + dgi) : 0.0) : m / dgi;
+    if (cutoff > 1.7976931348623157e308) xi = (a == 5 || fabs(dgi) <= 1.7976931348623157e308) ? 0.0 : __builtin_nan("");   // infinite diagonal: see wave_solve6_core
+    xs[idx[a]] = xi;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // same lane: LDS keeps program order
+#pragma unroll
+  for (int c = 0; c < 6; ++c) x[c] = xs[c];
+}
+
+// one GN loop (:103-195 / :469-563) for the four frames of the wave
+__device__ __forceinline__ void rows_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseStateDev* st, int job_id, PoseRowLds& L, bool row_on,
+                                             int n_iter, int phase, double scale_pt, double scale_ls, double* init_vec) {
+  const int lane = threadIdx.x & 63, rl = lane & 15;
+  const int nf = job.n_pts + job.n_seg;
+  bool running = row_on && n_iter > 0;
+  for (int iter = 0; __any(running); ++iter) {
+    double acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    if (running) {
+      double P[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) P[k] = L.pose[k];
+      for (int f = rl; f < nf; f += 16) popt_accumulate_feature(b, job, f, P, scale_pt, scale_ls, iter == 0, init_vec, acc);
+    }
+    double out2[2];
+    row_reduce_scatter32(acc, out2);     // every lane of the wave takes part (DPP); the row's totals are the frame's
+    if (running) *reinterpret_cast<double2*>(L.tot + row_reduce_scatter32_index(lane)) = make_double2(out2[0], out2[1]);
+    wave_lds_fence();
+    if (running && rl == 0) {
+      double dT[6];
+      lane_solve6(L.tot, L.x, dT, job.ldlt_flavour);                          // A.ldlt().solve(b) :170
+      const double new_chi2 = L.tot[27];
+      L.pose[27] += L.tot[28]; L.pose[28] += L.tot[29];
+      L.ctl[1 + phase] += 1;
+      SE3d model = se3_load(L.pose + 12);
+      int accepted = 1, brk = 0;
+      if ((iter > 0 && new_chi2 > L.pose[26]) || isnan(dT[0])) {              // :173-180
+        model = se3_load(L.pose + 19); accepted = 0; brk = 1;
+      } else {
+        const SE3d Tn = se3_mul_dev(se3_exp_dev(dT), model);                   // :183 left update
+        se3_store(model, L.pose + 19);
+        model = Tn; L.pose[26] = new_chi2;
+        if (norm_max6(dT) <= 0.0000000001) brk = 1;                            // EPS, global.h:99
+      }
+      if (iter + 1 >= n_iter) brk = 1;
+      se3_store(model, L.pose + 12);
+      quat_to_matrix(model.q, L.pose); L.pose[9] = model.t[0]; L.pose[10] = model.t[1]; L.pose[11] = model.t[2];
+      L.ctl[0] = brk;
+      if (b.log) {
+        const int lc = st->log_count;
+        if (lc < b.log_cap) {
+          plsvo_poseopt_iterlog* r = b.log + (size_t)job_id * b.log_cap + lc;
+          r->phase = phase; r->iter = iter; r->accepted = accepted; r->reserved0 = 0; r->new_chi2 = new_chi2;
+          for (int k = 0; k < 6; ++k) r->dT[k] = dT[k];
+          se3_store(model, r->T_after);
+          for (int i = 0; i < 6; ++i) for (int jj = 0; jj < 6; ++jj) r->A[i * 6 + jj] = L.tot[sym6_index(i, jj)];
+          for (int k = 0; k < 6; ++k) r->b[k] = L.tot[21 + k];
+        }
+        st->log_count = lc + 1;
+      }
+    }
+    wave_lds_fence();
+    if (running && L.ctl[0]) running = false;
+  }
+}
+
+__global__ __launch_bounds__(64) void pose_opt_rows_kernel(PoseBatchDev b, double* poses) {
+  __shared__ __align__(16) PoseRowLds s_rows[4];
+  const int lane = threadIdx.x & 63, row = lane >> 4, rl = lane & 15;
+  const int job_raw = blockIdx.x * 4 + row;
+  const bool row_valid = job_raw < b.n_jobs;
+  const int job_id = row_valid ? job_raw : b.n_jobs - 1;
+  const PoseJobDev job = b.jobs[job_id];
+  PoseStateDev* st = b.state + job_id;
+  PoseRowLds& L = s_rows[row];
+  const int np = job.n_pts, ns = job.n_seg, nf = np + ns;
+
+  // scratch: floats [0,np) point errors, [np, np+ns) line errors; doubles [0,nf) init (first loop), [nf,2nf) init (refinement), [2nf,3nf) final
+  const size_t fbase = (size_t)job.pt_off + (size_t)job.seg_off;
+  float* errs = b.scratch_f32 + fbase;
+  double* vec = b.scratch_f64 + 3 * fbase;
+
+  if (row_valid && rl == 0) {
+    SE3d m = se3_load(job.T0);
+    se3_store(m, L.pose + 12); se3_store(m, L.pose + 19); L.pose[26] = 0.0; L.pose[27] = 0.0; L.pose[28] = 0.0;
+    for (int k = 0; k < 32; ++k) L.tot[k] = 0.0;
+    quat_to_matrix(m.q, L.pose); L.pose[9] = m.t[0]; L.pose[10] = m.t[1]; L.pose[11] = m.t[2];
+    L.ctl[0] = 0; L.ctl[1] = 0; L.ctl[2] = 0;
+    st->log_count = 0; st->status = 0; st->iters = 0; st->iters_ref = 0; st->pt_iters = 0; st->seg_iters = 0;
+    st->num_obs_pt = 0; st->num_obs_ls = 0; st->estimated_scale = 0; st->error_init = 0; st->error_final = 0;
+    for (int k = 0; k < 36; ++k) st->cov[k] = 0.0;
+    for (int k = 0; k < 7; ++k) st->T[k] = job.T0[k];
+    for (int k = 0; k < 8; ++k) st->phase_ticks[k] = 0;
+    if (nf == 0) { st->status = 1; if (poses) for (int k = 0; k < 7; ++k) poses[7 * job_id + k] = job.T0[k]; }   // errors.empty() :88-89
+  }
+  const bool row_on = row_valid && nf > 0;
+  if (row_on) {
+    for (int i = rl; i < np; i += 16) b.pt_keep[job.pt_off + i] = 1;
+    for (int s = rl; s < ns; s += 16) b.seg_keep[job.seg_off + s] = 1;
+  }
+  wave_lds_fence();
+
+  // ---- scale pass :57-95 ----
+  if (row_on) {
+    double P[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) P[k] = L.pose[k];
+    for (int f = rl; f < nf; f += 16) errs[f] = popt_scale_error(b, job, f, P);
+  }
+  wave_lds_fence();   // (global scratch written and read by lanes of this wave only)
+  // MAD scale = 1.48f * median (float).  Zero points: the reference is undefined (:70); we define 1.0.
+  double scale_pt = 1.0, scale_ls = 1.0;
+  {
+    const uint32_t m_pt = row_radix_select<32, uint32_t>([&](int i) { return (uint32_t)__float_as_uint(errs[i]); }, np, np / 2, row_on && np > 0, L.hist, L.sel);
+    const uint32_t m_ls = row_radix_select<32, uint32_t>([&](int i) { return (uint32_t)__float_as_uint(errs[np + i]); }, ns, ns / 2, row_on && ns > 0, L.hist, L.sel);
+    if (np > 0) scale_pt = (double)__fmul_rn(1.48f, __uint_as_float(m_pt));
+    if (ns > 0) scale_ls = (double)__fmul_rn(1.48f, __uint_as_float(m_ls));
+  }
+
+  // ---- first GN loop ----
+  if (row_on && job.n_iter <= 0) for (int f = rl; f < nf; f += 16) vec[f] = __longlong_as_double(0x7ff0000000000000LL);
+  rows_gn_loop(b, job, st, job_id, L, row_on, job.n_iter, 0, scale_pt, scale_ls, vec);
+
+  // ---- covariance :197-199 (from the last assembled A, even if that iteration was rolled back) ----
+  if (row_on) {
+    const double f2 = job.fx * job.fx;
+    for (int t = rl; t < 36; t += 16) L.lu[t] = L.tot[sym6_index(t / 6, t % 6)] * f2;
+  }
+  wave_lds_fence();
+  if (row_on && rl == 0) lu6_lds(L.lu, L.perm);
+  wave_lds_fence();
+  if (row_on && rl < 6) inv6_column_lds(L.lu, L.perm, rl, st->cov);
+
+  // ---- cull :201-242 ----
+  const double thr_pt = job.reproj_thresh / job.fx;
+  const double thr_ls = thr_pt * scale_ls / scale_pt;
+  int del_pt = 0, del_ls = 0;
+  if (row_on) {
+    double P[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) P[k] = L.pose[k];
+    for (int f = rl; f < nf; f += 16) {
+      int deleted;
+      vec[2 * nf + f] = popt_cull_feature(b, job, f, P, thr_pt, thr_ls, deleted);
+      del_pt += deleted == 1; del_ls += deleted == 2;
+      vec[nf + f] = __longlong_as_double(0x7ff0000000000000LL);  // +inf sentinel for the refinement's init entries
+    }
+  }
+  const int n_del_pt = row_sum_i32(del_pt), n_del_ls = row_sum_i32(del_ls);
+  wave_lds_fence();   // keep flags and vec visible to the row
+
+  // ---- refinement with inliers :469-563 (10-argument overload) ----
+  int n_init = job.n_iter > 0 ? nf : 0;
+  rows_gn_loop(b, job, st, job_id, L, row_on && job.n_iter_ref >= 0, job.n_iter_ref, 1, scale_pt, scale_ls, vec + nf);
+  if (job.n_iter_ref > 0) n_init += nf - n_del_pt - n_del_ls;
+  wave_lds_fence();
+
+  // ---- medians :244-249 ----
+  const unsigned long long mi = row_radix_select<64, unsigned long long>([&](int i) { return (unsigned long long)__double_as_longlong(vec[i]); },
+                                                                         (job.n_iter_ref > 0) ? 2 * nf : nf, n_init / 2, row_on && n_init > 0, L.hist, L.sel);   // unwritten refinement entries hold +inf and sort last
+  const unsigned long long mf = row_radix_select<64, unsigned long long>([&](int i) { return (unsigned long long)__double_as_longlong(vec[2 * nf + i]); },
+                                                                         nf, nf / 2, row_on, L.hist, L.sel);
+  if (row_on && rl == 0) {
+    for (int k = 0; k < 7; ++k) st->T[k] = L.pose[12 + k];
+    if (poses) for (int k = 0; k < 7; ++k) poses[7 * job_id + k] = L.pose[12 + k];
+    st->error_init = n_init > 0 ? sqrt(__longlong_as_double((long long)mi)) * job.fx : 0.0;
+    st->error_final = sqrt(__longlong_as_double((long long)mf)) * job.fx;
+    st->estimated_scale = scale_pt * job.fx;
+    st->num_obs_pt = (unsigned long long)(np - n_del_pt);
+    st->num_obs_ls = (unsigned long long)(ns - n_del_ls);
+    st->iters = L.ctl[1]; st->iters_ref = L.ctl[2];
+    st->pt_iters = (unsigned long long)(L.pose[27] + 0.5); st->seg_iters = (unsigned long long)(L.pose[28] + 0.5);
+  }
+}
+
 hipError_t launch_pose_opt(const PoseBatchDev& b, double* d_poses, int threads, hipStream_t stream) {
   switch (threads) {
+    case 16: hipLaunchKernelGGL(pose_opt_rows_kernel, dim3((b.n_jobs + 3) / 4), dim3(64), 0, stream, b, d_poses); break;   // a 16-lane row per frame
     case 64: hipLaunchKernelGGL((pose_opt_kernel<64>), dim3(b.n_jobs), dim3(64), 0, stream, b, d_poses); break;
     case 256: hipLaunchKernelGGL((pose_opt_kernel<256>), dim3(b.n_jobs), dim3(256), 0, stream, b, d_poses); break;
     case 512: hipLaunchKernelGGL((pose_opt_kernel<512>), dim3(b.n_jobs), dim3(512), 0, stream, b, d_poses); break;

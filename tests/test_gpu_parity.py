@@ -657,7 +657,7 @@ def _every_launch_shape_body(P, ob, gpu_ctx, threads):
     assert np.array_equal(single.T, batch[3].T) and single.n_meas == batch[3].n_meas
 
 
-@pytest.mark.parametrize("threads", [64, 256, 512])
+@pytest.mark.parametrize("threads", [16, 64, 256, 512])
 def test_pose_optimizer_every_launch_shape(P, ob, gpu_ctx, threads):
     gpu_ctx.set_launch_shapes(poseopt_threads=threads)
     try:
@@ -702,6 +702,50 @@ def test_pose_optimizer_matches_oracle(P, ob, gpu_ctx, case):
     a, b = lo[0], ld[0]
     assert Hh.rel(b["A"], a["A"]) < 1e-9 and Hh.rel(b["b"], a["b"]) < 1e-7
     assert abs(a["new_chi2"] - b["new_chi2"]) <= 1e-9 * abs(a["new_chi2"])
+
+
+def test_pose_optimizer_row_per_frame_shape_on_a_mixed_batch(P, ob, gpu_ctx):
+    """The large-batch shape of the pose optimiser (a 16-lane DPP row per frame, four frames per wave: pose_opt_rows_kernel) on ONE batch
+    that mixes everything the other tests feed one frame at a time -- config 5, the 10-argument overload, points only, lines only, tiny,
+    empty, rank-deficient, noise-free, far outliers, NaN pose, identical points, zero iterations, 2000 + 600 features -- so that the four
+    frames of a wave differ in feature counts, iteration counts, early returns and NaN patterns; 19 frames (the last wave has an idle
+    row).  Every frame against the oracle as in its own test, and against the same frame alone at the default shape."""
+    import copy
+    frames = [(P.synth.make_poseopt_frame(seed, npts, nseg), dict(n_iter_ref=nref)) for _, seed, npts, nseg, nref in POSE_CASES]
+    frames += [(P.synth.make_poseopt_frame(83, npts, nseg), {}) for _, npts, nseg in POSE_DEGENERATE]
+    frames.append((P.synth.make_poseopt_frame(95, 60, 20, noise_px=0.0, outlier_frac=0.0, pert_t=0.0, pert_r=0.0), {}))
+    fr = P.synth.make_poseopt_frame(96, 60, 20)
+    f3 = copy.copy(fr); f3.pt_pos = fr.pt_pos.copy(); f3.pt_pos[:5] = 1e6
+    f4 = copy.copy(fr); f4.T_init = fr.T_init.copy(); f4.T_init[6] = np.nan
+    f5 = copy.copy(fr); f5.pt_pos = np.repeat(fr.pt_pos[:1], len(fr.pt_pos), 0); f5.pt_f = np.repeat(fr.pt_f[:1], len(fr.pt_f), 0)
+    frames += [(f3, {}), (f4, {}), (f5, {}), (fr, {"n_iter": 0})]
+    assert len(frames) == 19
+    jobs = [P.poseopt_job_from_frame(f, **kw) for f, kw in frames]
+    gpu_ctx.poseopt_set_trace(0)
+    alone = [gpu_ctx.pose_optimize(j) for j in jobs]            # default shape for one frame: a workgroup per frame
+    gpu_ctx.set_launch_shapes(poseopt_threads=16)
+    try:
+        rows = gpu_ctx.pose_optimize_batch(jobs)
+        recs = gpu_ctx.fetch_pose_records(len(jobs))
+    finally:
+        gpu_ctx.set_launch_shapes(poseopt_threads=0)
+    for k, (job, rd, ra) in enumerate(zip(jobs, rows, alone)):
+        ro, _ = ob.pose_optimize(job)
+        assert np.array_equal(np.isnan(rd.T), np.isnan(ro.T)), (k, rd.T, ro.T)
+        assert np.array_equal(rd.pt_keep, ro.pt_keep) and np.array_equal(rd.seg_keep, ro.seg_keep), k
+        assert (rd.num_obs_pt, rd.num_obs_ls, rd.iters, rd.iters_ref, rd.status) == (ro.num_obs_pt, ro.num_obs_ls, ro.iters, ro.iters_ref, ro.status), k
+        if not np.any(np.isnan(ro.T)):
+            assert Hh.pose_close(rd.T, ro.T)[2], (k, Hh.pose_close(rd.T, ro.T))
+            # the two launch shapes sum the normal equations in different orders: equal to rounding, not bitwise
+            assert Hh.pose_close(rd.T, ra.T, rot_tol=1e-9, trans_tol=1e-9)[2], (k, Hh.pose_close(rd.T, ra.T))
+            if k < len(POSE_CASES) + len(POSE_DEGENERATE):     # (noise-free data at the true pose: every error is projection rounding)
+                assert rd.error_init == pytest.approx(ro.error_init, rel=1e-9, abs=1e-300), k
+            if k < len(POSE_CASES):      # (rank-deficient and noise-free frames: the reference's own result hangs on rounding, DESIGN.md 5)
+                assert rd.error_final == pytest.approx(ro.error_final, rel=1e-6) and Hh.rel(rd.cov, ro.cov) < 1e-6, k
+                assert rd.estimated_scale == pytest.approx(ro.estimated_scale, rel=1e-6), k
+        assert (rd.num_obs_pt, rd.num_obs_ls, rd.iters) == (ra.num_obs_pt, ra.num_obs_ls, ra.iters), k
+        assert np.array_equal(recs[k]["T_f_w"], np.asarray(rd.T), equal_nan=True) and int(recs[k]["num_obs_pt"]) == rd.num_obs_pt, k
+    assert int(recs[7]["status"]) & P.abi.REC_POSEOPT_EMPTY      # the empty frame
 
 
 POSE_DEGENERATE = [("empty", 0, 0), ("one-point", 1, 0), ("two-points", 2, 0), ("one-line", 0, 1), ("three-points", 3, 0), ("two-and-two", 2, 2),
