@@ -253,7 +253,6 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   const AlignJobDev job = b.jobs[job_id];
   AlignStateDev* st = b.state + job_id;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int pair = tid >> 1, half = tid & 1;   // iteration pass: two lanes per patch slot
   const int grp = tid >> 2, row = tid & 3;     // reference-patch precompute: four lanes per slot, one patch row each
   constexpr int ROWS = T / 16;                 // DPP rows of the workgroup (row partials of the reduction)
 
@@ -425,7 +424,6 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     // ---- Gauss-Newton iterations ([ext] NLLSSolver::optimizeGaussNewton) ----
     const double fs = fabs(job.fx) / (double)(1 << level);  // focal_length / (1<<level)  :262
     const float colmax = (float)(W - 2), rowmax = (float)(Hh - 2);
-    const double f_sel = half ? job.fy : job.fx, c_sel = half ? job.cy : job.cx;
 
     for (int iter = 0; iter < job.n_iter; ++iter) {
      // A near tie whose per-pixel terms were NOT kept (HBM planes are written only while the solver is armed: 471 of 69 631 near ties
@@ -438,11 +436,9 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       if (stage > 0 && !(redo_mask & stage)) continue;
       const bool terms_only = stage > 0;
       const int last_stage = (redo_mask & 2) ? 2 : ((redo_mask & 1) ? 1 : 0);
-      // this lane's share of the pose: the row of R (and t) of its image coordinate, and the depth row (stage 2: of the previous
-      // iteration's pose, whose rotation matrix thread 0 left in s_red -- free between the reduction and the next pass)
+      // the pose (stage 2: the previous iteration's, whose rotation matrix thread 0 left in s_red -- free between the reduction and
+      // the next pass)
       const double* const pose_rt = (stage == 2) ? s_red : s_pose;
-      const double Ra = pose_rt[3 * half], Rb = pose_rt[3 * half + 1], Rc = pose_rt[3 * half + 2], ta = pose_rt[9 + half];
-      const double Rz0 = pose_rt[6], Rz1 = pose_rt[7], Rz2 = pose_rt[8], tz = pose_rt[11];
 
       // HBM planes are written only while the solver is ARMED: the step that led to this iteration was small (||x||_inf < 1e-3), which is
       // when two successive chi2 values can come within the rounding noise of the reference's sums (99 % of the near ties of 60
@@ -460,20 +456,17 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
         const bool write_abs = (!long_lines || pass == 0) && !terms_only;
         const bool accumulate = pass == 1 && !terms_only;
         const int n_rounds_slots = terms_only ? min(n_slots, job.n_pts) : n_slots;   // a terms-only re-run visits the point slots only
-        // Three stages per slot, software-pipelined over the rounds of the pass:
-        //   stage A  table entry + 3-D point                      (does not depend on the pose)
-        //   stage B  warp + project the point, gather the 5x5 window of the current image (needs A)
-        //   stage C  cached reference patch rows 2h, 2h+1 -> residuals, patch sums, line weights, expansion (needs B)
-        // The loads of stages A and C of round r+1 are issued right after the pixel arithmetic of round r -- the registers of r's
-        // cache rows are dead there, the latency overlaps r's line weights and expansion (measured: -2.7 % launch time at 32768
-        // frames, nothing at small batches; also projecting round r+1 and requesting its window a round ahead spilled 11 VGPRs and
-        // gained nothing: DESIGN.md 3.1).
+        // ONE LANE PER SLOT.  Per round a lane (a) reads its table entry and 3-D point, (b) warps and projects the point and requests the
+        // 5x5 window of the current image (five rows, two aligned dwords each), (c) reads the four cached rows of reference intensity and
+        // gradient, then evaluates the 16 pixels row by row -- the sums over a patch in the reference's own pixel order -- exchanges the
+        // line residuals through LDS and expands the slot's 6x6 contribution.  Table entry and 3-D point of round r+1 are requested
+        // before round r's arithmetic.  (Rounds 1-3 of this build gave a slot to a lane PAIR: per-slot work -- projection, Jacobian,
+        // line weights, half of the expansion -- was issued twice per slot, a wave-round covered 32 slots and a frame kept 64 slots
+        // in flight per SIMD at two waves of 249 VGPRs; a lane per slot issues that work once and keeps 128 slots in flight.)
         struct SlotA { int2 meta; bool cand; double X, Y, Z; };
-        struct SlotB { bool live; float u, v; int sh0, sh1, sh2; uint32_t r0a, r0b, r1a, r1b, r2a, r2b; };
-        struct SlotC { float4 vr0, vx0, vy0, vr1, vx1, vy1; };
         auto stage_a = [&](int pb_) -> SlotA {
           SlotA f;
-          const int p_ = pb_ + pair;
+          const int p_ = pb_ + tid;
           f.meta = make_int2(SLOT_HOLE, 0);
           if (p_ < n_slots) f.meta = s_meta[p_];
           f.cand = f.meta.x != SLOT_HOLE;
@@ -482,105 +475,115 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           if (f.cand) { f.X = pxyz[3 * p_]; f.Y = pxyz[3 * p_ + 1]; f.Z = pxyz[3 * p_ + 2]; }
           return f;
         };
-        auto stage_b = [&](const SlotA& sa) -> SlotB {
-          SlotB g;
-          // warp the 3-D point, project (:422-431, :583-594): lane 0 of the pair computes u, lane 1 computes v
-          const double c_cam = Ra * sa.X + Rb * sa.Y + Rc * sa.Z + ta;
-          const double z_cam = Rz0 * sa.X + Rz1 * sa.Y + Rz2 * sa.Z + tz;
-          const float w_mine = (float)((f_sel * (c_cam / z_cam) + c_sel) * scale);
-          const float w_other = dpp_mov_f32<DPP_QUAD_XOR1>(w_mine);
-          g.u = half ? w_other : w_mine; g.v = half ? w_mine : w_other;
-          // Patch::isInFrame(halfsize=2) on floorf(u), floorf(v); NaN -> out of frame
-          g.live = sa.cand && (g.u >= 2.0f) && (g.v >= 2.0f) && (g.u < colmax) && (g.v < rowmax);
-          g.sh0 = g.sh1 = g.sh2 = 0; g.r0a = g.r0b = g.r1a = g.r1b = g.r2a = g.r2b = 0u;
-          if (g.live) {
-            // rows y0 .. y0+2 of the window, columns x0 .. x0+4: two aligned dwords per row (32-bit offsets from the wave-uniform level base)
-            const int ui = (int)floorf(g.u), vi = (int)floorf(g.v);
-            const int x0 = ui - 2, y0 = vi - 2 + 2 * half;
-            int a0, a1, a2, b0, b1, b2;
-            if (lds_img) {   // (constexpr false unless built with PLSVO_LDS_IMG)
-              const int off = y0 * W + x0;
-              g.sh0 = off & 3; g.sh1 = (off + W) & 3; g.sh2 = (off + 2 * W) & 3;
-              a0 = off & ~3; a1 = (off + W) & ~3; a2 = (off + 2 * W) & ~3;
-              // (explicit LDS address space: left generic, the compiler merges this path with the global one into flat_load)
-              const PLSVO_LDS unsigned char* const li = (const PLSVO_LDS unsigned char*)s_img;
-              g.r0a = *(const PLSVO_LDS uint32_t*)(li + a0); g.r0b = *(const PLSVO_LDS uint32_t*)(li + a0 + 4);
-              g.r1a = *(const PLSVO_LDS uint32_t*)(li + a1); g.r1b = *(const PLSVO_LDS uint32_t*)(li + a1 + 4);
-              g.r2a = *(const PLSVO_LDS uint32_t*)(li + a2); g.r2b = *(const PLSVO_LDS uint32_t*)(li + a2 + 4);
-              return g;
-            }
-            if constexpr (kTiled) {
-              g.sh0 = g.sh1 = g.sh2 = x0 & 3;
-              const int ca = tiled_col_offset(x0 & ~3), cb = tiled_col_offset((x0 & ~3) + 4);
-              const int q0 = tiled_row_offset(pitch, y0), q1 = tiled_row_offset(pitch, y0 + 1), q2 = tiled_row_offset(pitch, y0 + 2);
-              a0 = q0 + ca; b0 = q0 + cb; a1 = q1 + ca; b1 = q1 + cb; a2 = q2 + ca; b2 = q2 + cb;
-            } else {
-              const int off = y0 * pitch + x0;
-              g.sh0 = off & 3; g.sh1 = (off + pitch) & 3; g.sh2 = (off + 2 * pitch) & 3;
-              a0 = off & ~3; a1 = (off + pitch) & ~3; a2 = (off + 2 * pitch) & ~3;
-              b0 = a0 + 4; b1 = a1 + 4; b2 = a2 + 4;
-            }
-            g.r0a = *reinterpret_cast<const uint32_t*>(cur_img + a0); g.r0b = *reinterpret_cast<const uint32_t*>(cur_img + b0);
-            g.r1a = *reinterpret_cast<const uint32_t*>(cur_img + a1); g.r1b = *reinterpret_cast<const uint32_t*>(cur_img + b1);
-            g.r2a = *reinterpret_cast<const uint32_t*>(cur_img + a2); g.r2b = *reinterpret_cast<const uint32_t*>(cur_img + b2);
-          }
-          return g;
-        };
-        auto stage_c_loads = [&](int pb_, bool cand_) -> SlotC {
+        struct SlotC { float4 vr[4], vx[4], vy[4]; };
+        auto stage_c = [&](int pb_, bool cand_) -> SlotC {
           SlotC c;
-          c.vr0 = make_float4(0.f, 0.f, 0.f, 0.f); c.vx0 = c.vr0; c.vy0 = c.vr0; c.vr1 = c.vr0; c.vx1 = c.vr0; c.vy1 = c.vr0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { c.vr[r] = make_float4(0.f, 0.f, 0.f, 0.f); c.vx[r] = c.vr[r]; c.vy[r] = c.vr[r]; }
           if (cand_) {
-            const size_t q = (pbase + pb_ + pair) * 4 + 2 * half;
-            c.vr0 = reinterpret_cast<const float4*>(b.cache_ref)[q]; c.vr1 = reinterpret_cast<const float4*>(b.cache_ref)[q + 1];
-            c.vx0 = reinterpret_cast<const float4*>(b.cache_dx)[q];  c.vx1 = reinterpret_cast<const float4*>(b.cache_dx)[q + 1];
-            c.vy0 = reinterpret_cast<const float4*>(b.cache_dy)[q];  c.vy1 = reinterpret_cast<const float4*>(b.cache_dy)[q + 1];
+            // cached reference patch + gradient: 3 x 64 contiguous bytes per lane, consecutive lanes consecutive slots
+            const size_t q = (pbase + pb_ + tid) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              c.vr[r] = reinterpret_cast<const float4*>(b.cache_ref)[q + r];
+              c.vx[r] = reinterpret_cast<const float4*>(b.cache_dx)[q + r];
+              c.vy[r] = reinterpret_cast<const float4*>(b.cache_dy)[q + r];
+            }
           }
           return c;
         };
         SlotA a_nxt = stage_a(0);
-        SlotC c_nxt = stage_c_loads(0, a_nxt.cand);
-        for (int pb = 0; pb < n_rounds_slots; pb += T / 2) {
-          const int p = pb + pair;
+        SlotC c_nxt = stage_c(0, a_nxt.cand);
+        for (int pb = 0; pb < n_rounds_slots; pb += T) {
+          const int p = pb + tid;
           const SlotA sa = a_nxt;
-          const SlotC sc = c_nxt;
-          const SlotB sb = stage_b(sa);
           const int2 meta = sa.meta;
           const bool hole = meta.x == SLOT_HOLE;
           const bool is_line = !hole && meta.x < 0;
           const bool cand = sa.cand;
           const double X = sa.X, Y = sa.Y, Z = sa.Z;
-          const float u = sb.u, v = sb.v;
-          const bool live = sb.live;
-          const float4 vr0 = sc.vr0, vx0 = sc.vx0, vy0 = sc.vy0, vr1 = sc.vr1, vx1 = sc.vx1, vy1 = sc.vy1;
+          // -- warp the 3-D point, project (:422-431, :583-594); the pose is re-read from LDS every round (twelve doubles that would
+          //    otherwise stay in registers across the whole pass)
+          const PLSVO_LDS double* const pq = (const PLSVO_LDS double*)pose_rt;
+          const double x_cam = pq[0] * X + pq[1] * Y + pq[2] * Z + pq[9];
+          const double y_cam = pq[3] * X + pq[4] * Y + pq[5] * Z + pq[10];
+          const double z_cam = pq[6] * X + pq[7] * Y + pq[8] * Z + pq[11];
+          const float u = (float)((job.fx * (x_cam / z_cam) + job.cx) * scale);
+          const float v = (float)((job.fy * (y_cam / z_cam) + job.cy) * scale);
+          // Patch::isInFrame(halfsize=2) on floorf(u), floorf(v); NaN -> out of frame
+          const bool live = cand && (u >= 2.0f) && (v >= 2.0f) && (u < colmax) && (v < rowmax);
+          // -- the window: rows vi-2 .. vi+2, columns ui-2 .. ui+2, two aligned dwords per row (32-bit offsets from the wave-uniform level base)
+          uint32_t wlo[5] = { 0u, 0u, 0u, 0u, 0u }, whi[5] = { 0u, 0u, 0u, 0u, 0u };
+          int wsh[5] = { 0, 0, 0, 0, 0 };
+          const SlotC sc = c_nxt;
+          if (live) {
+            const int ui = (int)floorf(u), vi = (int)floorf(v);
+            const int x0 = ui - 2, y0 = vi - 2;
+            if (lds_img) {   // (constexpr false unless built with PLSVO_LDS_IMG)
+              // (explicit LDS address space: left generic, the compiler merges this path with the global one into flat_load)
+              const PLSVO_LDS unsigned char* const li = (const PLSVO_LDS unsigned char*)s_img;
+#pragma unroll
+              for (int r = 0; r < 5; ++r) {
+                const int off = (y0 + r) * W + x0;
+                wsh[r] = off & 3;
+                wlo[r] = *(const PLSVO_LDS uint32_t*)(li + (off & ~3)); whi[r] = *(const PLSVO_LDS uint32_t*)(li + (off & ~3) + 4);
+              }
+            } else if constexpr (kTiled) {
+              const int ca = tiled_col_offset(x0 & ~3), cb = tiled_col_offset((x0 & ~3) + 4);
+#pragma unroll
+              for (int r = 0; r < 5; ++r) {
+                const int q = tiled_row_offset(pitch, y0 + r);
+                wsh[r] = x0 & 3;
+                wlo[r] = *reinterpret_cast<const uint32_t*>(cur_img + (q + ca)); whi[r] = *reinterpret_cast<const uint32_t*>(cur_img + (q + cb));
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 5; ++r) {
+                const int off = (y0 + r) * pitch + x0;
+                wsh[r] = off & 3;
+                wlo[r] = *reinterpret_cast<const uint32_t*>(cur_img + (off & ~3)); whi[r] = *reinterpret_cast<const uint32_t*>(cur_img + (off & ~3) + 4);
+              }
+            }
+          }
+          a_nxt = stage_a(pb + T);   // (slots beyond the table come back as holes: no loads)
 
-          // -- residuals and the five patch sums over this lane's two patch rows (8 pixels)
+          // -- residuals and the five patch sums over the 16 pixels, row by row
           double sA = 0, sB = 0, sC = 0, sD = 0, sE = 0, sChi = 0;
           float sAbs = 0.0f;
           const bool any_point = __any(live && !is_line) != 0;   // wave-uniform
-          float4 chi_t0 = make_float4(0.f, 0.f, 0.f, 0.f), chi_t1 = chi_t0;   // a patch outside the current image contributes nothing (:432-433): +0
+          // The chi2 terms of a POINT slot (16 floats = 64 contiguous bytes per lane) go to this iteration's plane of chi_terms, row by
+          // row (written while the solver is armed or a near tie is being re-run; line pixels are not stored: every byte written costs
+          // its time).  A patch outside the current image contributes nothing (:432-433): +0.
+          const bool chi_out = (accumulate || terms_only) && store_chi && p < job.n_pts;
+          // (two explicit address spaces: one generic pointer would make these flat stores, which also wait for the LDS counter)
+          PLSVO_LDS plsvo_v4f* const chi_lds = (PLSVO_LDS plsvo_v4f*)(s_win + (iter & 1) * b.chi_lds_pts * 16 + p * 16);     // small batches: the planes are in LDS (kernel-uniform)
+          PLSVO_GLOBAL plsvo_v4f* const chi_glb = (PLSVO_GLOBAL plsvo_v4f*)(chi_it + (unsigned)(p * 16));                    // wave-uniform base + 32-bit lane offset
+          auto chi_store = [&](int r, const float4& t) {
+            const plsvo_v4f t4 = { t.x, t.y, t.z, t.w };
+            if (b.chi_lds_pts > 0) chi_lds[r] = t4; else chi_glb[r] = t4;
+          };
+          if (chi_out && !live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) chi_store(r, make_float4(0.f, 0.f, 0.f, 0.f));
+          }
           if (live) {
             const PatchW pw = patch_weights(u, v);
-            const uint32_t r0a = sb.r0a, r0b = sb.r0b, r1a = sb.r1a, r1b = sb.r1b, r2a = sb.r2a, r2b = sb.r2b;
             auto unpack5 = [](uint32_t lo, uint32_t hi, int sh, float* o) {
               const uint32_t w0 = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh);
               o[0] = (float)(w0 & 0xffu); o[1] = (float)((w0 >> 8) & 0xffu); o[2] = (float)((w0 >> 16) & 0xffu); o[3] = (float)(w0 >> 24);
               o[4] = (float)((hi >> (8 * sh)) & 0xffu);
             };
-            float r0[5], r1[5], r2[5];
-            unpack5(r0a, r0b, sb.sh0, r0);
-            unpack5(r1a, r1b, sb.sh1, r1);
-            unpack5(r2a, r2b, sb.sh2, r2);
             const bool is_point = !is_line;
             // WEIGHTED is decided per wave: the slot table lists points first, then line samples, so most rounds are
-            // homogeneous and the line-only ones skip the robust weight (11 instructions per pixel) and the chi2 term.
+            // homogeneous and the line-only ones skip the robust weight and the chi2 term.
             // (a packed-FP32 form of this loop, two pixels per v_pk_* instruction, was measured 12 % slower)
-            // (every pixel's chi2 term -- res*res*w of a point pixel, |res| of a line pixel -- also goes to this iteration's
-            //  plane of chi_terms, one float4 per patch row: what exact_chi2_pair re-adds in the reference's order on a near tie)
-            auto row4 = [&](auto WEIGHTED, const float* top, const float* bot, const float4& vr, const float4& vx, const float4& vy, float4& tv4) {
+            // (every POINT pixel's chi2 term res*res*w goes to this iteration's plane of chi_terms, one float4 per patch row: what
+            //  exact_chi2_pair re-adds in the reference's order on a near tie)
+            auto row4 = [&](auto WEIGHTED, const float* top, const float* bot, const float4& r4, const float4& x4, const float4& y4, float4& tv4) {
               constexpr bool weighted = decltype(WEIGHTED)::value;
-              const float* pr = reinterpret_cast<const float*>(&vr);
-              const float* pxp = reinterpret_cast<const float*>(&vx);
-              const float* pyp = reinterpret_cast<const float*>(&vy);
+              const float* pr = reinterpret_cast<const float*>(&r4);
+              const float* pxp = reinterpret_cast<const float*>(&x4);
+              const float* pyp = reinterpret_cast<const float*>(&y4);
               float* tv = reinterpret_cast<float*>(&tv4);
 #pragma unroll
               for (int x = 0; x < 4; ++x) {
@@ -606,39 +609,26 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
                 sAbs += ares;
               }
             };
-            if (any_point) {
-              row4(std::true_type{}, r0, r1, vr0, vx0, vy0, chi_t0);
-              row4(std::true_type{}, r1, r2, vr1, vx1, vy1, chi_t1);
-            } else {
-              row4(std::false_type{}, r0, r1, vr0, vx0, vy0, chi_t0);
-              row4(std::false_type{}, r1, r2, vr1, vx1, vy1, chi_t1);
+            float ra[5], rb[5];
+            unpack5(wlo[0], whi[0], wsh[0], ra);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* const top = (r & 1) ? rb : ra;
+              float* const bot = (r & 1) ? ra : rb;
+              unpack5(wlo[r + 1], whi[r + 1], wsh[r + 1], bot);
+              float4 chi_t = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (any_point) row4(std::true_type{}, top, bot, sc.vr[r], sc.vx[r], sc.vy[r], chi_t);
+              else row4(std::false_type{}, top, bot, sc.vr[r], sc.vx[r], sc.vy[r], chi_t);
+              if (chi_out) chi_store(r, chi_t);
             }
           }
-          // pair totals (both lanes of the pair end up with the patch sums)
-          sA += dpp_mov_f64<DPP_QUAD_XOR1>(sA); sB += dpp_mov_f64<DPP_QUAD_XOR1>(sB); sC += dpp_mov_f64<DPP_QUAD_XOR1>(sC);
-          sD += dpp_mov_f64<DPP_QUAD_XOR1>(sD); sE += dpp_mov_f64<DPP_QUAD_XOR1>(sE); sChi += dpp_mov_f64<DPP_QUAD_XOR1>(sChi);
-          sAbs += dpp_mov_f32<DPP_QUAD_XOR1>(sAbs);
-          a_nxt = stage_a(pb + T / 2);
-          c_nxt = stage_c_loads(pb + T / 2, a_nxt.cand);
-          // The chi2 terms of a POINT slot (16 floats) go to this iteration's plane of chi_terms, placed after the next round's loads
-          // have been issued: the compiler cannot prove that these stores do not alias the cache arrays, and a store inside the
-          // pixel arithmetic pins every later load behind it (measured +31 % launch time there, and the launch is within a few
-          // per cent of the achievable HBM rate: every byte written costs its time, which is why line pixels are not stored).
-          if ((accumulate || terms_only) && store_chi && p < job.n_pts) {
-            if (b.chi_lds_pts > 0) {   // small batches: the planes are in LDS (kernel-uniform)
-              float4* const chi_dst = reinterpret_cast<float4*>(s_win + (iter & 1) * b.chi_lds_pts * 16 + p * 16 + 8 * half);
-              chi_dst[0] = chi_t0; chi_dst[1] = chi_t1;
-            } else {
-              float4* const chi_dst = reinterpret_cast<float4*>(chi_it + (unsigned)(p * 16 + 8 * half));   // wave-uniform base + 32-bit lane offset
-              chi_dst[0] = chi_t0; chi_dst[1] = chi_t1;
-            }
-          }
+          c_nxt = stage_c(pb + T, a_nxt.cand);   // next round's cache rows: this round's are dead now
 
           // -- weights: points 1; a line's samples share w / mean|res| (H) and w (Jres), :640-688
           double wh = 0.0, wj = 0.0;
           if (__any(is_line && cand)) {   // wave-uniform
             if (write_abs) {
-              if (is_line && cand && half == 0) s_abs[p] = live ? sAbs : -1.0f;
+              if (is_line && cand) s_abs[p] = live ? sAbs : -1.0f;
               wave_lds_fence();   // all samples of a line sit in this wave's round (host layout); two-pass levels: see the barrier below
             }
             if (accumulate && is_line && cand) {
@@ -650,12 +640,12 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
                 const float w = (float)(1.0 / (1.0 + (double)res_));               // :675
                 wh = (double)w / (double)res_;                                     // :681  H += H_ * w / res_
                 wj = (double)w;                                                    // :682  Jres += Jres_ * w
-                if (p == first && half == 0) {                                     // :683-684
+                if (p == first) {                                                  // :683-684
                   const float term = __fmul_rn(__fmul_rn(res_, res_), w);
                   acc[27] += (double)term; acc[28] += 1.0;
                   s_lterm[(iter & 1) * scap + (-1 - meta.x)] = term;               // this iteration's plane (exact_chi2_pair)
                 }
-              } else if (p == first && half == 0) {
+              } else if (p == first) {
                 s_dead[-1 - meta.x] = iter + 1;                                    // :687-688 it->feat3D = NULL
                 b.seg_alive[job.seg_off + (-1 - meta.x)] = 0;
               }
@@ -664,26 +654,26 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           if (accumulate) {
             if (!is_line && live) {
               wh = 1.0; wj = 1.0;
-              if (half == 0) { acc[27] += sChi; acc[28] += (double)PLSVO_PATCH_AREA; }
+              acc[27] += sChi; acc[28] += (double)PLSVO_PATCH_AREA;
             }
-            if (live && half == 0) { acc[29] += 1.0; if (!is_line && store_chi && b.chi_lds_pts == 0) acc[30] += 1.0; }
-            // -- 6x6 expansion shared by the lane pair: lane 0 adds r0 (A r0 + B r1)^T and D r0, lane 1 adds r1 (B r0 + C r1)^T and E r1
+            if (live) { acc[29] += 1.0; if (!is_line && store_chi && b.chi_lds_pts == 0) acc[30] += 1.0; }
+            // -- 6x6 expansion: sum_pix w J J^T = fs^2 (r0 (A r0 + B r1)^T + r1 (B r0 + C r1)^T), sum_pix w res J = fs (D r0 + E r1)
             if (wh != 0.0 || wj != 0.0) {
               const double xyz[3] = { X, Y, Z };
               double J[12];
               jacobian_xyz2uv(xyz, J);
               const double hs = wh * fs * fs, js = wj * fs;
-              const double al = (half ? sB : sA) * hs, be = (half ? sC : sB) * hs, ga = (half ? sE : sD) * js;
-              double rr[6], vv[6];
+              const double hA = sA * hs, hB = sB * hs, hC = sC * hs, jD = sD * js, jE = sE * js;
+              double v0[6], v1[6];
 #pragma unroll
-              for (int k = 0; k < 6; ++k) { rr[k] = half ? J[6 + k] : J[k]; vv[k] = al * J[k] + be * J[6 + k]; }
+              for (int k = 0; k < 6; ++k) { v0[k] = hA * J[k] + hB * J[6 + k]; v1[k] = hB * J[k] + hC * J[6 + k]; }
               int k = 0;
 #pragma unroll
               for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int jj = i; jj < 6; ++jj) { acc[k] += rr[i] * vv[jj]; ++k; }
+                for (int jj = i; jj < 6; ++jj) { acc[k] += J[i] * v0[jj] + J[6 + i] * v1[jj]; ++k; }
 #pragma unroll
-              for (int i = 0; i < 6; ++i) acc[21 + i] -= ga * rr[i];
+              for (int i = 0; i < 6; ++i) acc[21 + i] -= jD * J[i] + jE * J[6 + i];
             }
           }
         }
