@@ -20,11 +20,12 @@ __device__ __forceinline__ float robust_weight_f64(float a) {
   return (float)q;
 }
 
-// Float-only form (rounds 1 and 2 of this build): 1 + a split exactly into s_hi + s_lo (two-sum), y0 = rcp(s_hi), exact residual by fma,
-// one correction: the quotient to ~1e-14 relative before the final rounding.  NOT bit-exact: whenever the quotient lies within ~1e-14
-// of a float rounding boundary the result can be the neighbouring float -- 13 ... 285 of the 1 132 462 081 floats in [0, 256] depending
-// on the reciprocal seed's last bit (host enumeration with seeds within +-1 ulp), and the reference's own double rounding (double
-// quotient exactly on a float midpoint: 11 inputs, e.g. a = 0.0645160973 -> 31/33) cannot be reproduced by any single rounding.
+// Float-only form (rounds 1-3 of this build; kept for tools/robust_weight_exhaustive.hip, NOT used by the kernel): 1 + a split exactly
+// into s_hi + s_lo (two-sum), y0 = rcp(s_hi), exact residual by fma, one correction: the quotient to ~1e-14 relative before the final
+// rounding.  NOT bit-exact: whenever the quotient lies within ~1e-14 of a float rounding boundary the result can be the neighbouring
+// float -- 13 of the 1 132 462 081 floats in [0, 256] on the MI355X (13 ... 285 in a host enumeration with reciprocal seeds within
+// +-1 ulp), and the reference's own double rounding (double quotient exactly on a float midpoint: 11 inputs, e.g. a = 0.0645160973 ->
+// 31/33) cannot be reproduced by any single rounding.
 __device__ __forceinline__ float robust_weight_f32(float a) {
   const float s_hi = __fadd_rn(1.0f, a);
   const float bv = __fsub_rn(s_hi, 1.0f);
