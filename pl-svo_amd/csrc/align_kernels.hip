@@ -81,6 +81,32 @@ __device__ __forceinline__ void load_row7(const uint8_t* img, int pitch, int x, 
 // every float in [0, 256] on the MI355X; +0.9 % launch time against the float-only form of rounds 1-3, which missed 13 inputs)
 __device__ __forceinline__ float robust_weight(float a) { return robust_weight_f64(a); }
 
+// PLSVO_BYTE_CACHE (A/B build, `make byte_cache`): the per-slot cache of the reference patch holds the 64-byte record of
+// align_refpatch.hpp (7x7 image bytes + the two sub-pixel fractions) instead of 3 x 16 floats; every iteration rebuilds ref / dx / dy
+// from it -- bit-identical values, 64 B instead of 192 B streamed per patch-iteration, ~340 more float operations per slot.  The record
+// lives in the cache_ref array (16 floats = 64 B per slot); cache_dx / cache_dy are not touched.
+#ifndef PLSVO_BYTE_CACHE
+#define PLSVO_BYTE_CACHE 0
+#endif
+template <bool TILED>
+__device__ __forceinline__ uint2 load_row8_raw(const uint8_t* img, int pitch, int x, int y) {   // bytes [x, x+8) of row y (same requests as load_row7)
+  uint32_t d0, d1, d2, sh;
+  if constexpr (TILED) {
+    const int a = x & ~3;
+    sh = (uint32_t)(x & 3);
+    const int row = tiled_row_offset(pitch, y);
+    d0 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a)));
+    d1 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a + 4)));
+    d2 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a + 8)));
+  } else {
+    const int off = y * pitch + x, a = off & ~3;
+    sh = (uint32_t)(off & 3);
+    d0 = *reinterpret_cast<const uint32_t*>(img + a);
+    d1 = *reinterpret_cast<const uint32_t*>(img + a + 4);
+    d2 = *reinterpret_cast<const uint32_t*>(img + a + 8);
+  }
+  return make_uint2(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh));
+}
 // optional per-phase timing (compile with -DPLSVO_TIMING): thread 0 accumulates s_memtime deltas
 #ifdef PLSVO_TIMING
 #define TICK(slot) do { if (tid == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); s_time[slot] += t__ - s_tlast; s_tlast = t__; } } while (0)
@@ -400,6 +426,16 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
       if (p < n_slots && s_meta[p].x != SLOT_HOLE) {
         const float u = b.patch_uvref[2 * (pbase + p)], v = b.patch_uvref[2 * (pbase + p) + 1];
         const PatchW pw = patch_weights(u, v);
+#if PLSVO_BYTE_CACHE
+        {   // lane `row` of the slot's four writes record rows `row` and `row + 4` (image rows vi-3+.., columns ui-3 .. ui+3); lane 3 the fractions
+          unsigned char* const rec = reinterpret_cast<unsigned char*>(b.cache_ref) + ((pbase + p) << 6);
+          const int cx = pw.ui - 3, ry = pw.vi - 3 + row;
+          *reinterpret_cast<uint2*>(rec + 8 * row) = load_row8_raw<kTiled>(ref_img, pitch, cx, ry);
+          if (row < 3) *reinterpret_cast<uint2*>(rec + 8 * (row + 4)) = load_row8_raw<kTiled>(ref_img, pitch, cx, ry + 4);
+          else *reinterpret_cast<float2*>(rec + 56) = make_float2(u - floorf(u), v - floorf(v));
+          continue;
+        }
+#endif
         // patch row `row` sits on image row vi-2+row; the stencil needs image rows -1..+2 around it
         const int r0 = pw.vi - 2 + row - 1;
         const int c0 = pw.ui - 2 - 1;
@@ -472,6 +508,20 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           if (f.cand) { f.X = pxyz[3 * p_]; f.Y = pxyz[3 * p_ + 1]; f.Z = pxyz[3 * p_ + 2]; }
           return f;
         };
+#if PLSVO_BYTE_CACHE
+        struct SlotC { uint4 q[4]; };
+        auto stage_c = [&](int pb_, bool cand_) -> SlotC {
+          SlotC c;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c.q[r] = make_uint4(0u, 0u, 0u, 0u);
+          if (cand_) {
+            const uint4* const rec = reinterpret_cast<const uint4*>(b.cache_ref) + (pbase + pb_ + tid) * 4;   // one 64-byte record per lane
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c.q[r] = rec[r];
+          }
+          return c;
+        };
+#else
         struct SlotC { float4 vr[4], vx[4], vy[4]; };
         auto stage_c = [&](int pb_, bool cand_) -> SlotC {
           SlotC c;
@@ -489,6 +539,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           }
           return c;
         };
+#endif
         SlotA a_nxt = stage_a(0);
         SlotC c_nxt = stage_c(0, a_nxt.cand);
         for (int pb = 0; pb < n_rounds_slots; pb += T) {
@@ -608,16 +659,28 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
             };
             float ra[5], rb[5];
             unpack5(wlo[0], whi[0], wsh[0], ra);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
+#if PLSVO_BYTE_CACHE
+            RecordRows rec;
+            rec.start(sc.q);
+#endif
+            auto patch_row = [&](auto RI) {
+              constexpr int r = decltype(RI)::value;
               float* const top = (r & 1) ? rb : ra;
               float* const bot = (r & 1) ? ra : rb;
               unpack5(wlo[r + 1], whi[r + 1], wsh[r + 1], bot);
               float4 chi_t = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (any_point) row4(std::true_type{}, top, bot, sc.vr[r], sc.vx[r], sc.vy[r], chi_t);
-              else row4(std::false_type{}, top, bot, sc.vr[r], sc.vx[r], sc.vy[r], chi_t);
+#if PLSVO_BYTE_CACHE
+              float4 r4, x4, y4;
+              rec.template row<r>(r4, x4, y4);
+#else
+              const float4 r4 = sc.vr[r], x4 = sc.vx[r], y4 = sc.vy[r];
+#endif
+              if (any_point) row4(std::true_type{}, top, bot, r4, x4, y4, chi_t);
+              else row4(std::false_type{}, top, bot, r4, x4, y4, chi_t);
               if (chi_out) chi_store(r, chi_t);
-            }
+            };
+            patch_row(std::integral_constant<int, 0>{}); patch_row(std::integral_constant<int, 1>{});
+            patch_row(std::integral_constant<int, 2>{}); patch_row(std::integral_constant<int, 3>{});
           }
           c_nxt = stage_c(pb + T, a_nxt.cand);   // next round's cache rows: this round's are dead now
 
@@ -823,6 +886,9 @@ extern "C" const char* plsvo_hip_build_flags(void) {
   return ""
 #if PLSVO_LDS_IMG
          "lds_img "
+#endif
+#if PLSVO_BYTE_CACHE
+         "byte_cache "
 #endif
       ;
 }

@@ -1,6 +1,7 @@
 // Host build of pl-svo_amd/csrc/align_refpatch.hpp (g++ -ffp-contract=off): the record form of the reference-patch cache (PLSVO_BYTE_CACHE:
-// 7 rows of 8 image bytes + the two sub-pixel fractions, rebuilt every iteration by the lane pair) against the direct form the precompute
-// writes (four lanes, one patch row each).  Bitwise comparison of all 48 floats of a patch; prints "<cases> <mismatching floats>".
+// 7 rows of 8 image bytes + the two sub-pixel fractions, rebuilt every iteration by the slot's lane, one patch row at a time) against the
+// direct form the precompute writes (four lanes, one patch row each).  Bitwise comparison of all 48 floats of a patch; prints
+// "<cases> <mismatching float4s>".
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -35,18 +36,17 @@ int main(int argc, char** argv) {
       for (int rr = 0; rr < 4; ++rr) for (int c = 0; c < 7; ++c) I[rr][c] = (float)win[row + rr][c];
       ref_row_direct(I, pw.wTL, pw.wTR, pw.wBL, pw.wBR, dr[row], dx[row], dy[row]);
     }
-    // ---- record form: 64 bytes = 7 rows x 8 B, then su, sv; lane `half` reads bytes [16 half, 16 half + 40) and [56, 64)
+    // ---- record form: 64 bytes = 7 rows x 8 B, then su, sv; the slot's lane reads the record as four 16-byte words
     unsigned char rec[64];
     for (int r = 0; r < 7; ++r) memcpy(rec + 8 * r, win[r], 8);
     const float frac[2] = { u - floorf(u), v - floorf(v) };
     memcpy(rec + 56, frac, 8);
-    for (int half = 0; half < 2; ++half) {
-      uint4 q01, q23; uint2 q4; float sw[2];
-      memcpy(&q01, rec + 16 * half, 16); memcpy(&q23, rec + 16 * half + 16, 16); memcpy(&q4, rec + 16 * half + 32, 8); memcpy(sw, rec + 56, 8);
-      float4 r0, x0, y0, r1, x1, y1;
-      ref_rows_from_record(q01, q23, q4, sw[0], sw[1], r0, x0, y0, r1, x1, y1);
-      bad += memcmp(&r0, &dr[2 * half], 16) != 0; bad += memcmp(&x0, &dx[2 * half], 16) != 0; bad += memcmp(&y0, &dy[2 * half], 16) != 0;
-      bad += memcmp(&r1, &dr[2 * half + 1], 16) != 0; bad += memcmp(&x1, &dx[2 * half + 1], 16) != 0; bad += memcmp(&y1, &dy[2 * half + 1], 16) != 0;
+    uint4 q[4];
+    memcpy(q, rec, 64);
+    float4 rr[4], rx[4], ry[4];
+    ref_patch_from_record(q, rr, rx, ry);
+    for (int row = 0; row < 4; ++row) {
+      bad += memcmp(&rr[row], &dr[row], 16) != 0; bad += memcmp(&rx[row], &dx[row], 16) != 0; bad += memcmp(&ry[row], &dy[row], 16) != 0;
     }
   }
   printf("%d %ld\n", cases, bad);
