@@ -540,32 +540,25 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           return c;
         };
 #endif
-        SlotA a_nxt = stage_a(0);
-        SlotC c_nxt = stage_c(0, a_nxt.cand);
-        for (int pb = 0; pb < n_rounds_slots; pb += T) {
-          const int p = pb + tid;
-          const SlotA sa = a_nxt;
-          const int2 meta = sa.meta;
-          const bool hole = meta.x == SLOT_HOLE;
-          const bool is_line = !hole && meta.x < 0;
-          const bool cand = sa.cand;
-          const double X = sa.X, Y = sa.Y, Z = sa.Z;
-          // -- warp the 3-D point, project (:422-431, :583-594); the pose is re-read from LDS every round (twelve doubles that would
-          //    otherwise stay in registers across the whole pass)
+        // stage B: warp + project the slot's point, request the 5x5 window of the current image
+        struct SlotB { bool live; float u, v; uint32_t wlo[5], whi[5]; int wsh[5]; };
+        auto stage_b = [&](const SlotA& a_) -> SlotB {
+          SlotB g;
+          // warp the 3-D point, project (:422-431, :583-594); the pose is re-read from LDS every round (twelve doubles that would
+          // otherwise stay in registers across the whole pass)
           const PLSVO_LDS double* const pq = (const PLSVO_LDS double*)pose_rt;
-          const double x_cam = pq[0] * X + pq[1] * Y + pq[2] * Z + pq[9];
-          const double y_cam = pq[3] * X + pq[4] * Y + pq[5] * Z + pq[10];
-          const double z_cam = pq[6] * X + pq[7] * Y + pq[8] * Z + pq[11];
-          const float u = (float)((job.fx * (x_cam / z_cam) + job.cx) * scale);
-          const float v = (float)((job.fy * (y_cam / z_cam) + job.cy) * scale);
+          const double x_cam = pq[0] * a_.X + pq[1] * a_.Y + pq[2] * a_.Z + pq[9];
+          const double y_cam = pq[3] * a_.X + pq[4] * a_.Y + pq[5] * a_.Z + pq[10];
+          const double z_cam = pq[6] * a_.X + pq[7] * a_.Y + pq[8] * a_.Z + pq[11];
+          g.u = (float)((job.fx * (x_cam / z_cam) + job.cx) * scale);
+          g.v = (float)((job.fy * (y_cam / z_cam) + job.cy) * scale);
           // Patch::isInFrame(halfsize=2) on floorf(u), floorf(v); NaN -> out of frame
-          const bool live = cand && (u >= 2.0f) && (v >= 2.0f) && (u < colmax) && (v < rowmax);
-          // -- the window: rows vi-2 .. vi+2, columns ui-2 .. ui+2, two aligned dwords per row (32-bit offsets from the wave-uniform level base)
-          uint32_t wlo[5] = { 0u, 0u, 0u, 0u, 0u }, whi[5] = { 0u, 0u, 0u, 0u, 0u };
-          int wsh[5] = { 0, 0, 0, 0, 0 };
-          const SlotC sc = c_nxt;
-          if (live) {
-            const int ui = (int)floorf(u), vi = (int)floorf(v);
+          g.live = a_.cand && (g.u >= 2.0f) && (g.v >= 2.0f) && (g.u < colmax) && (g.v < rowmax);
+          // the window: rows vi-2 .. vi+2, columns ui-2 .. ui+2, two aligned dwords per row (32-bit offsets from the wave-uniform level base)
+#pragma unroll
+          for (int r = 0; r < 5; ++r) { g.wlo[r] = 0u; g.whi[r] = 0u; g.wsh[r] = 0; }
+          if (g.live) {
+            const int ui = (int)floorf(g.u), vi = (int)floorf(g.v);
             const int x0 = ui - 2, y0 = vi - 2;
             if (lds_img) {   // (constexpr false unless built with PLSVO_LDS_IMG)
               // (explicit LDS address space: left generic, the compiler merges this path with the global one into flat_load)
@@ -573,27 +566,68 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 #pragma unroll
               for (int r = 0; r < 5; ++r) {
                 const int off = (y0 + r) * W + x0;
-                wsh[r] = off & 3;
-                wlo[r] = *(const PLSVO_LDS uint32_t*)(li + (off & ~3)); whi[r] = *(const PLSVO_LDS uint32_t*)(li + (off & ~3) + 4);
+                g.wsh[r] = off & 3;
+                g.wlo[r] = *(const PLSVO_LDS uint32_t*)(li + (off & ~3)); g.whi[r] = *(const PLSVO_LDS uint32_t*)(li + (off & ~3) + 4);
               }
             } else if constexpr (kTiled) {
               const int ca = tiled_col_offset(x0 & ~3), cb = tiled_col_offset((x0 & ~3) + 4);
 #pragma unroll
               for (int r = 0; r < 5; ++r) {
                 const int q = tiled_row_offset(pitch, y0 + r);
-                wsh[r] = x0 & 3;
-                wlo[r] = *reinterpret_cast<const uint32_t*>(cur_img + (q + ca)); whi[r] = *reinterpret_cast<const uint32_t*>(cur_img + (q + cb));
+                g.wsh[r] = x0 & 3;
+                g.wlo[r] = *reinterpret_cast<const uint32_t*>(cur_img + (q + ca)); g.whi[r] = *reinterpret_cast<const uint32_t*>(cur_img + (q + cb));
               }
             } else {
 #pragma unroll
               for (int r = 0; r < 5; ++r) {
                 const int off = (y0 + r) * pitch + x0;
-                wsh[r] = off & 3;
-                wlo[r] = *reinterpret_cast<const uint32_t*>(cur_img + (off & ~3)); whi[r] = *reinterpret_cast<const uint32_t*>(cur_img + (off & ~3) + 4);
+                g.wsh[r] = off & 3;
+                g.wlo[r] = *reinterpret_cast<const uint32_t*>(cur_img + (off & ~3)); g.whi[r] = *reinterpret_cast<const uint32_t*>(cur_img + (off & ~3) + 4);
               }
             }
           }
-          a_nxt = stage_a(pb + T);   // (slots beyond the table come back as holes: no loads)
+          return g;
+        };
+        // PLSVO_GATHER_AHEAD (A/B build): round r+1 is projected and its window requested BEFORE round r's arithmetic (its table entry and
+        // 3-D point were requested a round earlier still), so that the gather's latency -- the one load of a round that depends on another
+        // load -- also has a whole round to arrive.  Costs the registers of a second SlotA and a SlotB.
+#ifndef PLSVO_GATHER_AHEAD
+#define PLSVO_GATHER_AHEAD 0
+#endif
+#if PLSVO_GATHER_AHEAD
+        SlotA a_cur = stage_a(0);
+        SlotC c_nxt = stage_c(0, a_cur.cand);
+        SlotA a_nxt = stage_a(T);
+        SlotB b_cur = stage_b(a_cur);
+#else
+        SlotA a_nxt = stage_a(0);
+        SlotC c_nxt = stage_c(0, a_nxt.cand);
+#endif
+        for (int pb = 0; pb < n_rounds_slots; pb += T) {
+          const int p = pb + tid;
+#if PLSVO_GATHER_AHEAD
+          const SlotA sa = a_cur;
+          const SlotB sb = b_cur;
+          const SlotC sc = c_nxt;
+          b_cur = stage_b(a_nxt);            // round r+1: project, request its window
+          a_cur = a_nxt;
+          a_nxt = stage_a(pb + 2 * T);       // round r+2: table entry + 3-D point (slots beyond the table come back as holes: no loads)
+          const bool next_cand = a_cur.cand;
+#else
+          const SlotA sa = a_nxt;
+          const SlotC sc = c_nxt;
+          const SlotB sb = stage_b(sa);
+          a_nxt = stage_a(pb + T);           // (slots beyond the table come back as holes: no loads)
+          const bool next_cand = a_nxt.cand;
+#endif
+          const int2 meta = sa.meta;
+          const bool hole = meta.x == SLOT_HOLE;
+          const bool is_line = !hole && meta.x < 0;
+          const bool cand = sa.cand;
+          const double X = sa.X, Y = sa.Y, Z = sa.Z;
+          const float u = sb.u, v = sb.v;
+          const bool live = sb.live;
+          const uint32_t* const wlo = sb.wlo; const uint32_t* const whi = sb.whi; const int* const wsh = sb.wsh;
 
           // -- residuals and the five patch sums over the 16 pixels, row by row
           double sA = 0, sB = 0, sC = 0, sD = 0, sE = 0, sChi = 0;
@@ -682,7 +716,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
             patch_row(std::integral_constant<int, 0>{}); patch_row(std::integral_constant<int, 1>{});
             patch_row(std::integral_constant<int, 2>{}); patch_row(std::integral_constant<int, 3>{});
           }
-          c_nxt = stage_c(pb + T, a_nxt.cand);   // next round's cache rows: this round's are dead now
+          c_nxt = stage_c(pb + T, next_cand);   // next round's cache rows: this round's are dead now
 
           // -- weights: points 1; a line's samples share w / mean|res| (H) and w (Jres), :640-688
           double wh = 0.0, wj = 0.0;
@@ -889,6 +923,9 @@ extern "C" const char* plsvo_hip_build_flags(void) {
 #endif
 #if PLSVO_BYTE_CACHE
          "byte_cache "
+#endif
+#if PLSVO_GATHER_AHEAD
+         "gather_ahead "
 #endif
       ;
 }

@@ -910,11 +910,14 @@ extern "C" int plsvo_poseopt_run(plsvo_ctx* c) {
   RoctxRange range("pose_optimizer");
   if (!c->p_staged) return fail(c, PLSVO_E_STATE, "poseopt_run: no staged batch");
   HIP_TRY(c, hipSetDevice(c->device));
-  // a 16-lane row per frame, four frames per wave, for large batches (the serial solve + update of four frames share one instruction
-  // stream: poseopt_kernels.hip); four waves per frame when there are too few frames to fill the chip (the Gauss-Newton loop of one
-  // frame is then ~2x shorter); PLSVO_POSEOPT_THREADS / PLSVO_OPT_POSEOPT_THREADS override (tests and measurements)
+  // Large batches: a 16-lane row per frame, four frames per wave (the serial solve + update of four frames share one instruction stream:
+  // poseopt_kernels.hip) while a frame has a few hundred features -- measured on MI355X, 32768 frames: 200 + 80 features 1.86 ms against
+  // 2.03 ms for a wave per frame, 500 + 200 features 4.55 against 3.77 (a row then needs 44 dependent feature rounds per pass), so frames
+  // above ~450 features keep the wave-per-frame shape.  Too few frames to fill the chip: four waves per frame (the Gauss-Newton loop of
+  // one frame is then ~2x shorter).  PLSVO_POSEOPT_THREADS / PLSVO_OPT_POSEOPT_THREADS override (tests and measurements).
   const int cus = c->cu_count > 0 ? c->cu_count : 256;
-  int threads = c->p_n <= 2 * cus ? 256 : 16;
+  const long feats = (long)c->p_total_pt + (long)c->p_total_seg;
+  int threads = c->p_n <= 2 * cus ? 256 : (feats <= 450l * c->p_n ? 16 : 64);
   if (c->env_poseopt_threads) threads = c->env_poseopt_threads;
   EventPair ep{}; prof_begin(c, PLSVO_K_POSEOPT, &ep);
   HIP_TRY(c, launch_pose_opt(c->p_b, c->p_d_poses.as<double>(), threads, c->stream));
@@ -1328,7 +1331,7 @@ extern "C" int plsvo_chain_run(plsvo_ctx* c) {
     HIP_TRY(c, launch_chain_select(c->ch_b, c->stream));
     prof_end(c, PLSVO_K_MATCH, &ep); }
   const int cus = c->cu_count > 0 ? c->cu_count : 256;
-  int threads = c->ch_n <= 2 * cus ? 256 : 16;
+  int threads = c->ch_n <= 2 * cus ? 256 : ((long)c->ch_b.n_cand <= 450l * c->ch_n ? 16 : 64);   // (selected features <= candidates; see plsvo_poseopt_run)
   if (c->env_poseopt_threads) threads = c->env_poseopt_threads;
   EventPair ep{}; prof_begin(c, PLSVO_K_POSEOPT, &ep);
   HIP_TRY(c, launch_pose_opt(c->ch_pose, c->ch_d_poses.as<double>(), threads, c->stream));
