@@ -42,17 +42,17 @@ BYTES_PER_PATCH_LEVEL = 497     # precompute, per patch-level
 BYTES_PER_PATCH_ITER = 485      # residual/Jacobian, per patch-iteration
 BYTES_PER_POINT_ITER = 24       # pose-opt, per point-iteration
 BYTES_PER_SEG_ITER = 40         # pose-opt, per segment-iteration
-# what align_fused_kernel itself requests: per patch-iteration 192 B of ref/dx/dy cache + 24 B 3-D point
+# what align_fused_kernel itself requests: per patch-iteration the 64-byte record of the reference patch + 24 B 3-D point
 # + 5 rows x 2 aligned dwords of the current image (+ 64 B of chi2 terms written per POINT patch-iteration); per
-# patch-level 4 lanes x 4 rows x 3 dwords of the reference image read, 192 + 24 + 8 B written
-OWN_BYTES_PER_PATCH_ITER = 192 + 24 + 40
-OWN_BYTES_PER_PATCH_LEVEL = 192 + 192 + 24 + 8
+# patch-level 7 rows x 3 dwords of the reference image read, 64 + 24 + 8 B written
+OWN_BYTES_PER_PATCH_ITER = 64 + 24 + 40
+OWN_BYTES_PER_PATCH_LEVEL = 84 + 64 + 24 + 8
 CHI_BYTES_PER_POINT_ITER = 64
-# the bytes THIS formulation cannot avoid moving (the bound `roofline.frac` is priced against): per patch-iteration the 5x5 u8
-# window of the current image, the cached reference patch + gradients (3 x 16 floats) and the 3-D point; per point
-# patch-iteration also the 16 chi2 terms; per patch-level the 7x7 u8 window of the reference image read, cache + point written
-MIN_BYTES_PER_PATCH_ITER = 25 + 192 + 24
-MIN_BYTES_PER_PATCH_LEVEL = 49 + 192 + 24
+# the bytes THIS formulation cannot avoid moving (the bounded figure beside `roofline.frac`): per patch-iteration the 5x5 u8
+# window of the current image, the reference patch's 64-byte record (7x7 image bytes + two fractions) and the 3-D point; per point
+# patch-iteration also the 16 chi2 terms while armed; per patch-level the 7x7 u8 window of the reference image read, record + point written
+MIN_BYTES_PER_PATCH_ITER = 25 + 64 + 24
+MIN_BYTES_PER_PATCH_LEVEL = 49 + 64 + 24
 
 METRIC = "sparse-align+pose-opt frames/sec, 640×480, ~200 pts+80 lines; 1/2/4/8 GPU"   # BASELINE.json's metric, verbatim
 CONFIGS = {
@@ -504,7 +504,7 @@ def main():
                     patch_levels += a_; patch_iters += b_
                 pt_iters = sum(sh["ctx"].align_work_points() for sh in shard)
                 flags = (capi.lib().plsvo_hip_build_flags() or b"").decode().split() if hasattr(capi.lib(), "plsvo_hip_build_flags") else []
-                cache_b = 192
+                cache_b = 64
                 OWN_ITER, OWN_LEVEL = OWN_BYTES_PER_PATCH_ITER, OWN_BYTES_PER_PATCH_LEVEL
                 MIN_ITER, MIN_LEVEL = MIN_BYTES_PER_PATCH_ITER, MIN_BYTES_PER_PATCH_LEVEL
                 survey_bytes = patch_levels * BYTES_PER_PATCH_LEVEL + patch_iters * BYTES_PER_PATCH_ITER
@@ -532,7 +532,7 @@ def main():
                             "formulation_min_bytes_per_launch": int(per_launch(min_bytes)),
                             "formulation_min_GBps": round(rate(min_bytes), 1), "formulation_min_frac": round(rate(min_bytes) / HBM_PEAK_GBPS, 4),
                             "formulation_min_definition": ("bytes THIS formulation cannot avoid moving: per patch-iteration 25 B window of the current image + %d B "
-                                                           "cached reference patch and gradients + 24 B 3-D point, + 64 B of chi2 terms per POINT patch-iteration "
+                                                           "record of the reference patch + 24 B 3-D point, + 64 B of chi2 terms per POINT patch-iteration "
                                                            "written while armed; per patch-level 49 B reference window + %d B cache and point written") % (cache_b, cache_b + 24),
                             "kernel_requested_bytes_per_launch": int(per_launch(own_bytes)),
                             "kernel_requested_GBps": round(rate(own_bytes), 1),

@@ -52,44 +52,19 @@ namespace plsvo_hip {
 //           itself reads -- it is bound by latency and issue, and there the tile arithmetic and the three separate dword requests
 //           per row (instead of one 12-byte request) cost 12 % of a pass and 25-45 % of a level's set-up.
 // ------------------------------------------------------------------------------------------------
-template <bool TILED>
-__device__ __forceinline__ void load_row7(const uint8_t* img, int pitch, int x, int y, float* o7) {
-  uint32_t d0, d1, d2, sh;
-  if constexpr (TILED) {
-    const int a = x & ~3;
-    sh = (uint32_t)(x & 3);
-    const int row = tiled_row_offset(pitch, y);
-    d0 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a)));
-    d1 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a + 4)));
-    d2 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a + 8)));
-  } else {
-    const int off = y * pitch + x, a = off & ~3;
-    sh = (uint32_t)(off & 3);
-    d0 = *reinterpret_cast<const uint32_t*>(img + a);
-    d1 = *reinterpret_cast<const uint32_t*>(img + a + 4);
-    d2 = *reinterpret_cast<const uint32_t*>(img + a + 8);
-  }
-  const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);  // bytes x..x+3
-  const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);  // bytes x+4..x+7
-  o7[0] = (float)(w0 & 0xffu); o7[1] = (float)((w0 >> 8) & 0xffu);
-  o7[2] = (float)((w0 >> 16) & 0xffu); o7[3] = (float)(w0 >> 24);
-  o7[4] = (float)(w1 & 0xffu); o7[5] = (float)((w1 >> 8) & 0xffu);
-  o7[6] = (float)((w1 >> 16) & 0xffu);
-}
-
 // robust weight of a point pixel: robust_weight.hpp (the reference's (float)(1.0 / (1.0 + (double)|res|)) bit for bit: 0 mismatches over
 // every float in [0, 256] on the MI355X; +0.9 % launch time against the float-only form of rounds 1-3, which missed 13 inputs)
 __device__ __forceinline__ float robust_weight(float a) { return robust_weight_f64(a); }
 
-// PLSVO_BYTE_CACHE (A/B build, `make byte_cache`): the per-slot cache of the reference patch holds the 64-byte record of
-// align_refpatch.hpp (7x7 image bytes + the two sub-pixel fractions) instead of 3 x 16 floats; every iteration rebuilds ref / dx / dy
-// from it -- bit-identical values, 64 B instead of 192 B streamed per patch-iteration, ~340 more float operations per slot.  The record
-// lives in the cache_ref array (16 floats = 64 B per slot); cache_dx / cache_dy are not touched.
-#ifndef PLSVO_BYTE_CACHE
-#define PLSVO_BYTE_CACHE 0
-#endif
+// The per-slot cache of the reference patch (the reference's ref_patch_cache_ + jacobian_cache_, include/plsvo/sparse_img_align.h:83-96) is
+// the 64-byte RECORD of align_refpatch.hpp: the 7x7 window of image bytes around the patch + the two sub-pixel fractions.  Every
+// iteration the slot's lane rebuilds interpolated intensity and central-difference gradient from it, one patch row at a time, with the
+// very operations of the reference's precompute (:236-264, :348-375) -- bit-identical values (tests/test_refpatch_host.py) -- for 64 B
+// streamed per patch-iteration instead of the 192 B of three float arrays (rounds 1-3) and ~340 more float operations per slot.
+// Measured on MI355X (round 4, one lane per slot): 15.14 -> 13.91 ms per 32768-frame launch.
+// bytes [x, x+8) of row y of a u8 pyramid level: aligned dword reads + v_alignbyte
 template <bool TILED>
-__device__ __forceinline__ uint2 load_row8_raw(const uint8_t* img, int pitch, int x, int y) {   // bytes [x, x+8) of row y (same requests as load_row7)
+__device__ __forceinline__ uint2 load_row8_raw(const uint8_t* img, int pitch, int x, int y) {
   uint32_t d0, d1, d2, sh;
   if constexpr (TILED) {
     const int a = x & ~3;
@@ -122,7 +97,7 @@ __device__ __forceinline__ void block_sync() {
   if constexpr (T == 64) wave_lds_fence(); else __syncthreads();
 }
 
-// launch shapes up to this many threads per frame read the tiled pyramid mirror, larger ones the row-major slab (load_row7).
+// launch shapes up to this many threads per frame read the tiled pyramid mirror, larger ones the row-major slab.
 // Measured: 64 threads (32768 frames, the chip saturated) -7 % launch time tiled; 128 threads (8192 frames) +4 % tiled; 512 +12 % per pass.
 constexpr int kTiledMaxThreads = 64;
 // half-width of the near-tie band, in units of sqrt(n_meas) * 2^-24 (one sigma of the reference's float sum is ~0.25 of that)
@@ -134,19 +109,11 @@ __host__ __device__ inline size_t align_chi_window_offset(int threads, int cap, 
   o += (size_t)cap * (sizeof(int2) + sizeof(float)) + (size_t)scap * sizeof(int) + ((size_t)2 * scap + 2) * sizeof(float);
   return (o + 15) & ~(size_t)15;
 }
-// everything the kernel's own tables take; what the launch adds behind them is the staging area of PLSVO_LDS_IMG
+// everything the kernel's own tables take
 __host__ __device__ inline size_t align_lds_used(int threads, int cap, int scap, int chi_lds_pts) {
   const size_t window = 1024 * sizeof(float), planes = (size_t)2 * chi_lds_pts * 16 * sizeof(float);
   return align_chi_window_offset(threads, cap, scap) + (planes > window ? planes : window) + 16;
 }
-// PLSVO_LDS_IMG (experiment build, `make lds_img`): a pyramid level of the CURRENT image that fits into the LDS the workgroup has to
-// spare (AlignBatchDev::lds_img_bytes: level 3 of a 640x480 frame is 4.8 KB, next to eight frames' tables on a CU; a frame that has the CU
-// to itself fits level 1) is copied there once per level, and the 5x5 windows of every iteration are gathered from LDS instead of
-// through L2: half of all patch-iterations of the BASELINE workloads run on the coarsest level.  Same bytes, same arithmetic.
-#ifndef PLSVO_LDS_IMG
-#define PLSVO_LDS_IMG 0
-#endif
-
 // ------------------------------------------------------------------------------------------------
 // The chi2 the solver compares (`new_chi2 > chi2_`, [ext] vk::NLLSSolver::optimizeGaussNewton) is
 //     (float)(pt_chi2 + seg_chi2) / (float)n_meas_                                   src/sparse_img_align.cpp:171, 192
@@ -288,7 +255,6 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
   float* s_abs = reinterpret_cast<float*>(s_meta + cap);                 // cap: sum |res| of the slot's 16 pixels, -1 = sample not in the image
   int* s_dead = reinterpret_cast<int*>(s_abs + cap);                     // scap: per segment, 0 = alive, k + 1 = culled at iteration k of this level
   float* s_lterm = reinterpret_cast<float*>(s_dead + scap);              // 2 * scap + 2: exact chi2 term of every line, two iterations; the two sums
-  unsigned char* const s_img = smem + align_lds_used(T, cap, scap, b.chi_lds_pts);   // PLSVO_LDS_IMG: b.lds_img_bytes bytes for a level of the current image
   float* s_win = reinterpret_cast<float*>(smem + align_chi_window_offset(T, cap, scap));   // 1024: two 32-slot windows of chi_terms, or the two planes themselves (chi_lds_pts)
 
 #ifdef PLSVO_TIMING
@@ -333,7 +299,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     // (level geometry is recomputed instead of indexing the kernel-argument arrays with a run-time level,
     //  which would force the whole argument struct into scratch memory)
     const int W = job.width >> level, Hh = job.height >> level;
-    // throughput shapes read the tiled mirror of the pyramids, latency shapes the row-major slab (load_row7)
+    // throughput shapes read the tiled mirror of the pyramids, latency shapes the row-major slab
     constexpr bool kTiled = T <= kTiledMaxThreads;
     const unsigned int lvl_off = kTiled ? pyr_tiled_level_offset(job.width, job.height, level) : pyr_level_offset(job.width, job.height, level);
     const uint8_t* const pyr_base = kTiled ? b.pyr.tbase : b.pyr.base;
@@ -352,17 +318,6 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 
     if (tid == 0) { s_ctl[0] = 0; s_ctl[2] = 0; s_ctl[5] = 0; s_ctl[7] = 0; s_ctl[8] = 0; s_pose[27] = 0.0; }
     for (int p = tid; p < n_slots; p += T) s_meta[p] = make_int2(SLOT_HOLE, 0);
-#if PLSVO_LDS_IMG
-    // the level of the current image, row-major (pitch W), from the row-major slab: 16 bytes per thread and step; the slab has >= 64
-    // bytes of slack behind every level and the staging area 16, for the aligned dword pairs of the gather
-    const bool lds_img = W * Hh + 16 <= b.lds_img_bytes;   // kernel argument and level geometry: workgroup-uniform
-    if (lds_img) {
-      const uint8_t* const src = b.pyr.base + (size_t)job.cur_slot * b.pyr.slot_bytes + pyr_level_offset(job.width, job.height, level);
-      for (int i = tid * 16; i < W * Hh + 16; i += T * 16) *reinterpret_cast<uint4*>(s_img + i) = *reinterpret_cast<const uint4*>(src + i);
-    }
-#else
-    constexpr bool lds_img = false;
-#endif
     block_sync<T>();
 
     // ---- slot table: every feature fills the slots the host layout gives it ----
@@ -420,34 +375,18 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
     if (my_patches) atomicAdd(&s_ctl[5], my_patches);   // integer count: order-independent
     block_sync<T>();  // patch_uvref / patch_xyz (global) and s_meta (LDS) visible to the workgroup
 
-    // ---- reference patches: interpolated intensity + central-difference gradient (:236-264, :348-375) ----
+    // ---- reference patches (:236-264, :348-375): the byte record the iterations rebuild intensity and gradient from ----
     for (int pb = 0; pb < n_slots; pb += T / 4) {
       const int p = pb + grp;
       if (p < n_slots && s_meta[p].x != SLOT_HOLE) {
         const float u = b.patch_uvref[2 * (pbase + p)], v = b.patch_uvref[2 * (pbase + p) + 1];
         const PatchW pw = patch_weights(u, v);
-#if PLSVO_BYTE_CACHE
-        {   // lane `row` of the slot's four writes record rows `row` and `row + 4` (image rows vi-3+.., columns ui-3 .. ui+3); lane 3 the fractions
-          unsigned char* const rec = reinterpret_cast<unsigned char*>(b.cache_ref) + ((pbase + p) << 6);
-          const int cx = pw.ui - 3, ry = pw.vi - 3 + row;
-          *reinterpret_cast<uint2*>(rec + 8 * row) = load_row8_raw<kTiled>(ref_img, pitch, cx, ry);
-          if (row < 3) *reinterpret_cast<uint2*>(rec + 8 * (row + 4)) = load_row8_raw<kTiled>(ref_img, pitch, cx, ry + 4);
-          else *reinterpret_cast<float2*>(rec + 56) = make_float2(u - floorf(u), v - floorf(v));
-          continue;
-        }
-#endif
-        // patch row `row` sits on image row vi-2+row; the stencil needs image rows -1..+2 around it
-        const int r0 = pw.vi - 2 + row - 1;
-        const int c0 = pw.ui - 2 - 1;
-        float I[4][7];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) load_row7<kTiled>(ref_img, pitch, c0, r0 + rr, I[rr]);
-        float4 vr, vx, vy;
-        ref_row_direct(I, pw.wTL, pw.wTR, pw.wBL, pw.wBR, vr, vx, vy);
-        const size_t q = (pbase + p) * 4 + row;  // float4 index: slot-major, row-minor -> coalesced
-        reinterpret_cast<float4*>(b.cache_ref)[q] = vr;
-        reinterpret_cast<float4*>(b.cache_dx)[q] = vx;
-        reinterpret_cast<float4*>(b.cache_dy)[q] = vy;
+        // lane `row` of the slot's four writes record rows `row` and `row + 4` (image rows vi-3+.., columns ui-3 .. ui+3); lane 3 the fractions
+        unsigned char* const rec = reinterpret_cast<unsigned char*>(b.cache_ref) + ((pbase + p) << 6);
+        const int cx = pw.ui - 3, ry = pw.vi - 3 + row;
+        *reinterpret_cast<uint2*>(rec + 8 * row) = load_row8_raw<kTiled>(ref_img, pitch, cx, ry);
+        if (row < 3) *reinterpret_cast<uint2*>(rec + 8 * (row + 4)) = load_row8_raw<kTiled>(ref_img, pitch, cx, ry + 4);
+        else *reinterpret_cast<float2*>(rec + 56) = make_float2(u - floorf(u), v - floorf(v));
       }
     }
     if (tid == 0) { SE3d m = se3_load(s_pose + 12); quat_to_matrix(m.q, s_pose); s_pose[9] = m.t[0]; s_pose[10] = m.t[1]; s_pose[11] = m.t[2]; }
@@ -508,7 +447,6 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           if (f.cand) { f.X = pxyz[3 * p_]; f.Y = pxyz[3 * p_ + 1]; f.Z = pxyz[3 * p_ + 2]; }
           return f;
         };
-#if PLSVO_BYTE_CACHE
         struct SlotC { uint4 q[4]; };
         auto stage_c = [&](int pb_, bool cand_) -> SlotC {
           SlotC c;
@@ -521,25 +459,6 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           }
           return c;
         };
-#else
-        struct SlotC { float4 vr[4], vx[4], vy[4]; };
-        auto stage_c = [&](int pb_, bool cand_) -> SlotC {
-          SlotC c;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { c.vr[r] = make_float4(0.f, 0.f, 0.f, 0.f); c.vx[r] = c.vr[r]; c.vy[r] = c.vr[r]; }
-          if (cand_) {
-            // cached reference patch + gradient: 3 x 64 contiguous bytes per lane, consecutive lanes consecutive slots
-            const size_t q = (pbase + pb_ + tid) * 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              c.vr[r] = reinterpret_cast<const float4*>(b.cache_ref)[q + r];
-              c.vx[r] = reinterpret_cast<const float4*>(b.cache_dx)[q + r];
-              c.vy[r] = reinterpret_cast<const float4*>(b.cache_dy)[q + r];
-            }
-          }
-          return c;
-        };
-#endif
         // stage B: warp + project the slot's point, request the 5x5 window of the current image
         struct SlotB { bool live; float u, v; uint32_t wlo[5], whi[5]; int wsh[5]; };
         auto stage_b = [&](const SlotA& a_) -> SlotB {
@@ -560,16 +479,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           if (g.live) {
             const int ui = (int)floorf(g.u), vi = (int)floorf(g.v);
             const int x0 = ui - 2, y0 = vi - 2;
-            if (lds_img) {   // (constexpr false unless built with PLSVO_LDS_IMG)
-              // (explicit LDS address space: left generic, the compiler merges this path with the global one into flat_load)
-              const PLSVO_LDS unsigned char* const li = (const PLSVO_LDS unsigned char*)s_img;
-#pragma unroll
-              for (int r = 0; r < 5; ++r) {
-                const int off = (y0 + r) * W + x0;
-                g.wsh[r] = off & 3;
-                g.wlo[r] = *(const PLSVO_LDS uint32_t*)(li + (off & ~3)); g.whi[r] = *(const PLSVO_LDS uint32_t*)(li + (off & ~3) + 4);
-              }
-            } else if constexpr (kTiled) {
+            if constexpr (kTiled) {
               const int ca = tiled_col_offset(x0 & ~3), cb = tiled_col_offset((x0 & ~3) + 4);
 #pragma unroll
               for (int r = 0; r < 5; ++r) {
@@ -588,38 +498,18 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
           }
           return g;
         };
-        // PLSVO_GATHER_AHEAD (A/B build): round r+1 is projected and its window requested BEFORE round r's arithmetic (its table entry and
-        // 3-D point were requested a round earlier still), so that the gather's latency -- the one load of a round that depends on another
-        // load -- also has a whole round to arrive.  Costs the registers of a second SlotA and a SlotB.
-#ifndef PLSVO_GATHER_AHEAD
-#define PLSVO_GATHER_AHEAD 0
-#endif
-#if PLSVO_GATHER_AHEAD
-        SlotA a_cur = stage_a(0);
-        SlotC c_nxt = stage_c(0, a_cur.cand);
-        SlotA a_nxt = stage_a(T);
-        SlotB b_cur = stage_b(a_cur);
-#else
+        // (Projecting round r+1 and requesting its window BEFORE round r's arithmetic -- a second SlotA and a SlotB in flight -- was
+        //  measured slower on MI355X, 15.1 -> 16.4 ms and 13.9 -> 15.5 ms with the byte records: the registers it takes cost more than
+        //  the latency it hides.  profiles/r04d_byte_records_gather_ahead_ab.log)
         SlotA a_nxt = stage_a(0);
         SlotC c_nxt = stage_c(0, a_nxt.cand);
-#endif
         for (int pb = 0; pb < n_rounds_slots; pb += T) {
           const int p = pb + tid;
-#if PLSVO_GATHER_AHEAD
-          const SlotA sa = a_cur;
-          const SlotB sb = b_cur;
-          const SlotC sc = c_nxt;
-          b_cur = stage_b(a_nxt);            // round r+1: project, request its window
-          a_cur = a_nxt;
-          a_nxt = stage_a(pb + 2 * T);       // round r+2: table entry + 3-D point (slots beyond the table come back as holes: no loads)
-          const bool next_cand = a_cur.cand;
-#else
           const SlotA sa = a_nxt;
           const SlotC sc = c_nxt;
           const SlotB sb = stage_b(sa);
           a_nxt = stage_a(pb + T);           // (slots beyond the table come back as holes: no loads)
           const bool next_cand = a_nxt.cand;
-#endif
           const int2 meta = sa.meta;
           const bool hole = meta.x == SLOT_HOLE;
           const bool is_line = !hole && meta.x < 0;
@@ -693,22 +583,16 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
             };
             float ra[5], rb[5];
             unpack5(wlo[0], whi[0], wsh[0], ra);
-#if PLSVO_BYTE_CACHE
             RecordRows rec;
             rec.start(sc.q);
-#endif
             auto patch_row = [&](auto RI) {
               constexpr int r = decltype(RI)::value;
               float* const top = (r & 1) ? rb : ra;
               float* const bot = (r & 1) ? ra : rb;
               unpack5(wlo[r + 1], whi[r + 1], wsh[r + 1], bot);
               float4 chi_t = make_float4(0.f, 0.f, 0.f, 0.f);
-#if PLSVO_BYTE_CACHE
               float4 r4, x4, y4;
               rec.template row<r>(r4, x4, y4);
-#else
-              const float4 r4 = sc.vr[r], x4 = sc.vx[r], y4 = sc.vy[r];
-#endif
               if (any_point) row4(std::true_type{}, top, bot, r4, x4, y4, chi_t);
               else row4(std::false_type{}, top, bot, r4, x4, y4, chi_t);
               if (chi_out) chi_store(r, chi_t);
@@ -916,19 +800,7 @@ __global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBa
 size_t align_level_lds_bytes(int threads, int cap, int scap, int chi_lds_pts) { return align_lds_used(threads, cap, scap, chi_lds_pts); }
 
 }  // namespace plsvo_hip
-extern "C" const char* plsvo_hip_build_flags(void) {
-  return ""
-#if PLSVO_LDS_IMG
-         "lds_img "
-#endif
-#if PLSVO_BYTE_CACHE
-         "byte_cache "
-#endif
-#if PLSVO_GATHER_AHEAD
-         "gather_ahead "
-#endif
-      ;
-}
+extern "C" const char* plsvo_hip_build_flags(void) { return ""; }   // no compile-time experiment switch is left in this build
 namespace plsvo_hip {
 
 template <int T>

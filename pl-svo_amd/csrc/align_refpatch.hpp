@@ -1,5 +1,6 @@
 // align_refpatch.hpp -- the float arithmetic of a reference patch (interpolated intensity + central-difference gradient) of
-// align_kernels.hip, every product and sum rounded on its own.
+// align_kernels.hip, every product and sum rounded on its own: the kernel's record form (RecordRows) and, as the statement of the
+// reference's precompute it must equal bit for bit, the direct form (ref_row_direct); tests/test_refpatch_host.py compiles both for the host.
 // Reference: SparseImgAlign::precomputeGaussNewtonParamsPoints/Segments src/sparse_img_align.cpp:236-264, :348-375;
 //            Patch::setPosition + computeInterpWeights src/feature.cpp:189-208.
 #pragma once
@@ -55,7 +56,7 @@ PLSVO_HD void ref_row_direct(const float (*I)[7], float wTL, float wTR, float wB
   }
 }
 
-// ---- record form of the reference-patch cache (align_kernels.hip, PLSVO_BYTE_CACHE): the 7x7 window of image BYTES around the patch
+// ---- record form of the reference-patch cache (what align_kernels.hip keeps per slot): the 7x7 window of image BYTES around the patch
 // (record row k = image row vi-3+k, columns ui-3 .. ui+3, 8 bytes per row) and the two sub-pixel fractions, 64 B per slot instead of
 // 3 x 16 floats.  Every iteration rebuilds ref / dx / dy from it with the very operations ref_row_direct uses -- B[k][c] = bilinear over
 // record rows k, k+1 at columns c, c+1; ref = B[y+1][x+1], dx = 0.5 (B[y+1][x+2] - B[y+1][x]), dy = 0.5 (B[y+2][x+1] - B[y][x+1]) -- so the

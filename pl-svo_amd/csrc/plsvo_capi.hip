@@ -19,10 +19,6 @@
 #include "plsvo_dev.hpp"
 #include "plsvo_math.hpp"
 
-#ifndef PLSVO_LDS_IMG
-#define PLSVO_LDS_IMG 0
-#endif
-
 namespace plsvo_hip {
 // kernels (align_kernels.hip, poseopt_kernels.hip, pyramid_kernels.hip)
 size_t align_level_lds_bytes(int threads, int cap, int scap, int chi_lds_pts);
@@ -110,7 +106,7 @@ struct plsvo_ctx {
   int a_scap = 4;   // max segments of one job
   int a_trace_cap = 0;
   DevBuf a_d_state, a_d_alive;   // (inputs: a_d_blob)
-  DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_cdx, a_d_cdy, a_d_chi, a_d_log, a_d_poses;
+  DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_chi, a_d_log, a_d_poses;
   AlignBatchDev a_b{};
 
   // pose-opt batch
@@ -242,8 +238,8 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-  DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_tiled, &c->pyr_upload, &c->a_d_blob, &c->a_d_state, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv, &c->a_d_cref, &c->a_d_cdx,
-                     &c->a_d_cdy, &c->a_d_chi, &c->a_d_log, &c->a_d_poses, &c->p_d_blob, &c->p_d_state, &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64,
+  DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_tiled, &c->pyr_upload, &c->a_d_blob, &c->a_d_state, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv, &c->a_d_cref,
+                     &c->a_d_chi, &c->a_d_log, &c->a_d_poses, &c->p_d_blob, &c->p_d_state, &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64,
                      &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out, &c->ch_d_blob, &c->ch_d_work, &c->ch_d_po, &c->ch_d_state,
                      &c->ch_d_ptkeep, &c->ch_d_segkeep, &c->ch_d_s32, &c->ch_d_s64, &c->ch_d_poses, &c->rec_d };
   for (DevBuf* b : bufs) b->release();
@@ -573,9 +569,7 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   const size_t pt = std::max(patch_total, (size_t)4);
   HIP_TRY(c, c->a_d_pxyz.ensure(pt * 3 * sizeof(double)));
   HIP_TRY(c, c->a_d_puv.ensure(pt * 2 * sizeof(float)));
-  HIP_TRY(c, c->a_d_cref.ensure(pt * 16 * sizeof(float)));
-  HIP_TRY(c, c->a_d_cdx.ensure(pt * 16 * sizeof(float)));
-  HIP_TRY(c, c->a_d_cdy.ensure(pt * 16 * sizeof(float)));
+  HIP_TRY(c, c->a_d_cref.ensure(pt * 64));   // one 64-byte record per patch slot
   const size_t npt_total = ptpx.size() / 2 + 32;
   HIP_TRY(c, c->a_d_chi.ensure(2 * npt_total * 16 * sizeof(float)));   // two planes of the points' per-pixel chi2 terms
   if (c->a_trace_cap > 0) HIP_TRY(c, c->a_d_log.ensure((size_t)n * c->a_trace_cap * sizeof(plsvo_align_iterlog)));
@@ -590,7 +584,7 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   b.seg_p = reinterpret_cast<const double*>(base + o_sp); b.seg_q = reinterpret_cast<const double*>(base + o_sq);
   b.seg_alive_in = base + o_alive; b.seg_alive = c->a_d_alive.as<uint8_t>();
   b.patch_xyz = c->a_d_pxyz.as<double>(); b.patch_uvref = c->a_d_puv.as<float>();
-  b.cache_ref = c->a_d_cref.as<float>(); b.cache_dx = c->a_d_cdx.as<float>(); b.cache_dy = c->a_d_cdy.as<float>();
+  b.cache_ref = c->a_d_cref.as<float>();
   b.chi_terms = c->a_d_chi.as<float>(); b.chi_plane = (unsigned long long)npt_total * 16;
   b.seg_slot = reinterpret_cast<const int*>(base + o_slot); b.slot_level0 = slot_level0; b.slot_stride = (int)total_seg;
   b.poses = c->a_d_poses.as<double>();
@@ -666,19 +660,7 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
   int max_pts = 0, chi_lds_pts = 0;
   for (const AlignJobDev& J : c->a_jobs) max_pts = std::max(max_pts, J.n_pts);
   pick_align_config(c, c->a_n, cap, scap, max_pts, &threads, &lds, &chi_lds_pts);
-  c->a_b.chi_lds_pts = chi_lds_pts; c->a_b.lds_img_bytes = 0;
-#if PLSVO_LDS_IMG   // experiment build (make lds_img): what is left of the workgroup's share of the CU's LDS may hold a level of the current image
-  {
-    const size_t wgs_per_cu = threads <= 64 ? 8 : threads <= 128 ? 4 : threads <= 256 ? 2 : 1;
-    const size_t share = std::min((size_t)(160 * 1024) / wgs_per_cu, c->lds_per_block);
-    size_t want = 0;   // the largest level image any job of the batch reads (+ 16 bytes for the aligned over-read)
-    if (have_levels) for (const AlignJobDev& J : c->a_jobs) want = std::max(want, (size_t)(J.width >> J.min_level) * (size_t)(J.height >> J.min_level) + 16);
-    size_t budget = share > lds + 256 ? share - lds - 256 : 0;
-    budget = std::min(budget, (want + 15) & ~(size_t)15) & ~(size_t)15;
-    c->a_b.lds_img_bytes = (int)budget;
-    lds += budget;
-  }
-#endif
+  c->a_b.chi_lds_pts = chi_lds_pts;
   if (lds > c->lds_per_block) return fail(c, PLSVO_E_CAPACITY, "align_run: slot tables do not fit in LDS (too many features in one job)");
   const bool per_level = c->env_align_per_level;
   if (!per_level || !have_levels) {

@@ -107,9 +107,7 @@ struct AlignBatchDev {
   // per-level patch cache (capacity = sum over jobs of patch_cap slots)
   double* patch_xyz;           // 3 per slot: 3-D point in the ref frame
   float* patch_uvref;          // 2 per slot: ref pixel position at the level (float, as Patch::setPosition)
-  float* cache_ref;            // 16 per slot: interpolated reference intensity
-  float* cache_dx;             // 16 per slot
-  float* cache_dy;             // 16 per slot
+  float* cache_ref;            // 64 bytes per slot: the reference patch's byte record (7 rows of 8 image bytes + the two sub-pixel fractions, align_refpatch.hpp)
   // per-pixel terms of the solver's chi2 for the POINT features, double-buffered by iteration parity (plane 0 / 1, chi_plane
   // floats apart): 16 per point of the batch, res*res*w (src/sparse_img_align.cpp:484).  Written by every iteration, read only when
   // two successive chi2 values are too close for the double-precision sums to order them the way the reference's sequential
@@ -117,8 +115,7 @@ struct AlignBatchDev {
   float* chi_terms;
   unsigned long long chi_plane;
   int chi_lds_pts;             // > 0: the two planes live in LDS instead (capacity in points per plane): small batches, where a
-  int lds_img_bytes;           //      workgroup has LDS to spare and nothing to hide a global store's acknowledge behind.  lds_img_bytes: LDS bytes behind the
-                               //      kernel's own tables that it may stage a level of the current image in (0 unless built with PLSVO_LDS_IMG)
+  int reserved_lds;            //      workgroup has LDS to spare and nothing to hide a global store's acknowledge behind
   double* poses;               // 7 per job: final model, contiguous (what a device-side consumer / the RCCL gather reads)
   PyrDesc pyr;
   plsvo_align_iterlog* log;    // log_cap per job, or null

@@ -15,7 +15,7 @@ coalesced stream on gfx950 and calls other access widths and WRITE_SIZE uncalibr
              correction (factor 1); only the wide share is doubled.
 Three figures are written per kernel: uncorrected (FETCH + WRITE), upper bound (2 x FETCH + WRITE: every fetch wide) and the
 estimate bench.py reports, c_fetch x FETCH + c_write x WRITE with c_fetch = w_wide x c_wide + (1 - w_wide) x 1, where w_wide is the
-wide share of the kernel's own requests (192 + 24 B of dense 16-B loads against 48 B of gathered dwords per patch-iteration)."""
+wide share of the kernel's own requests (64 + 24 B of dense loads against 40 B of gathered dwords per patch-iteration; rounds 1-3: 192 + 24 against 48)."""
 import csv, json, sys
 
 
@@ -50,7 +50,7 @@ if len(sys.argv) > 9:
     res["calibration"] = calib
 else:
     res["note"] += " No calibration pass given: FETCH_SIZE doubled (the guide's wide-read figure) for every fetch, WRITE_SIZE as is."
-w_wide = (192.0 + 24.0) / (192.0 + 24.0 + 48.0)     # request mix of align_fused_kernel per patch-iteration (bench.py OWN_BYTES_PER_PATCH_ITER)
+w_wide = (64.0 + 24.0) / (64.0 + 24.0 + 40.0)     # request mix of align_fused_kernel per patch-iteration (bench.py OWN_BYTES_PER_PATCH_ITER): 64-B record + 3-D point wide, 5 rows x 2 dwords gathered
 c_fetch = w_wide * c_wide + (1.0 - w_wide) * c_gather
 res["fetch_correction_used"] = c_fetch
 res["write_correction_used"] = c_write
