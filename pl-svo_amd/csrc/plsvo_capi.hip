@@ -137,8 +137,11 @@ struct plsvo_ctx {
 
   // staging: one blob per batch type (Blob), pinned bounce buffer for small ones
   DevBuf a_d_blob, p_d_blob;
-  void* pinned = nullptr;
-  size_t pinned_cap = 0;
+  // pinned bounce buffers of the stage calls: two, used in turn, each guarded by an event recorded behind its last DMA
+  void* pinned[2] = { nullptr, nullptr };
+  size_t pinned_cap[2] = { 0, 0 };
+  hipEvent_t pinned_done[2] = { nullptr, nullptr };
+  int pinned_next = 0;
 
   // profiling
   bool profiling = false;
@@ -243,7 +246,7 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
                      &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out, &c->ch_d_blob, &c->ch_d_work, &c->ch_d_po, &c->ch_d_state,
                      &c->ch_d_ptkeep, &c->ch_d_segkeep, &c->ch_d_s32, &c->ch_d_s64, &c->ch_d_poses, &c->rec_d };
   for (DevBuf* b : bufs) b->release();
-  if (c->pinned) (void)hipHostFree(c->pinned);
+  for (int k = 0; k < 2; ++k) { if (c->pinned[k]) (void)hipHostFree(c->pinned[k]); if (c->pinned_done[k]) (void)hipEventDestroy(c->pinned_done[k]); }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -460,19 +463,31 @@ static int upload_blob(plsvo_ctx* c, DevBuf& buf, const Blob& blob) {
   const size_t bytes = std::max(blob.host.size(), (size_t)256);
   HIP_TRY(c, buf.ensure(bytes));
   if (blob.host.empty()) return PLSVO_OK;
-  const void* src = blob.host.data();
+  // Small blobs (a frame, a few hundred frames) bounce through one of two pinned buffers: the DMA of a stage call is awaited only when
+  // ITS buffer comes up for reuse two stage calls later (an event recorded behind the copy), so a per-frame caller's stage -> run -> fetch
+  // makes ONE synchronisation, the fetch's.  (Round 3 waited for the stream inside every stage call.)
   if (blob.host.size() <= kPinnedMax) {
-    if (c->pinned_cap < blob.host.size()) {
-      if (c->pinned) (void)hipHostFree(c->pinned);
-      c->pinned = nullptr; c->pinned_cap = 0;
-      const size_t want = std::max(blob.host.size() * 2, (size_t)1 << 20);
-      if (hipHostMalloc(&c->pinned, want, hipHostMallocDefault) == hipSuccess) c->pinned_cap = want; else c->pinned = nullptr;
+    const int k = c->pinned_next;
+    if (!c->pinned_done[k] && hipEventCreate(&c->pinned_done[k]) != hipSuccess) c->pinned_done[k] = nullptr;
+    if (c->pinned_done[k]) {
+      HIP_TRY(c, hipEventSynchronize(c->pinned_done[k]));        // the copy that last read this buffer has landed (no-op when never recorded)
+      if (c->pinned_cap[k] < blob.host.size()) {
+        if (c->pinned[k]) (void)hipHostFree(c->pinned[k]);
+        c->pinned[k] = nullptr; c->pinned_cap[k] = 0;
+        const size_t want = std::max(blob.host.size() * 2, (size_t)1 << 20);
+        if (hipHostMalloc(&c->pinned[k], want, hipHostMallocDefault) == hipSuccess) c->pinned_cap[k] = want; else c->pinned[k] = nullptr;
+      }
+      if (c->pinned[k]) {
+        memcpy(c->pinned[k], blob.host.data(), blob.host.size());
+        HIP_TRY(c, hipMemcpyAsync(buf.p, c->pinned[k], blob.host.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipEventRecord(c->pinned_done[k], c->stream));
+        c->pinned_next = k ^ 1;
+        return PLSVO_OK;
+      }
     }
-    if (c->pinned) { memcpy(c->pinned, blob.host.data(), blob.host.size()); src = c->pinned; }
   }
-  HIP_TRY(c, hipMemcpyAsync(buf.p, src, blob.host.size(), hipMemcpyHostToDevice, c->stream));
-  // the source (the caller's Blob, or the ctx-wide pinned bounce buffer the next stage call writes into) must not be touched while
-  // the DMA is in flight, whatever early return follows: wait here (this is the one synchronisation a stage call makes)
+  // large blobs (or no pinned memory): straight from the caller's Blob, which must not be touched while the DMA is in flight -- wait here
+  HIP_TRY(c, hipMemcpyAsync(buf.p, blob.host.data(), blob.host.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return PLSVO_OK;
 }

@@ -1,5 +1,5 @@
 """One config-2 (or config-3) frame (seed given) at a given launch shape through whatever library PLSVO_HIP_LIB names -- the emulated one in the
-CPU suite, the gfx950 one on a GPU box (tools/ab_variants.sh) --; prints a JSON line:
+CPU suite, the gfx950 one on a GPU box (tools/r04_ab.sh) --; prints a JSON line:
 whether the device followed the oracle's Gauss-Newton path, the near-tie counters, the inter-frame pose error.  tests/test_emu_parity.py
 uses it on a seed whose near tie falls on an iteration whose per-pixel terms the default build does not keep.  usage: ... <seed> [threads per frame, default 64]"""
 import importlib
