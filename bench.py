@@ -59,7 +59,9 @@ CONFIGS = {
     2: dict(W=640, H=480, pts=200, seg=80, pyr=4, maxl=3, minl=1, batch=32768, pose_pts=200, pose_seg=80, metric=METRIC,
             workload="BASELINE configs[1]: 640x480, 200 points + 80 line segments, 4-image pyramid (levels 3..1), "
                      "sparse_img_align (<=30 GN it/level) + pose_optimizer (<=10 it, Tukey/MAD)"),
-    3: dict(W=1280, H=720, pts=400, seg=150, pyr=5, maxl=4, minl=2, batch=8192, pose_pts=400, pose_seg=150,
+    # (16384 streams: 64 per CU selects the one-wave-per-frame launch shape with the tiled pyramid mirror -- measured 1.10 M frames/s against
+    #  0.98 M at 8192 streams / two waves per frame; 80 GB of pyramids + mirror of the 288)
+    3: dict(W=1280, H=720, pts=400, seg=150, pyr=5, maxl=4, minl=2, batch=16384, pose_pts=400, pose_seg=150,
             metric="sparse-align+pose-opt frames/sec, 1280×720, 400 pts+150 lines (BASELINE configs[2])",
             workload="BASELINE configs[2]: 1280x720, 400 points + 150 line segments, 5-image pyramid (levels 4..2 = the reference's "
                      "defaults, src/config.cpp:98-99), sparse_img_align (<=30 GN it/level) + pose_optimizer (<=10 it, Tukey/MAD)"),

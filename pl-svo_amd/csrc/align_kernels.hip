@@ -145,27 +145,90 @@ typedef float plsvo_v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float chain4(float s, plsvo_v4f v) {   // four sequential float additions, never re-associated
   s = __fadd_rn(s, v.x); s = __fadd_rn(s, v.y); s = __fadd_rn(s, v.z); return __fadd_rn(s, v.w);
 }
-// Sequential float sum over `slots4` slots (a multiple of 4; 16 floats each, slots beyond the last point hold +0) starting at w: four
-// register sets, each reloaded with the slot four ahead as soon as it has been added, so that a slot's LDS reads have 48 dependent
-// additions to complete under and nothing is copied between registers.  (The first version rotated two sets through v_mov and
-// waited for every read right after issuing it: 260 cycles per slot, 21 us per near tie for a frame alone on a CU.)
-__device__ __forceinline__ float chain_slots4(float sum, const PLSVO_LDS plsvo_v4f* w, int slots4) {
-  plsvo_v4f r[4][4];
+// One round of the SLOT-PARALLEL form of that sequential sum (tests/test_exact_sum_model.py::half_wave_sum is its CPU statement and the
+// evidence that it is bit-exact): the 32 lanes of a half-wave hold one slot each (t[0..15], in summation order; lanes without a slot
+// hold +0), s is the true running float sum in front of the round (uniform in the half), base the plain double sum of everything before.
+// While the running sum stays inside one binade every addition rounds ITS TERM to the binade's quantum (s' = s + RN_ulp(t): the rounded
+// terms add exactly, in any order) unless the term sits exactly half a quantum from a multiple (round-to-even looks at the running
+// parity) or the sum crosses into the next binade.  So each lane, from the binade its double prefix predicts, rounds its sixteen terms
+// and adds them (delta); an exclusive scan of delta gives every lane its candidate start value; the first lane whose prediction does
+// not hold (wrong binade, crossing, half quantum: ~6 % of the slots) re-adds its own sixteen terms one after the other from the exact
+// value in front of it, and the lanes behind it are checked again from there.  ~200 dependent additions are left of 3300.
+// (Rounds 3 walked the terms on ONE lane: 8.8 us per near tie for a lone frame; measured on MI355X: -2 ... -3 % per small-batch step.)
+// 32-lane inclusive prefix sum inside each half-wave without touching LDS: four row_shr steps inside the 16-lane DPP rows, then the
+// last lane of rows 0 / 2 is added to rows 1 / 3 (row_bcast15, row mask 0xA).  Lanes a shift has no source for receive 0.
+__device__ __forceinline__ double half_scan_incl(double v) {
+  v += dpp_bcast_f64<DPP_ROW_SHR(1), 0xF>(v);
+  v += dpp_bcast_f64<DPP_ROW_SHR(2), 0xF>(v);
+  v += dpp_bcast_f64<DPP_ROW_SHR(4), 0xF>(v);
+  v += dpp_bcast_f64<DPP_ROW_SHR(8), 0xF>(v);
+  v += dpp_bcast_f64<DPP_ROW_BCAST15, 0xA>(v);
+  return v;
+}
+// value of lane `la` (half 0) / `32 + lb` (half 1), each half-wave its own; la, lb wave-uniform
+__device__ __forceinline__ double half_readlane(double v, int la, int lb) {
+  const double a = readlane_f64(v, la), b = readlane_f64(v, 32 + lb);
+  return (threadIdx.x & 32) ? b : a;
+}
+__device__ __forceinline__ float half_readlane(float v, int la, int lb) {
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), la)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32 + lb));
+  return (threadIdx.x & 32) ? b : a;
+}
+
+__device__ __forceinline__ void exact_round32(const float (&t)[16], float& s, double& base) {
+  const int lane = threadIdx.x & 63, l32 = lane & 31;
+  double d = 0.0;
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int i = 0; i < 16; ++i) d += (double)t[i];
+  const double inc = half_scan_incl(d);
+  const double excl = inc - d;                               // a predictor only: its last bit does not matter
+  const double tot = half_readlane(inc, 31, 31);
+  const double lo = base + excl, hi = lo + d;
+  int e = (int)((__double2hiint(lo) >> 20) & 0x7ff) - 1023;
+  bool safe = lo > 0.0 && hi < 1.7976931348623157e308 && e - 24 >= -126 && e <= 126;
+  e = min(max(e, -100), 126);
+  const double two_e = __hiloint2double((e + 1023) << 20, 0), two_e1 = __hiloint2double((e + 1024) << 20, 0);
+  safe = safe && lo * (1.0 - 0.0009765625) >= two_e && hi * (1.0 + 0.0009765625) < two_e1;
+  const float C = __int_as_float((e + 127) << 23), half_q = __int_as_float((e - 24 + 127) << 23);
+  double delta = 0.0;
+  bool half_hit = false;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[u][q] = w[4 * u + q];
-  const int last = slots4 - 4;
-  for (int g = 0; g < slots4; g += 4) {
-    const PLSVO_LDS plsvo_v4f* nx = w + 4 * (g + 4 <= last ? g + 4 : last);   // the last group is read twice rather than branching
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      sum = chain4(sum, r[u][0]); sum = chain4(sum, r[u][1]); sum = chain4(sum, r[u][2]); sum = chain4(sum, r[u][3]);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) r[u][q] = nx[4 * u + q];
-    }
+  for (int i = 0; i < 16; ++i) {
+    const float r = __fsub_rn(__fadd_rn(C, t[i]), C);
+    half_hit = half_hit || fabsf(__fsub_rn(t[i], r)) == half_q;
+    delta += (double)r;
   }
-  return sum;
+  safe = safe && !half_hit;
+  if (!safe) delta = 0.0;
+  const double dinc = half_scan_incl(delta);
+  const double dex = dinc - delta;                           // exact: every value is a multiple of the smallest quantum of the round, < 2^53 of them
+  const double dlast = half_readlane(dinc, 31, 31);
+  int start = 0;
+  double s0 = (double)s, off = 0.0;
+  bool done = false;
+  for (;;) {
+    const double sl = s0 + (dex - off);
+    bool ok = safe && sl > 0.0 && two_e <= sl && sl + delta < two_e1;
+    if (l32 < start || done) ok = true;
+    const unsigned long long m = __ballot(!ok);              // scalar: the first failing lane of each half is a scalar too
+    const unsigned ba = (unsigned)m, bb = (unsigned)(m >> 32);
+    const int fa = ba ? __builtin_ctz(ba) : 32, fb = bb ? __builtin_ctz(bb) : 32;
+    const int f = (lane & 32) ? fb : fa;
+    const double dex_f = half_readlane(dex, fa & 31, fb & 31), delta_f = half_readlane(delta, fa & 31, fb & 31);
+    float sf = (float)(s0 + (dex_f - off));
+    if (!done && l32 == f) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sf = __fadd_rn(sf, t[i]);
+    }
+    sf = half_readlane(sf, fa & 31, fb & 31);
+    if (!done) {
+      if (f == 32) { s0 = s0 + (dlast - off); done = true; }
+      else { s0 = (double)sf; start = f + 1; off = dex_f + delta_f; if (start == 32) done = true; }
+    }
+    if (!__any(!done)) break;
+  }
+  s = (float)s0;
+  base += tot;
 }
 
 __device__ __noinline__ void exact_chi2_pair(const PLSVO_GLOBAL float* bufA, const PLSVO_GLOBAL float* bufB, int n_pts, int n_seg, int iter,
@@ -183,7 +246,8 @@ __device__ __noinline__ void exact_chi2_pair(const PLSVO_GLOBAL float* bufA, con
       v[2 + h] = ok ? reinterpret_cast<const PLSVO_GLOBAL plsvo_v4f*>(bufB + f0)[q] : z4;
     }
   };
-  float sum = 0.0f;   // lane 0: plane A, lane 1: plane B
+  float sum = 0.0f;   // lanes 0..31: plane A, lanes 32..63: plane B
+  double base = 0.0;
   const int n_rounds = (n_pts + 31) >> 5;
   plsvo_v4f nxt[4] = { z4, z4, z4, z4 };
   if (n_rounds > 0) load_win(0, nxt);
@@ -194,18 +258,23 @@ __device__ __noinline__ void exact_chi2_pair(const PLSVO_GLOBAL float* bufA, con
     PLSVO_LDS plsvo_v4f* const w4 = reinterpret_cast<PLSVO_LDS plsvo_v4f*>(s_win);
     w4[lane] = c0; w4[lane + 64] = c1; w4[128 + lane] = c2; w4[128 + lane + 64] = c3;
     wave_lds_fence();
-    const int cnt4 = (min(32, n_pts - 32 * r) + 3) & ~3;   // the window holds +0 beyond the last point
-    if (lane < 2) sum = chain_slots4(sum, w4 + 128 * lane, cnt4);
+    {   // lanes 0..31: the window's slots of plane A, lanes 32..63: of plane B (the window holds +0 beyond the last point)
+      const PLSVO_LDS plsvo_v4f* w = w4 + 128 * (lane >> 5) + 4 * (lane & 31);
+      const plsvo_v4f q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
+      const float t[16] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
+      exact_round32(t, sum, base);
+    }
   }
-  if (lane < 2) {
+  if ((lane & 31) == 0) {
+    const int h = lane >> 5;                                             // 0: this iteration (plane A), 1: the previous one (plane B)
     float seg_sum = 0.0f;                                                // :683, segments in feature order
     for (int sg = 0; sg < n_seg; ++sg) {
       const int dead = s_dead[sg];
-      const float t = s_lterm[((iter - lane) & 1) * scap + sg];
-      // the line took part in iteration j (= iter for lane 0, iter - 1 for lane 1) unless it was culled at an iteration <= j
-      seg_sum = __fadd_rn(seg_sum, (dead == 0 || dead > iter - lane + 1) ? t : 0.0f);
+      const float t = s_lterm[((iter - h) & 1) * scap + sg];
+      // the line took part in iteration j (= iter - h) unless it was culled at an iteration <= j
+      seg_sum = __fadd_rn(seg_sum, (dead == 0 || dead > iter - h + 1) ? t : 0.0f);
     }
-    s_out[lane] = __fadd_rn(sum, seg_sum);                               // :171  chi2 = pt_chi2 + seg_chi2
+    s_out[h] = __fadd_rn(sum, seg_sum);                                  // :171  chi2 = pt_chi2 + seg_chi2
   }
   wave_lds_fence();
 }
@@ -213,18 +282,26 @@ __device__ __noinline__ void exact_chi2_pair(const PLSVO_GLOBAL float* bufA, con
 // the same with the two planes in LDS (small batches): no staging, lane 0 / lane 1 walk plane A / B directly
 __device__ __noinline__ void exact_chi2_pair_lds(const PLSVO_LDS float* planeA, const PLSVO_LDS float* planeB, int n_pts, int n_seg, int iter,
                                                  const PLSVO_LDS int* s_dead, const PLSVO_LDS float* s_lterm, int scap, PLSVO_LDS float* s_out) {
-  const int lane = threadIdx.x & 63;
-  if (lane < 2) {
-    const PLSVO_LDS plsvo_v4f* w = reinterpret_cast<const PLSVO_LDS plsvo_v4f*>(lane ? planeB : planeA);
-    float sum = 0.0f;
-    if (n_pts > 0) sum = chain_slots4(sum, w, (n_pts + 3) & ~3);   // the planes hold +0 between the last point and the next multiple of 4
+  const int lane = threadIdx.x & 63, h = lane >> 5, l32 = lane & 31;
+  const PLSVO_LDS plsvo_v4f* plane = reinterpret_cast<const PLSVO_LDS plsvo_v4f*>(h ? planeB : planeA);
+  float sum = 0.0f;
+  double base = 0.0;
+  for (int p0 = 0; p0 < n_pts; p0 += 32) {
+    const int p = p0 + l32;
+    const plsvo_v4f z4 = { 0.f, 0.f, 0.f, 0.f };
+    plsvo_v4f q0 = z4, q1 = z4, q2 = z4, q3 = z4;
+    if (p < n_pts) { q0 = plane[4 * p]; q1 = plane[4 * p + 1]; q2 = plane[4 * p + 2]; q3 = plane[4 * p + 3]; }
+    const float t[16] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
+    exact_round32(t, sum, base);
+  }
+  if (l32 == 0) {
     float seg_sum = 0.0f;
     for (int sg = 0; sg < n_seg; ++sg) {
       const int dead = s_dead[sg];
-      const float t = s_lterm[((iter - lane) & 1) * scap + sg];
-      seg_sum = __fadd_rn(seg_sum, (dead == 0 || dead > iter - lane + 1) ? t : 0.0f);
+      const float t = s_lterm[((iter - h) & 1) * scap + sg];
+      seg_sum = __fadd_rn(seg_sum, (dead == 0 || dead > iter - h + 1) ? t : 0.0f);
     }
-    s_out[lane] = __fadd_rn(sum, seg_sum);
+    s_out[h] = __fadd_rn(sum, seg_sum);
   }
   wave_lds_fence();
 }

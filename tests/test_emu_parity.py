@@ -11,8 +11,6 @@ run on the MI355X stays the parity gate.  The emulated library is test infrastru
 marker `plsvo_emu_build`, and bench.py / smoke() refuse it unless asked for a DRY RUN -- which this module also does: the round's two
 driver-run scripts are executed end to end here (bench.py: configs 2, 5, 4, and under torchrun with two ranks), labelled as such."""
 import os
-import pickle
-import shutil
 import subprocess
 import sys
 
@@ -163,38 +161,3 @@ def test_near_ties_on_unarmed_iterations_follow_the_oracle(emu_lib):
         var = run(emu_lib, *args)
         assert var["same_path"] and var["near_ties_without_terms"] == 0 and var["decided_on_exact_sums"] >= 2, var
         assert var["inter_trans_rel"] < 1e-7 and var["inter_rot_rad"] < 1e-9 and var["iters_device"] == var["iters_oracle"], var
-
-
-def run_variant(lib, out_pkl):
-    env = emu_env(lib)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host", "emu_variant_runner.py"), str(out_pkl)], env=env, capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    return pickle.load(open(out_pkl, "rb"))
-
-
-def patched_sources(tmp_path, patch_name):
-    if shutil.which("patch") is None:
-        pytest.skip("patch(1) not available")
-    w = tmp_path / "src"
-    (w / "pl-svo_amd").mkdir(parents=True)
-    (w / "include").mkdir()
-    shutil.copytree(os.path.join(ROOT, "pl-svo_amd", "csrc"), w / "pl-svo_amd" / "csrc", ignore=shutil.ignore_patterns("*.o"))
-    shutil.copy(os.path.join(ROOT, "include", "plsvo_hip.h"), w / "include")
-    with open(os.path.join(ROOT, "tools", "patches", patch_name)) as f:
-        subprocess.run(["patch", "-p1", "-s"], stdin=f, cwd=str(w), check=True)
-    return w / "pl-svo_amd" / "csrc"
-
-
-@pytest.mark.parametrize("variant", ["dpp_exact_sum"])
-def test_kernel_variants_are_bitwise_the_default_build(emu_lib, tmp_path, variant):
-    """A variant of align_fused_kernel that exists for speed only and is not in the tree -- the DPP form of the slot-parallel near-tie sums
-    (tools/patches/: measured -2.5 % for a lone frame on MI355X) -- must return, bit for bit, what the default build returns: poses, counts,
-    culled segments, every iteration's chi2 and step, the number of near ties resolved; at 64 and 256 threads per frame.  (Round 4's other
-    A/B builds were decided on the MI355X: the byte-record cache is the build, the staged level and the gather a round ahead are gone.)"""
-    base = run_variant(emu_lib, tmp_path / "base.pkl")
-    lib = build_emu(tmp_path / "emu_variant", patched_sources(tmp_path, "slot_parallel_exact_sum_dpp.patch"))
-    var = run_variant(lib, tmp_path / "variant.pkl")
-    assert base.keys() == var.keys()
-    for k in base:
-        assert base[k] == var[k], k
-    assert any(v[5][1] > 0 for v in base.values())      # the cases do contain near ties decided on the exact float sums
