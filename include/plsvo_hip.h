@@ -445,12 +445,20 @@ typedef struct plsvo_chain_params {
   int32_t cell_size;                /* Config::gridSize(): the reprojection grid of the points (reprojector.cpp:57-66) */
   int32_t cell_rule;                /* 0: every matched candidate becomes a feature; 1: the reference's rule -- per cell the first
                                        candidate that matches, cells in cell_order, stop after the match that makes the count exceed
-                                       max_fts (reprojector.cpp:188-199, :222-243).  Points only: every segment whose two end points
-                                       match becomes a feature (the reference files a segment under both end-point cells, :405-421) */
+                                       max_fts (reprojector.cpp:188-199, :222-243).  Segments follow their own grid when seg_cell_size > 0
+                                       (below); with seg_cell_size == 0 every segment whose two end points match becomes a feature */
   int32_t max_fts;                  /* Config::maxFts() */
   int32_t poseopt_n_iter;           /* 10 (src/config.cpp:103) */
   const int32_t* cell_order;        /* grid_n_cols * grid_n_rows cell indices (Grid::cell_order, shuffled once, :63-66); NULL = 0,1,2,.. */
   double reproj_thresh;             /* 2.0 (src/config.cpp:102) */
+  /* the segments' grid, gridls_ (reprojector.cpp:68-79, :200-207, :256-275, :405-421), used when cell_rule != 0 and seg_cell_size > 0:
+   * a segment is filed under the cell of its projected start point AND under the cell of its projected end point; cells are visited
+   * in seg_cell_order, per cell the first segment (caller's order = quality order) whose findMatchDirect succeeded becomes a feature,
+   * and the visit stops after the match that makes the count exceed max_fts_segs.  A segment that wins both of its cells becomes a
+   * feature TWICE, as in the reference (refine() adds a LineFeat per success): sel_seg / seg_keep hold up to 2 * n_cand_seg entries. */
+  int32_t seg_cell_size;            /* Config::gridSizeSegs(); 0 = no segment grid */
+  int32_t max_fts_segs;             /* Config::maxFtsSegs() (100, src/config.cpp:76) */
+  const int32_t* seg_cell_order;    /* ceil(width / seg_cell_size) * ceil(height / seg_cell_size) cell indices; NULL = 0,1,2,.. */
 } plsvo_chain_params;
 
 typedef struct plsvo_chain_out {
@@ -462,7 +470,7 @@ typedef struct plsvo_chain_out {
   double* px;                       /* 2 per candidate: refined pixel (the projection for candidates left out / not found) */
   int32_t* search_level;            /* per candidate */
   int32_t* sel_pt;                  /* n_cand_pt: candidate index of selected point feature k, k < n_sel_pt */
-  int32_t* sel_seg;                 /* n_cand_seg: segment index of selected segment feature k, k < n_sel_seg */
+  int32_t* sel_seg;                 /* n_cand_seg (2 * n_cand_seg with a segment grid): segment index of selected segment feature k, k < n_sel_seg */
 } plsvo_chain_out;
 
 int plsvo_chain_stage(plsvo_ctx* ctx, int n, const plsvo_chain_in* in, const plsvo_chain_params* params);

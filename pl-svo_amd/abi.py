@@ -114,7 +114,7 @@ class ChainIn(C.Structure):
 class ChainParams(C.Structure):
     _fields_ = [("cam", Pinhole), ("n_pyr_levels", C.c_int32), ("align_max_iter", C.c_int32), ("cell_size", C.c_int32),
                 ("cell_rule", C.c_int32), ("max_fts", C.c_int32), ("poseopt_n_iter", C.c_int32), ("cell_order", c_i32_p),
-                ("reproj_thresh", C.c_double)]
+                ("reproj_thresh", C.c_double), ("seg_cell_size", C.c_int32), ("max_fts_segs", C.c_int32), ("seg_cell_order", c_i32_p)]
 
 
 class ChainOut(C.Structure):

@@ -344,7 +344,7 @@ class Context:
 
     # ---- resident frame step ----
     def chain_stage(self, jobs, cam, n_pyr_levels=3, align_max_iter=10, cell_size=30, cell_rule=False, max_fts=120, cell_order=None,
-                    reproj_thresh=2.0, poseopt_n_iter=10):
+                    reproj_thresh=2.0, poseopt_n_iter=10, seg_cell_size=0, max_fts_segs=100, seg_cell_order=None):
         n = len(jobs)
         arr = (abi.ChainIn * n)(*[j.c for j in jobs])
         pr = abi.ChainParams()
@@ -353,6 +353,11 @@ class Context:
         pr.max_fts, pr.poseopt_n_iter, pr.reproj_thresh = int(max_fts), int(poseopt_n_iter), float(reproj_thresh)
         self._chain_order = None if cell_order is None else np.ascontiguousarray(cell_order, dtype=np.int32)
         pr.cell_order = C.cast(None, abi.c_i32_p) if self._chain_order is None else self._chain_order.ctypes.data_as(abi.c_i32_p)
+        # the segments' grid (gridls_): a segment filed under both end-point cells, one success per cell, max_fts_segs
+        pr.seg_cell_size, pr.max_fts_segs = int(seg_cell_size), int(max_fts_segs)
+        self._chain_seg_order = None if seg_cell_order is None else np.ascontiguousarray(seg_cell_order, dtype=np.int32)
+        pr.seg_cell_order = C.cast(None, abi.c_i32_p) if self._chain_seg_order is None else self._chain_seg_order.ctypes.data_as(abi.c_i32_p)
+        self._chain_seg_mult = 2 if (cell_rule and seg_cell_size > 0) else 1     # a segment that wins both of its cells is a feature twice
         self._chk(self.L.plsvo_chain_stage(self.h, n, arr, C.byref(pr)))
         self._chain_jobs = list(jobs)
         self._align_jobs = [j.align_job for j in jobs]
@@ -366,9 +371,9 @@ class Context:
         outs = (abi.ChainOut * n)()
         bufs = []
         for o, j in zip(outs, jobs):
-            b = dict(alive=np.ones(max(j.align_job.n_seg, 1), np.uint8), pk=np.zeros(max(j.n_cand_pt, 1), np.uint8), sk=np.zeros(max(j.n_cand_seg, 1), np.uint8),
+            b = dict(alive=np.ones(max(j.align_job.n_seg, 1), np.uint8), pk=np.zeros(max(j.n_cand_pt, 1), np.uint8), sk=np.zeros(max(self._chain_seg_mult * j.n_cand_seg, 1), np.uint8),
                      found=np.zeros(max(j.n_cand, 1), np.uint8), px=np.zeros((max(j.n_cand, 1), 2)), level=np.zeros(max(j.n_cand, 1), np.int32),
-                     sel_pt=np.zeros(max(j.n_cand_pt, 1), np.int32), sel_seg=np.zeros(max(j.n_cand_seg, 1), np.int32))
+                     sel_pt=np.zeros(max(j.n_cand_pt, 1), np.int32), sel_seg=np.zeros(max(self._chain_seg_mult * j.n_cand_seg, 1), np.int32))
             o.align.seg_alive_out = b["alive"].ctypes.data_as(abi.c_u8_p)
             o.pose.pt_keep = b["pk"].ctypes.data_as(abi.c_u8_p)
             o.pose.seg_keep = b["sk"].ctypes.data_as(abi.c_u8_p)

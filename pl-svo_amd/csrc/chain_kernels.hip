@@ -13,7 +13,9 @@
 //                         candidate (caller's order = its quality order) that matched, cells visited in the caller's (random) order until
 //                         more than max_fts have matched (src/reprojector.cpp:188-199, refineBestCandidate :222-243).  Matching every
 //                         candidate and selecting afterwards equals the reference's early exits because a match has no side effect on
-//                         other matches.  Then the selected features are written as pose-optimiser input, in selection order.
+//                         other matches.  Segments follow their own grid (gridls_: a segment filed under both end-point cells, :405-421,
+//                         max_fts_segs, its own cell order) when the caller gives one.  Then the selected features are written as
+//                         pose-optimiser input, in selection order.
 #include <hip/hip_runtime.h>
 
 #include "../../include/plsvo_hip.h"
@@ -95,7 +97,7 @@ __device__ __forceinline__ int wave_compact(int n, int limit, Flag flag, Emit em
 }
 
 __global__ void __launch_bounds__(256) chain_select_kernel(const ChainBatchDev b) {
-  extern __shared__ int s_winner[];   // n_cells (cell rule only)
+  extern __shared__ int s_winner[];   // n_cells (cell rule only), then seg_n_cells (segment grid only)
   __shared__ int s_n[2];
   const int j = blockIdx.x, tid = threadIdx.x;
   const ChainJobDev J = b.jobs[j];
@@ -111,6 +113,24 @@ __global__ void __launch_bounds__(256) chain_select_kernel(const ChainBatchDev b
       if (matched(k)) atomicMin(&s_winner[b.cell[c0 + k]], k);        // first candidate of the cell, in the caller's order, that matched
     __syncthreads();
   }
+  // the segments' own grid (gridls_, src/reprojector.cpp:405-421): a segment is filed under the cell of its projected start point and under
+  // the cell of its projected end point; per cell the first segment, in the caller's order, whose findMatchDirect succeeded
+  const bool seg_grid = b.cell_rule && b.seg_n_cells > 0;
+  int* const s_wseg = s_winner + (b.cell_rule ? b.n_cells : 0);
+  if (seg_grid) {
+    for (int c = tid; c < b.seg_n_cells; c += 256) s_wseg[c] = 0x7fffffff;
+    __syncthreads();
+    for (int s = tid; s < J.n_seg; s += 256) {
+      const int cs = c0 + J.n_pt + s, ce = cs + J.n_seg;
+      if (matched(J.n_pt + s) && matched(J.n_pt + J.n_seg + s)) {
+        const int sk = (int)(b.proj_px[2 * cs + 1] / b.seg_cell_size) * b.seg_n_cols + (int)(b.proj_px[2 * cs] / b.seg_cell_size);
+        const int ek = (int)(b.proj_px[2 * ce + 1] / b.seg_cell_size) * b.seg_n_cols + (int)(b.proj_px[2 * ce] / b.seg_cell_size);
+        atomicMin(&s_wseg[sk], s);
+        atomicMin(&s_wseg[ek], s);
+      }
+    }
+    __syncthreads();
+  }
   if (tid < 64) {
     int n_pt_sel;
     if (b.cell_rule)    // cells in visit order; the reference stops AFTER the match that makes n_matches_ exceed max_fts
@@ -119,8 +139,15 @@ __global__ void __launch_bounds__(256) chain_select_kernel(const ChainBatchDev b
                               [&](int r, int rank) { sel_pt[rank] = s_winner[b.cell_order ? b.cell_order[r] : r]; });
     else
       n_pt_sel = wave_compact(J.n_pt, -1, matched, [&](int k, int rank) { sel_pt[rank] = k; });
-    const int n_seg_sel = wave_compact(J.n_seg, -1, [&](int s) { return matched(J.n_pt + s) && matched(J.n_pt + J.n_seg + s); },
-                                       [&](int s, int rank) { sel_seg[rank] = s; });
+    int n_seg_sel;
+    if (seg_grid)       // cells in visit order, stop AFTER the match that makes n_ls_matches_ exceed max_fts_segs (:200-207); a segment that
+                        // wins both of its cells is emitted twice (refine() adds a LineFeat per success, :361-363)
+      n_seg_sel = wave_compact(b.seg_n_cells, b.max_fts_segs + 1,
+                               [&](int r) { return s_wseg[b.seg_cell_order ? b.seg_cell_order[r] : r] != 0x7fffffff; },
+                               [&](int r, int rank) { sel_seg[rank] = s_wseg[b.seg_cell_order ? b.seg_cell_order[r] : r]; });
+    else
+      n_seg_sel = wave_compact(J.n_seg, -1, [&](int s) { return matched(J.n_pt + s) && matched(J.n_pt + J.n_seg + s); },
+                               [&](int s, int rank) { sel_seg[rank] = s; });
     if (tid == 0) { s_n[0] = n_pt_sel; s_n[1] = n_seg_sel; }
   }
   __syncthreads();
@@ -170,7 +197,7 @@ hipError_t launch_chain_active(const ChainBatchDev& b, hipStream_t stream) {
 }
 hipError_t launch_chain_select(const ChainBatchDev& b, hipStream_t stream) {
   if (b.n_jobs <= 0) return hipSuccess;
-  const size_t lds = b.cell_rule ? (size_t)b.n_cells * sizeof(int) : 0;
+  const size_t lds = b.cell_rule ? ((size_t)b.n_cells + (size_t)b.seg_n_cells) * sizeof(int) : 0;
   hipLaunchKernelGGL(chain_select_kernel, dim3(b.n_jobs), dim3(256), lds, stream, b);
   return hipGetLastError();
 }

@@ -1201,12 +1201,18 @@ extern "C" int plsvo_chain_stage(plsvo_ctx* c, int n, const plsvo_chain_in* in, 
   int rc = plsvo_align_stage(c, n, ain.data()); if (rc) return rc;
   const int grid_n_cols = (pr->cam.width + pr->cell_size - 1) / pr->cell_size, grid_n_rows = (pr->cam.height + pr->cell_size - 1) / pr->cell_size;
   const int n_cells = grid_n_cols * grid_n_rows;
-  if (pr->cell_rule && (size_t)n_cells * sizeof(int) > 60000) return fail(c, PLSVO_E_CAPACITY, "chain_stage: reprojection grid too fine for the selection kernel");
+  const bool seg_grid = pr->cell_rule && pr->seg_cell_size > 0;
+  if (pr->seg_cell_size < 0 || (seg_grid && pr->max_fts_segs < 0)) return fail(c, PLSVO_E_INVALID, "chain_stage: bad segment-grid parameters");
+  const int seg_n_cols = seg_grid ? (pr->cam.width + pr->seg_cell_size - 1) / pr->seg_cell_size : 0;
+  const int seg_n_cells = seg_grid ? seg_n_cols * ((pr->cam.height + pr->seg_cell_size - 1) / pr->seg_cell_size) : 0;
+  if (pr->cell_rule && ((size_t)n_cells + (size_t)seg_n_cells) * sizeof(int) > 60000) return fail(c, PLSVO_E_CAPACITY, "chain_stage: reprojection grid too fine for the selection kernel");
+  if (seg_grid && pr->seg_cell_order)
+    for (int k = 0; k < seg_n_cells; ++k) if (pr->seg_cell_order[k] < 0 || pr->seg_cell_order[k] >= seg_n_cells) return fail(c, PLSVO_E_INVALID, "chain_stage: seg_cell_order entry out of range");
   if (pr->cell_rule && pr->cell_order)
     for (int k = 0; k < n_cells; ++k) if (pr->cell_order[k] < 0 || pr->cell_order[k] >= n_cells) return fail(c, PLSVO_E_INVALID, "chain_stage: cell_order entry out of range");
   std::vector<ChainJobDev> jobs((size_t)n);
   std::vector<double> pos, rpx, rf, rgrad;
-  std::vector<int> rlevel, cand_job, frame_cur, frame_ref, order;
+  std::vector<int> rlevel, cand_job, frame_cur, frame_ref, order, seg_order;
   std::vector<uint8_t> rtype, active;
   bool any_active = false, any_edgelet = false;
   int npt_total = 0, nseg_total = 0;
@@ -1221,7 +1227,7 @@ extern "C" int plsvo_chain_stage(plsvo_ctx* c, int n, const plsvo_chain_in* in, 
     J.kf_slot = a.kf_slot; J.cur_slot = a.align.cur_slot;
     J.cand_off = (int)cand_job.size(); J.n_pt = a.n_cand_pt; J.n_seg = a.n_cand_seg;
     J.po_pt_off = npt_total; J.po_seg_off = nseg_total; J.reserved0 = 0;
-    npt_total += a.n_cand_pt; nseg_total += a.n_cand_seg;
+    npt_total += a.n_cand_pt; nseg_total += (seg_grid ? 2 : 1) * a.n_cand_seg;   // (a segment that wins both of its cells is a feature twice)
     pos.insert(pos.end(), a.pos, a.pos + 3 * (size_t)nc);
     rpx.insert(rpx.end(), a.ref_px, a.ref_px + 2 * (size_t)nc);
     rf.insert(rf.end(), a.ref_f, a.ref_f + 3 * (size_t)nc);
@@ -1242,10 +1248,11 @@ extern "C" int plsvo_chain_stage(plsvo_ctx* c, int n, const plsvo_chain_in* in, 
   (void)any_edgelet;
   const size_t NC = cand_job.size();
   if (pr->cell_rule) { order.resize((size_t)n_cells); for (int k = 0; k < n_cells; ++k) order[(size_t)k] = pr->cell_order ? pr->cell_order[k] : k; }
+  if (seg_grid) { seg_order.resize((size_t)seg_n_cells); for (int k = 0; k < seg_n_cells; ++k) seg_order[(size_t)k] = pr->seg_cell_order ? pr->seg_cell_order[k] : k; }
   Blob blob;
   const size_t o_jobs = blob.add(jobs), o_pos = blob.add(pos), o_rpx = blob.add(rpx), o_rf = blob.add(rf), o_rgrad = blob.add(rgrad), o_rlevel = blob.add(rlevel),
                o_cjob = blob.add(cand_job), o_fcur = blob.add(frame_cur), o_fref = blob.add(frame_ref), o_rtype = blob.add(rtype), o_active = blob.add(active),
-               o_order = blob.add(order);
+               o_order = blob.add(order), o_sorder = blob.add(seg_order);
   if ((rc = upload_blob(c, c->ch_d_blob, blob))) return rc;
   // work arrays
   Carver w;
@@ -1280,6 +1287,9 @@ extern "C" int plsvo_chain_stage(plsvo_ctx* c, int n, const plsvo_chain_in* in, 
   b.fx = pr->cam.fx; b.fy = pr->cam.fy; b.cx = pr->cam.cx; b.cy = pr->cam.cy;
   b.n_cells = n_cells; b.cell_rule = pr->cell_rule ? 1 : 0; b.max_fts = pr->max_fts;
   b.cell_order = pr->cell_rule ? reinterpret_cast<const int*>(B + o_order) : nullptr;
+  b.proj_px = reinterpret_cast<const double*>(Wk + w_px);
+  b.seg_cell_size = seg_grid ? pr->seg_cell_size : 0; b.seg_n_cols = seg_n_cols; b.seg_n_cells = seg_n_cells; b.max_fts_segs = pr->max_fts_segs;
+  b.seg_cell_order = seg_grid ? reinterpret_cast<const int*>(B + o_sorder) : nullptr;
   b.po_jobs = reinterpret_cast<PoseJobDev*>(Po + p_jobs);
   b.pt_f = reinterpret_cast<double*>(Po + p_ptf); b.pt_pos = reinterpret_cast<double*>(Po + p_ptpos); b.pt_level = reinterpret_cast<int*>(Po + p_ptlev);
   b.seg_line = reinterpret_cast<double*>(Po + p_line); b.seg_spos = reinterpret_cast<double*>(Po + p_spos); b.seg_epos = reinterpret_cast<double*>(Po + p_epos);

@@ -220,6 +220,9 @@ struct ChainBatchDev {
   const double* m_px; const uint8_t* found; const int* search_level; // matcher result
   double fx, fy, cx, cy;
   int n_cells, cell_rule, max_fts; const int* cell_order;
+  // the segments' grid (gridls_): 0 cells = every matched segment becomes a feature
+  const double* proj_px;            // 2 per candidate: the projection the reprojection kernel wrote (what files a segment in its cells)
+  int seg_cell_size, seg_n_cols, seg_n_cells, max_fts_segs; const int* seg_cell_order;
   PoseJobDev* po_jobs; double* pt_f; double* pt_pos; int* pt_level; double* seg_line; double* seg_spos; double* seg_epos; int* seg_level;
   int* sel_pt; int* sel_seg; int* n_sel;
   double reproj_thresh; int po_n_iter, ldlt_flavour;

@@ -180,3 +180,61 @@ def test_resident_chain_applies_the_reprojection_grid_rule(P, ob, gpu_ctx, seqm)
         assert list(r.sel_pt) == expect, (s, list(r.sel_pt)[:10], expect[:10])
         assert len(expect) == max_fts + 1                                              # the scene is dense enough to hit the limit
         assert r.pose.pt_keep.shape[0] == len(expect) and Hh.pose_close(r.pose.T, f.pose.T, rot_tol=2e-3, trans_tol=2e-2)[2]
+
+
+@pytest.mark.gpu
+def test_resident_chain_applies_the_segment_grid_rule(P, ob, gpu_ctx, seqm):
+    """The segments' own grid, gridls_ (src/reprojector.cpp:68-79, :200-207, :256-275, :405-421): a segment is filed under the cell of its
+    projected start point AND under the cell of its projected end point; cells are visited in gridls_.cell_order, per cell the first
+    segment (caller's order) whose findMatchDirect succeeded becomes a feature -- a segment that wins both of its cells becomes one TWICE,
+    as in the reference, where refine() adds a LineFeat per success -- and the visit stops after the match that makes the count exceed
+    max_fts_segs.  Checked against a NumPy statement of the rule applied to the device's own match results."""
+    abi, synth = P.abi, P.synth
+    seq = seqm.make_sequence(21, n_frames=2, W=320, H=240, n_pts=60, n_seg=40)
+    cam = seq["cam"]
+    gpu_ctx.config_pyramids(2, 320, 240, 4)
+    gpu_ctx.build_pyramid(0, seq["images"][0], 0)
+    gpu_ctx.build_pyramid(1, seq["images"][1], 0)
+    T0 = seq["poses_true"][0]
+    ref_pos = synth.se3_inv(T0)[4:]
+    scaled = lambda px, pos: seqm._bearing(cam, px) * np.linalg.norm(pos - ref_pos, axis=1)[:, None]
+    aj = abi.AlignJob(cam, 3, 1, 30, 1e-6, [0, 0, 0, 1, 0, 0, 0], seq["pt_px0"], scaled(seq["pt_px0"], seq["pt_pos"]), seq["seg_spx0"], seq["seg_epx0"],
+                      np.linalg.norm(seq["seg_epx0"] - seq["seg_spx0"], axis=1), scaled(seq["seg_spx0"], seq["seg_spos"]),
+                      scaled(seq["seg_epx0"], seq["seg_epos"]), ref_slot=0, cur_slot=1)
+    n_pts, n_seg = len(seq["pt_pos"]), len(seq["seg_spos"])
+    pos_all = np.concatenate([seq["pt_pos"], seq["seg_spos"], seq["seg_epos"]])
+    job = abi.ChainJob(aj, T0, T0, 0, n_pts, n_seg, pos_all, np.concatenate([seq["pt_px0"], seq["seg_spx0"], seq["seg_epx0"]]),
+                       np.concatenate([seq["pt_f0"], seq["seg_sf0"], seq["seg_ef0"]]))
+    seg_cell = 60
+    n_cols, n_rows = -(-320 // seg_cell), -(-240 // seg_cell)
+    seg_order = np.random.default_rng(9).permutation(n_cols * n_rows).astype(np.int32)
+    free = gpu_ctx.frame_step_batch([job], cam, n_pyr_levels=3, cell_size=40, cell_rule=False)[0]
+    for max_segs in (100, 5):
+        r = gpu_ctx.frame_step_batch([job], cam, n_pyr_levels=3, cell_size=40, cell_rule=True, max_fts=500, seg_cell_size=seg_cell,
+                                     max_fts_segs=max_segs, seg_cell_order=seg_order)[0]
+        assert np.array_equal(r.found, free.found) and np.array_equal(r.px, free.px)        # the rule selects, it does not change the matching
+        T_k = synth.se3_mul(r.align.T, T0)
+        R, t = synth.quat_to_R(T_k[:4]), T_k[4:]
+
+        def project(pos):
+            pc = pos @ R.T + t
+            return np.stack([cam[0] * pc[:, 0] / pc[:, 2] + cam[2], cam[1] * pc[:, 1] / pc[:, 2] + cam[3]], axis=1)
+        spx, epx = project(seq["seg_spos"]), project(seq["seg_epos"])
+        cell_of = lambda px: (px[:, 1] / seg_cell).astype(int) * n_cols + (px[:, 0] / seg_cell).astype(int)
+        sk, ek = cell_of(spx), cell_of(epx)
+        ok = r.found[n_pts:n_pts + n_seg].astype(bool) & r.found[n_pts + n_seg:].astype(bool)   # findMatchDirect(segment): both end points refined
+        expect = []
+        for c in seg_order:
+            cand = [s for s in range(n_seg) if ok[s] and (sk[s] == c or ek[s] == c)]
+            if cand:
+                expect.append(cand[0])
+            if len(expect) > max_segs:
+                break
+        assert list(r.sel_seg) == expect, (max_segs, list(r.sel_seg), expect)
+        assert len(r.sel_seg) == len(expect) and r.pose.seg_keep.shape[0] == len(expect)
+        if max_segs == 100:
+            assert len(set(expect)) < len(expect) <= 2 * int(ok.sum())      # some segment won both of its cells: a feature twice, as in the reference
+            assert set(expect) <= set(np.nonzero(ok)[0])
+        else:
+            assert len(expect) == max_segs + 1                              # stopped AFTER the match that exceeded the limit
+        assert Hh.pose_close(r.pose.T, free.pose.T, rot_tol=1e-2, trans_tol=1e-1)[2]          # (sanity only: another feature set, a few mrad apart at 320x240)
