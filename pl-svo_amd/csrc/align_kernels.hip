@@ -12,16 +12,16 @@
 //     patch is 4x4 pixels).  The slot layout is STATIC: the host computes it once per job and level (points own slots
 //     [0, n_pts), segments follow from the next multiple of 32 and a segment with N <= 32 samples never straddles a
 //     multiple of 32), so the device needs no scan, and all samples of a line sit in ONE wave-round of the kernel;
-//   * ONE PASS PER ITERATION.  Two lanes own a slot for the whole iteration: they split the projection of the 3-D
-//     point (one computes u, the other v), gather the 5x5 window of the current image through L2 (aligned dword pairs +
-//     v_alignbyte; LDS holds only the small slot tables, so several workgroups share a CU), evaluate 8 pixels each,
-//     exchange the line residuals through LDS with a WAVE-level fence (no workgroup barrier), and expand the 6x6
-//     contribution of the slot.  The only workgroup barriers of an iteration are the two around the 6x6 solve;
+//   * ONE PASS PER ITERATION, ONE LANE PER SLOT.  A lane owns a slot for the whole iteration: it warps and projects the 3-D
+//     point, gathers the 5x5 window of the current image through L2 (five rows of aligned dword pairs + v_alignbyte; LDS holds
+//     only the small slot tables, so several workgroups share a CU), rebuilds the reference patch's interpolated intensity and
+//     gradient row by row from the slot's 64-byte record of image bytes (align_refpatch.hpp), evaluates the 16 pixels, exchanges
+//     the line residuals through LDS with a WAVE-level fence (no workgroup barrier), and expands the 6x6 contribution of the
+//     slot.  The only workgroup barriers of an iteration are the two around the 6x6 solve;
 //   * FIVE SCALARS PER PATCH.  The 6-vector Jacobian of a pixel is J = fs * (dx * r0 + dy * r1) with r0, r1 the rows of
 //     the 2x6 projection Jacobian of the PATCH, so sum_pix w J J^T = fs^2 (A r0 r0^T + B (r0 r1^T + r1 r0^T) + C r1 r1^T)
 //     with A = sum w dx^2, B = sum w dx dy, C = sum w dy^2, and sum_pix w res J = fs (D r0 + E r1).  Only A..E are
-//     accumulated per pixel; the lane pair then shares the expansion: lane 0 adds r0 (A r0 + B r1)^T, lane 1 adds
-//     r1 (B r0 + C r1)^T (same instruction stream, operands selected by lane parity);
+//     accumulated per pixel;
 //   * per-line re-weighting (H += H_line * w / r, Jres += Jres_line * w, cull if r >= 200 or a sample leaves the image,
 //     src/sparse_img_align.cpp:640-688) needs the line's mean |residual| first: every sample lane sums its line's
 //     sample residuals from LDS in fixed order.  A job with a line of more than 32 samples at some level runs that level
@@ -309,11 +309,9 @@ __device__ __noinline__ void exact_chi2_pair_lds(const PLSVO_LDS float* planeA, 
 // ------------------------------------------------------------------------------------------------
 // SparseImgAlign::run for every job of the batch: levels [level_hi .. level_lo] of each job's range
 // ------------------------------------------------------------------------------------------------
-#ifndef PLSVO_MIN_WAVES
-#define PLSVO_MIN_WAVES 2   // VGPR budget of 256: capping at 128 (4 waves/SIMD) spills
-#endif
+constexpr int kMinWavesPerSimd = 2;   // VGPR budget of 256: capping at 168 / 128 (3 / 4 waves per SIMD) spills
 template <int T>
-__global__ __launch_bounds__(T, PLSVO_MIN_WAVES) void align_fused_kernel(AlignBatchDev b, int cap, int scap, int level_hi, int level_lo, int do_init) {
+__global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignBatchDev b, int cap, int scap, int level_hi, int level_lo, int do_init) {
   // longest-processing-time-first: the hardware hands out workgroups in blockIdx order, so the jobs with the most patches
   // start first and the launch tail is made of the cheapest frames
   const int job_id = b.order ? b.order[blockIdx.x] : (int)blockIdx.x;
