@@ -7,7 +7,7 @@ R=$(cd $(dirname $0)/../.. && pwd)
 CXX=${EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}
 OUT=$(mktemp -d /tmp/plsvo_emu_asan.XXXX)
 $R/tests/host/build_emu.sh $OUT "" -fsanitize=address -fno-omit-frame-pointer -g || exit 1
-K=${1:-"not rccl and not config4 and not bench_distributed and not test_gpu_adapter and not full_size and not resident_chain_equals"}
+K=${1:-"not rccl and not config4 and not bench_distributed and not test_gpu_adapter and not full_size and not resident_chain_equals and not every_float"}
 cd $R
 LD_PRELOAD=$($CXX -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 \
   OMP_NUM_THREADS=1 OPENBLAS_NUM_THREADS=1 PLSVO_HIP_LIB=$OUT/libplsvo_hip_emu.so \

@@ -13,7 +13,7 @@ EMU_LDFLAGS=--coverage $R/tests/host/build_emu.sh $OUT/build "" --coverage -Xcla
 cd $R
 OMP_NUM_THREADS=1 OPENBLAS_NUM_THREADS=1 PLSVO_SWEEP_SEEDS=12 PLSVO_HIP_LIB=$OUT/build/libplsvo_hip_emu.so \
   python -m pytest tests -m gpu -q -n 6 -p no:cacheprovider \
-    -k "not rccl and not config4 and not bench_distributed and not test_gpu_adapter and not full_size and not resident_chain_equals" 2>&1 | tail -2
+    -k "not rccl and not config4 and not bench_distributed and not test_gpu_adapter and not full_size and not resident_chain_equals and not every_float" 2>&1 | tail -2
 for f in align_kernels poseopt_kernels chain_kernels match_kernels seeds_kernels structopt_kernels pyramid_kernels plsvo_capi; do
   mkdir -p $OUT/$f
   (cd $R && gcov-11 -o $OUT/build/$f.gcda $OUT/build/$f.gcda > $OUT/$f.log 2>&1; mv *.gcov $OUT/$f/ 2>/dev/null)

@@ -1180,3 +1180,20 @@ def test_ldlt_flavour_option(P, ob, gpu_ctx):
     finally:
         gpu_ctx.set_ldlt_flavour(320)
         ob.set_ldlt_flavour(320)
+
+
+@pytest.mark.gpu
+def test_robust_weight_equals_the_reference_quotient_for_every_float():
+    """The photometric robust weight of a point pixel, (float)(1.0 / (1.0 + (double)|res|)) (src/sparse_img_align.cpp:479), as the
+    alignment kernel computes it (pl-svo_amd/csrc/robust_weight.hpp: the IEEE double quotient's own fma sequence without the scaling
+    wrapper) against the device's IEEE division for EVERY float in [0, 256] -- 1 132 462 081 bit patterns -- and, on a stride, against
+    the host's division: no mismatch.  (tools/robust_weight_exhaustive.hip, built by __graft_entry__.build().)"""
+    import json, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "robust_weight_exhaustive")
+    if not os.path.exists(exe):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", exe + ".hip", "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert out.returncode == 0 and d["inputs"] == 1132462081, out.stdout + out.stderr
+    assert d["robust_weight_f64_mismatches"] == 0 and d["device_division_vs_host_division_mismatches"] == 0, d
