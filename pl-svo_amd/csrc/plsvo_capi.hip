@@ -881,7 +881,7 @@ extern "C" int plsvo_poseopt_stage(plsvo_ctx* c, int n, const plsvo_poseopt_in* 
   HIP_TRY(c, c->p_d_ptkeep.ensure(std::max(npt, (size_t)1)));
   HIP_TRY(c, c->p_d_segkeep.ensure(std::max(nsg, (size_t)1)));
   HIP_TRY(c, c->p_d_s32.ensure(nft * sizeof(float)));
-  HIP_TRY(c, c->p_d_s64.ensure(nft * 3 * sizeof(double)));
+  HIP_TRY(c, c->p_d_s64.ensure(nft * 5 * sizeof(double)));
   HIP_TRY(c, c->p_d_state.ensure((size_t)n * sizeof(PoseStateDev)));
   HIP_TRY(c, c->p_d_poses.ensure((size_t)n * 7 * sizeof(double)));
   if (c->p_trace_cap > 0) HIP_TRY(c, c->p_d_log.ensure((size_t)n * c->p_trace_cap * sizeof(plsvo_poseopt_iterlog)));
@@ -1269,7 +1269,7 @@ extern "C" int plsvo_chain_stage(plsvo_ctx* c, int n, const plsvo_chain_in* in, 
   HIP_TRY(c, c->ch_d_ptkeep.ensure(std::max((size_t)npt_total, (size_t)1)));
   HIP_TRY(c, c->ch_d_segkeep.ensure(std::max((size_t)nseg_total, (size_t)1)));
   HIP_TRY(c, c->ch_d_s32.ensure(nft * sizeof(float)));
-  HIP_TRY(c, c->ch_d_s64.ensure(nft * 3 * sizeof(double)));
+  HIP_TRY(c, c->ch_d_s64.ensure(nft * 5 * sizeof(double)));
   HIP_TRY(c, c->ch_d_state.ensure((size_t)n * sizeof(PoseStateDev)));
   HIP_TRY(c, c->ch_d_poses.ensure((size_t)n * 7 * sizeof(double)));
   uint8_t* const B = c->ch_d_blob.as<uint8_t>();

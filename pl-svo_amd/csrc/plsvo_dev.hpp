@@ -155,7 +155,7 @@ struct PoseBatchDev {
   uint8_t* pt_keep;
   uint8_t* seg_keep;
   float* scratch_f32;          // per feature, for the float medians (errors)
-  double* scratch_f64;         // 3 per feature: chi2_vec_init (2x) and chi2_vec_final
+  double* scratch_f64;         // 5 per feature: chi2_vec_init (2x), chi2_vec_final, and two per point for its normalised observation
   plsvo_poseopt_iterlog* log;
   int log_cap;
   int n_jobs;

@@ -109,12 +109,17 @@ __device__ __forceinline__ float norm2_f32(float a, float b) {
 }
 
 // ---- per-feature arithmetic, shared by the workgroup-per-frame kernel and the row-per-frame kernel ----------------------------------
-// P[0..8] = R (row-major), P[9..11] = t of the current model.
+// P[0..8] = R (row-major), P[9..11] = t of the current model.  obs[2f], obs[2f+1] = f.x / f.z, f.y / f.z of point f: the observation's
+// normalised coordinates do not depend on the pose, so the scale pass divides once and the Gauss-Newton and cull passes read the two
+// quotients back (same operands, same IEEE results: bit-identical, two f64 divisions less per point and pass).
+
+// 1.0 / (1 << level) (the reference's scale of a pyramid level, :119-120): a power of two, written into the exponent -- exact
+__device__ __forceinline__ double pow2_neg(int level) { return __hiloint2double((1023 - level) << 20, 0); }
 
 // one feature of a Gauss-Newton iteration (src/pose_optimizer.cpp:107-166 / :473-533): residual, Jacobian, Tukey weight, accumulation
 // into acc (0..20 A upper row-major, 21..26 b, 27 chi2, 28 #points, 29 #segments)
 __device__ __forceinline__ void popt_accumulate_feature(const PoseBatchDev& b, const PoseJobDev& job, int f, const double (&P)[12], double scale_pt,
-                                                        double scale_ls, bool first_iter, double* init_vec, double* acc) {
+                                                        double scale_ls, bool first_iter, double* init_vec, const double* obs, double* acc) {
   const int np = job.n_pts;
   const double R0 = P[0], R1 = P[1], R2 = P[2], R3 = P[3], R4 = P[4], R5 = P[5], R6 = P[6], R7 = P[7], R8 = P[8], t0 = P[9], t1 = P[10], t2 = P[11];
   double J[12], e0, e1, weight, cnt_pt, cnt_ls;   // (the two counters are added at the common tail: `acc[28 + is_segment] += 1` would be a dynamically indexed private array, i.e. scratch)
@@ -124,10 +129,9 @@ __device__ __forceinline__ void popt_accumulate_feature(const PoseBatchDev& b, c
     const double x = b.pt_pos[3 * i], y = b.pt_pos[3 * i + 1], z = b.pt_pos[3 * i + 2];
     const double xyz[3] = { R0 * x + R1 * y + R2 * z + t0, R3 * x + R4 * y + R5 * z + t1, R6 * x + R7 * y + R8 * z + t2 };
     jacobian_xyz2uv(xyz, J);
-    const double fz = b.pt_f[3 * i + 2];
-    e0 = b.pt_f[3 * i] / fz - xyz[0] / xyz[2];
-    e1 = b.pt_f[3 * i + 1] / fz - xyz[1] / xyz[2];
-    const double sic = 1.0 / (double)(1 << b.pt_level[i]);
+    e0 = obs[2 * f] - xyz[0] / xyz[2];
+    e1 = obs[2 * f + 1] - xyz[1] / xyz[2];
+    const double sic = pow2_neg(b.pt_level[i]);
     e0 *= sic; e1 *= sic;
     if (first_iter) init_vec[f] = e0 * e0 + e1 * e1;
 #pragma unroll
@@ -147,7 +151,7 @@ __device__ __forceinline__ void popt_accumulate_feature(const PoseBatchDev& b, c
     const double l0 = b.seg_line[3 * s], l1 = b.seg_line[3 * s + 1], l2 = b.seg_line[3 * s + 2];
     const float ds = (float)(l0 * (xs[0] / xs[2]) + l1 * (xs[1] / xs[2]) + l2 * 1.0);
     const float de = (float)(l0 * (xe[0] / xe[2]) + l1 * (xe[1] / xe[2]) + l2 * 1.0);
-    const double sic = 1.0 / (double)(1 << b.seg_level[s]);
+    const double sic = pow2_neg(b.seg_level[s]);
     e0 = (double)ds * sic; e1 = (double)de * sic;
     if (first_iter) init_vec[f] = e0 * e0 + e1 * e1;
     const double en = sqrt(e0 * e0 + e1 * e1);
@@ -172,7 +176,7 @@ __device__ __forceinline__ void popt_accumulate_feature(const PoseBatchDev& b, c
 }
 
 // the float error of a feature in the scale pass (:57-87): points sqrt(e0^2 + e1^2) scaled by the level, lines the un-scaled float norm
-__device__ __forceinline__ float popt_scale_error(const PoseBatchDev& b, const PoseJobDev& job, int f, const double (&P)[12]) {
+__device__ __forceinline__ float popt_scale_error(const PoseBatchDev& b, const PoseJobDev& job, int f, const double (&P)[12], double* obs) {
   const int np = job.n_pts;
   const double R0 = P[0], R1 = P[1], R2 = P[2], R3 = P[3], R4 = P[4], R5 = P[5], R6 = P[6], R7 = P[7], R8 = P[8], t0 = P[9], t1 = P[10], t2 = P[11];
   if (f < np) {
@@ -180,8 +184,10 @@ __device__ __forceinline__ float popt_scale_error(const PoseBatchDev& b, const P
     const double x = b.pt_pos[3 * i], y = b.pt_pos[3 * i + 1], z = b.pt_pos[3 * i + 2];
     const double xc = R0 * x + R1 * y + R2 * z + t0, yc = R3 * x + R4 * y + R5 * z + t1, zc = R6 * x + R7 * y + R8 * z + t2;
     const double fz = b.pt_f[3 * i + 2];
-    double e0 = b.pt_f[3 * i] / fz - xc / zc, e1 = b.pt_f[3 * i + 1] / fz - yc / zc;
-    const double sic = 1.0 / (double)(1 << b.pt_level[i]);
+    const double ox = b.pt_f[3 * i] / fz, oy = b.pt_f[3 * i + 1] / fz;
+    obs[2 * f] = ox; obs[2 * f + 1] = oy;
+    double e0 = ox - xc / zc, e1 = oy - yc / zc;
+    const double sic = pow2_neg(b.pt_level[i]);
     e0 *= sic; e1 *= sic;
     return (float)sqrt(e0 * e0 + e1 * e1);
   }
@@ -199,7 +205,7 @@ __device__ __forceinline__ float popt_scale_error(const PoseBatchDev& b, const P
 // the cull of one feature (:201-242): clears its keep flag when the error exceeds the threshold, returns the squared error;
 // deleted = 1 (point) / 2 (segment) / 0
 __device__ __forceinline__ double popt_cull_feature(const PoseBatchDev& b, const PoseJobDev& job, int f, const double (&P)[12], double thr_pt, double thr_ls,
-                                                    int& deleted) {
+                                                    const double* obs, int& deleted) {
   const int np = job.n_pts;
   const double R0 = P[0], R1 = P[1], R2 = P[2], R3 = P[3], R4 = P[4], R5 = P[5], R6 = P[6], R7 = P[7], R8 = P[8], t0 = P[9], t1 = P[10], t2 = P[11];
   double e0, e1;
@@ -208,9 +214,8 @@ __device__ __forceinline__ double popt_cull_feature(const PoseBatchDev& b, const
     const int i = job.pt_off + f;
     const double x = b.pt_pos[3 * i], y = b.pt_pos[3 * i + 1], z = b.pt_pos[3 * i + 2];
     const double xc = R0 * x + R1 * y + R2 * z + t0, yc = R3 * x + R4 * y + R5 * z + t1, zc = R6 * x + R7 * y + R8 * z + t2;
-    const double fz = b.pt_f[3 * i + 2];
-    e0 = b.pt_f[3 * i] / fz - xc / zc; e1 = b.pt_f[3 * i + 1] / fz - yc / zc;
-    const double sic = 1.0 / (double)(1 << b.pt_level[i]);
+    e0 = obs[2 * f] - xc / zc; e1 = obs[2 * f + 1] - yc / zc;
+    const double sic = pow2_neg(b.pt_level[i]);
     e0 *= sic; e1 *= sic;
     if (sqrt(e0 * e0 + e1 * e1) > thr_pt) { b.pt_keep[i] = 0; deleted = 1; }
   } else {
@@ -220,7 +225,7 @@ __device__ __forceinline__ double popt_cull_feature(const PoseBatchDev& b, const
     const double xs0 = R0 * sx + R1 * sy + R2 * sz + t0, xs1 = R3 * sx + R4 * sy + R5 * sz + t1, xs2 = R6 * sx + R7 * sy + R8 * sz + t2;
     const double xe0 = R0 * ex + R1 * ey + R2 * ez + t0, xe1 = R3 * ex + R4 * ey + R5 * ez + t1, xe2 = R6 * ex + R7 * ey + R8 * ez + t2;
     const double l0 = b.seg_line[3 * s], l1 = b.seg_line[3 * s + 1], l2 = b.seg_line[3 * s + 2];
-    const double sic = 1.0 / (double)(1 << b.seg_level[s]);
+    const double sic = pow2_neg(b.seg_level[s]);
     e0 = (l0 * (xs0 / xs2) + l1 * (xs1 / xs2) + l2 * 1.0) * sic;     // doubles here, no float truncation (:229)
     e1 = (l0 * (xe0 / xe2) + l1 * (xe1 / xe2) + l2 * 1.0) * sic;
     if (sqrt(e0 * e0 + e1 * e1) > thr_ls) { b.seg_keep[s] = 0; deleted = 2; }
@@ -231,7 +236,7 @@ __device__ __forceinline__ double popt_cull_feature(const PoseBatchDev& b, const
 template <int PO_T>
 __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseStateDev* st, int job_id, double* s_red,
                              double* s_pose, int* s_ctl, int n_iter, int phase, double scale_pt, double scale_ls,
-                             double* init_vec, double* s_tot) {
+                             double* init_vec, const double* obs, double* s_tot) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int np = job.n_pts, ns = job.n_seg, nf = np + ns;
   for (int iter = 0; iter < n_iter; ++iter) {
@@ -241,7 +246,7 @@ __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseS
     double P[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) P[k] = s_pose[k];
-    for (int f = tid; f < nf; f += PO_T) popt_accumulate_feature(b, job, f, P, scale_pt, scale_ls, iter == 0, init_vec, acc);
+    for (int f = tid; f < nf; f += PO_T) popt_accumulate_feature(b, job, f, P, scale_pt, scale_ls, iter == 0, init_vec, obs, acc);
     {
       double out2[2];
       row_reduce_scatter32(acc, out2);
@@ -313,10 +318,10 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* 
   __shared__ int s_sel[16];
 
   // scratch: floats [0,np) point errors, [np, np+ns) line errors; doubles [0,nf) init (first loop),
-  // [nf,2nf) init (refinement), [2nf,3nf) final
+  // [nf,2nf) init (refinement), [2nf,3nf) final, [3nf, 3nf + 2 np) the points' normalised observations
   const size_t fbase = (size_t)job.pt_off + (size_t)job.seg_off;
   float* errs = b.scratch_f32 + fbase;
-  double* vec = b.scratch_f64 + 3 * fbase;
+  double* vec = b.scratch_f64 + 5 * fbase;
 
 #ifdef PLSVO_TIMING
   __shared__ unsigned long long s_time[8];
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* 
     double P[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) P[k] = s_pose[k];
-    for (int f = tid; f < nf; f += PO_T) errs[f] = popt_scale_error(b, job, f, P);
+    for (int f = tid; f < nf; f += PO_T) errs[f] = popt_scale_error(b, job, f, P, vec + 3 * nf);
   }
   __syncthreads();
   PTICK(0);
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* 
   PTICK(1);
   // ---- first GN loop ----
   if (job.n_iter <= 0) for (int f = tid; f < nf; f += PO_T) vec[f] = __longlong_as_double(0x7ff0000000000000LL);
-  popt_gn_loop<PO_T>(b, job, st, job_id, s_red, s_pose, s_ctl, job.n_iter, 0, scale_pt, scale_ls, vec, s_tot);
+  popt_gn_loop<PO_T>(b, job, st, job_id, s_red, s_pose, s_ctl, job.n_iter, 0, scale_pt, scale_ls, vec, vec + 3 * nf, s_tot);
 
   PTICK(2);
   // ---- covariance :197-199 (from the last assembled A, even if that iteration was rolled back) ----
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* 
     for (int k = 0; k < 12; ++k) P[k] = s_pose[k];
     for (int f = tid; f < nf; f += PO_T) {
       int deleted;
-      vec[2 * nf + f] = popt_cull_feature(b, job, f, P, thr_pt, thr_ls, deleted);
+      vec[2 * nf + f] = popt_cull_feature(b, job, f, P, thr_pt, thr_ls, vec + 3 * nf, deleted);
       del_pt += deleted == 1; del_ls += deleted == 2;
       vec[nf + f] = __longlong_as_double(0x7ff0000000000000LL);  // +inf sentinel for the refinement's init entries
     }
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* 
   // ---- refinement with inliers :469-563 (10-argument overload) ----
   int n_init = job.n_iter > 0 ? nf : 0;
   if (job.n_iter_ref >= 0) {
-    popt_gn_loop<PO_T>(b, job, st, job_id, s_red, s_pose, s_ctl, job.n_iter_ref, 1, scale_pt, scale_ls, vec + nf, s_tot);
+    popt_gn_loop<PO_T>(b, job, st, job_id, s_red, s_pose, s_ctl, job.n_iter_ref, 1, scale_pt, scale_ls, vec + nf, vec + 3 * nf, s_tot);
     if (job.n_iter_ref > 0) n_init += nf - n_del_pt - n_del_ls;
   }
   __syncthreads();
@@ -597,7 +602,7 @@ __device__ __forceinline__ void lane_solve6(const double* tot, double* xs, doubl
 
 // one GN loop (:103-195 / :469-563) for the four frames of the wave
 __device__ __forceinline__ void rows_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseStateDev* st, int job_id, PoseRowLds& L, bool row_on,
-                                             int n_iter, int phase, double scale_pt, double scale_ls, double* init_vec) {
+                                             int n_iter, int phase, double scale_pt, double scale_ls, double* init_vec, const double* obs) {
   const int lane = threadIdx.x & 63, rl = lane & 15;
   const int nf = job.n_pts + job.n_seg;
   bool running = row_on && n_iter > 0;
@@ -609,7 +614,7 @@ __device__ __forceinline__ void rows_gn_loop(const PoseBatchDev& b, const PoseJo
       double P[12];
 #pragma unroll
       for (int k = 0; k < 12; ++k) P[k] = L.pose[k];
-      for (int f = rl; f < nf; f += 16) popt_accumulate_feature(b, job, f, P, scale_pt, scale_ls, iter == 0, init_vec, acc);
+      for (int f = rl; f < nf; f += 16) popt_accumulate_feature(b, job, f, P, scale_pt, scale_ls, iter == 0, init_vec, obs, acc);
     }
     double out2[2];
     row_reduce_scatter32(acc, out2);     // every lane of the wave takes part (DPP); the row's totals are the frame's
@@ -664,10 +669,10 @@ __global__ __launch_bounds__(64) void pose_opt_rows_kernel(PoseBatchDev b, doubl
   PoseRowLds& L = s_rows[row];
   const int np = job.n_pts, ns = job.n_seg, nf = np + ns;
 
-  // scratch: floats [0,np) point errors, [np, np+ns) line errors; doubles [0,nf) init (first loop), [nf,2nf) init (refinement), [2nf,3nf) final
+  // scratch: floats [0,np) point errors, [np, np+ns) line errors; doubles [0,nf) init (first loop), [nf,2nf) init (refinement), [2nf,3nf) final, [3nf, 3nf + 2 np) the points' normalised observations
   const size_t fbase = (size_t)job.pt_off + (size_t)job.seg_off;
   float* errs = b.scratch_f32 + fbase;
-  double* vec = b.scratch_f64 + 3 * fbase;
+  double* vec = b.scratch_f64 + 5 * fbase;
 
   if (row_valid && rl == 0) {
     SE3d m = se3_load(job.T0);
@@ -694,7 +699,7 @@ __global__ __launch_bounds__(64) void pose_opt_rows_kernel(PoseBatchDev b, doubl
     double P[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) P[k] = L.pose[k];
-    for (int f = rl; f < nf; f += 16) errs[f] = popt_scale_error(b, job, f, P);
+    for (int f = rl; f < nf; f += 16) errs[f] = popt_scale_error(b, job, f, P, vec + 3 * nf);
   }
   wave_lds_fence();   // (global scratch written and read by lanes of this wave only)
   // MAD scale = 1.48f * median (float).  Zero points: the reference is undefined (:70); we define 1.0.
@@ -708,7 +713,7 @@ __global__ __launch_bounds__(64) void pose_opt_rows_kernel(PoseBatchDev b, doubl
 
   // ---- first GN loop ----
   if (row_on && job.n_iter <= 0) for (int f = rl; f < nf; f += 16) vec[f] = __longlong_as_double(0x7ff0000000000000LL);
-  rows_gn_loop(b, job, st, job_id, L, row_on, job.n_iter, 0, scale_pt, scale_ls, vec);
+  rows_gn_loop(b, job, st, job_id, L, row_on, job.n_iter, 0, scale_pt, scale_ls, vec, vec + 3 * nf);
 
   // ---- covariance :197-199 (from the last assembled A, even if that iteration was rolled back) ----
   if (row_on) {
@@ -730,7 +735,7 @@ __global__ __launch_bounds__(64) void pose_opt_rows_kernel(PoseBatchDev b, doubl
     for (int k = 0; k < 12; ++k) P[k] = L.pose[k];
     for (int f = rl; f < nf; f += 16) {
       int deleted;
-      vec[2 * nf + f] = popt_cull_feature(b, job, f, P, thr_pt, thr_ls, deleted);
+      vec[2 * nf + f] = popt_cull_feature(b, job, f, P, thr_pt, thr_ls, vec + 3 * nf, deleted);
       del_pt += deleted == 1; del_ls += deleted == 2;
       vec[nf + f] = __longlong_as_double(0x7ff0000000000000LL);  // +inf sentinel for the refinement's init entries
     }
@@ -740,7 +745,7 @@ __global__ __launch_bounds__(64) void pose_opt_rows_kernel(PoseBatchDev b, doubl
 
   // ---- refinement with inliers :469-563 (10-argument overload) ----
   int n_init = job.n_iter > 0 ? nf : 0;
-  rows_gn_loop(b, job, st, job_id, L, row_on && job.n_iter_ref >= 0, job.n_iter_ref, 1, scale_pt, scale_ls, vec + nf);
+  rows_gn_loop(b, job, st, job_id, L, row_on && job.n_iter_ref >= 0, job.n_iter_ref, 1, scale_pt, scale_ls, vec + nf, vec + 3 * nf);
   if (job.n_iter_ref > 0) n_init += nf - n_del_pt - n_del_ls;
   wave_lds_fence();
 
