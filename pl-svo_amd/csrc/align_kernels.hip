@@ -189,6 +189,10 @@ __device__ __forceinline__ void exact_round32(const float (&t)[16], float& s, do
   e = min(max(e, -100), 126);
   const double two_e = __hiloint2double((e + 1023) << 20, 0), two_e1 = __hiloint2double((e + 1024) << 20, 0);
   safe = safe && lo * (1.0 - 0.0009765625) >= two_e && hi * (1.0 + 0.0009765625) < two_e1;
+  // the scan of `delta` below must be exact in double: every lane's rounded terms are multiples of ITS quantum 2^(e-23), the round's sum
+  // stays below 2^(e_top+1) with e_top the binade the round ends in -- so a lane more than 26 binades below that walks its terms itself
+  const int e_top = (int)((__double2hiint(base + tot) >> 20) & 0x7ff) - 1023;
+  safe = safe && e >= e_top - 26;
   const float C = __int_as_float((e + 127) << 23), half_q = __int_as_float((e - 24 + 127) << 23);
   double delta = 0.0;
   bool half_hit = false;
@@ -749,7 +753,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
       if (wave == 0 && stage == last_stage) {
         // (after terms-only re-runs the totals of the iteration are read back from s_tot and the solve is simply done again)
         const double tot = terms_only ? s_tot[lane & 31] : reduce_rows_finish<ROWS>(s_red);
-        if (lane < 30 && !terms_only) s_tot[lane] = tot;
+        if (lane < 32 && !terms_only) s_tot[lane] = tot;   // (0..26 the system, 27..30 chi2 / n_meas / work counters: a terms-only re-run reads them back)
         TICK(3);
         double x[6];
         wave_solve6_reg(tot, x, job.ldlt_flavour);                             // solve() :699

@@ -130,7 +130,7 @@ struct plsvo_ctx {
   PoseBatchDev ch_pose{};
   DevBuf ch_d_state, ch_d_ptkeep, ch_d_segkeep, ch_d_s32, ch_d_s64, ch_d_poses;
   DevBuf rec_d;   // plsvo_fetch_pose_records
-  unsigned long long run_seq = 0, a_run_seq = 0, p_run_seq = 0;   // which resident batch ran last (plsvo_pack_pose_records)
+  unsigned long long run_seq = 0, a_run_seq = 0, p_run_seq = 0, ch_run_seq = 0;   // which resident batch ran last, 0 = not since it was staged (plsvo_pack_pose_records)
 
   // structure optimisation (one-shot batches)
   DevBuf s_d_in, s_d_out;
@@ -1321,7 +1321,7 @@ extern "C" int plsvo_chain_stage(plsvo_ctx* c, int n, const plsvo_chain_in* in, 
   q.log = nullptr; q.log_cap = 0; q.n_jobs = n;
   c->ch_jobs.swap(jobs);
   c->ch_n = n; c->ch_ncand = (int)NC; c->ch_npt_cap = npt_total; c->ch_nseg_cap = nseg_total;
-  c->ch_staged = true;
+  c->ch_staged = true; c->ch_run_seq = 0;
   return PLSVO_OK;
 }
 
@@ -1343,6 +1343,7 @@ extern "C" int plsvo_chain_run(plsvo_ctx* c) {
   EventPair ep{}; prof_begin(c, PLSVO_K_POSEOPT, &ep);
   HIP_TRY(c, launch_pose_opt(c->ch_pose, c->ch_d_poses.as<double>(), threads, c->stream));
   prof_end(c, PLSVO_K_POSEOPT, &ep);
+  c->ch_run_seq = ++c->run_seq;
   return PLSVO_OK;
 }
 
@@ -1531,34 +1532,47 @@ extern "C" int plsvo_update_seeds(plsvo_ctx* c, const plsvo_seeds_in* in, plsvo_
 }
 
 // ---- multi-GPU gather ------------------------------------------------------------------------------
+// which resident state the records come from, and how many there are -- decided BEFORE anything is sized or launched
+namespace {
+struct RecordSource { const AlignStateDev* ast = nullptr; const PoseStateDev* pst = nullptr; int n = 0; const char* why_not = nullptr; };
+RecordSource pick_record_source(plsvo_ctx* c) {
+  RecordSource r;
+  if (c->ch_staged && c->a_staged && c->a_n == c->ch_n) {   // the resident frame step: its own pose-optimisation state
+    if (c->ch_run_seq == 0) { r.why_not = "pack_pose_records: the staged frame step has not run"; return r; }
+    r.ast = c->a_d_state.as<AlignStateDev>(); r.pst = c->ch_d_state.as<PoseStateDev>(); r.n = c->ch_n;
+    return r;
+  }
+  // both batches when they describe the same streams (same size); otherwise the one that ran last
+  const bool use_a = c->a_staged && c->a_run_seq > 0, use_p = c->p_staged && c->p_run_seq > 0;
+  const bool both = use_a && use_p && c->a_n == c->p_n;
+  if (use_a && (both || !use_p || c->a_run_seq > c->p_run_seq)) { r.ast = c->a_d_state.as<AlignStateDev>(); r.n = c->a_n; }
+  if (use_p && (both || !use_a || c->p_run_seq > c->a_run_seq)) { r.pst = c->p_d_state.as<PoseStateDev>(); r.n = c->p_n; }
+  if (!r.ast && !r.pst) r.why_not = "pack_pose_records: no staged batch has run";
+  return r;
+}
+}  // namespace
+
 extern "C" int plsvo_pack_pose_records(plsvo_ctx* c, plsvo_pose_record* d_dst, int* n_out) {
   CTX_CHECK(c);
   if (!d_dst) return fail(c, PLSVO_E_INVALID, "pack_pose_records: null destination");
-  const AlignStateDev* ast = nullptr; const PoseStateDev* pst = nullptr; int n = 0;
-  if (c->ch_staged && c->a_staged && c->a_n == c->ch_n) {   // the resident frame step: its own pose-optimisation state
-    ast = c->a_d_state.as<AlignStateDev>(); pst = c->ch_d_state.as<PoseStateDev>(); n = c->ch_n;
-  } else {
-    // both batches when they describe the same streams (same size); otherwise the one that ran last
-    const bool use_a = c->a_staged && c->a_run_seq > 0, use_p = c->p_staged && c->p_run_seq > 0;
-    const bool both = use_a && use_p && c->a_n == c->p_n;
-    if (use_a && (both || !use_p || c->a_run_seq > c->p_run_seq)) { ast = c->a_d_state.as<AlignStateDev>(); n = c->a_n; }
-    if (use_p && (both || !use_a || c->p_run_seq > c->a_run_seq)) { pst = c->p_d_state.as<PoseStateDev>(); n = c->p_n; }
-  }
-  if (!ast && !pst) return fail(c, PLSVO_E_STATE, "pack_pose_records: no staged batch has run");
+  const RecordSource src = pick_record_source(c);
+  if (src.why_not) return fail(c, PLSVO_E_STATE, src.why_not);
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, launch_pack_pose_records(ast, pst, n, d_dst, c->stream));
-  if (n_out) *n_out = n;
+  HIP_TRY(c, launch_pack_pose_records(src.ast, src.pst, src.n, d_dst, c->stream));
+  if (n_out) *n_out = src.n;
   return PLSVO_OK;
 }
 
 extern "C" int plsvo_fetch_pose_records(plsvo_ctx* c, int n, plsvo_pose_record* out) {
   CTX_CHECK(c);
   if (!out || n <= 0) return fail(c, PLSVO_E_INVALID, "fetch_pose_records: bad arguments");
+  const RecordSource src = pick_record_source(c);
+  if (src.why_not) return fail(c, PLSVO_E_STATE, src.why_not);
+  // (the pack kernel writes one record per RESIDENT stream: a caller's n that is not that count is rejected before the buffer is sized)
+  if (src.n != n) return fail(c, PLSVO_E_INVALID, "fetch_pose_records: n does not match the resident batch");
+  HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, c->rec_d.ensure((size_t)n * sizeof(plsvo_pose_record)));
-  int n_packed = 0;
-  const int rc = plsvo_pack_pose_records(c, c->rec_d.as<plsvo_pose_record>(), &n_packed);
-  if (rc) return rc;
-  if (n_packed != n) return fail(c, PLSVO_E_INVALID, "fetch_pose_records: n does not match the resident batch");
+  HIP_TRY(c, launch_pack_pose_records(src.ast, src.pst, src.n, c->rec_d.as<plsvo_pose_record>(), c->stream));
   HIP_TRY(c, hipMemcpyAsync(out, c->rec_d.p, (size_t)n * sizeof(plsvo_pose_record), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return PLSVO_OK;

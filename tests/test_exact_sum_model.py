@@ -141,10 +141,14 @@ def half_wave_sum(t, margin=2.0 ** -10):
         excl = np.concatenate([[0.0], np.cumsum(d)[:-1]])   # exclusive scan over the 32 lanes
         lo, hi = base + excl, base + excl + d
         e = np.zeros(32, int); safe = np.zeros(32, bool); delta = np.zeros(32)
+        top = base + d.sum()
+        e_top = int(np.floor(np.log2(top))) if top > 0.0 and np.isfinite(top) else -1023
         for l in range(32):
             if not (lo[l] > 0.0 and np.isfinite(hi[l])):
                 continue
             el = int(np.floor(np.log2(lo[l])))
+            if el < e_top - 26:                               # the scan of delta must stay exact in double: 26 binades of spread at most
+                continue
             if not (lo[l] * (1.0 - margin) >= 2.0 ** el and hi[l] * (1.0 + margin) < 2.0 ** (el + 1)) or el - 24 < -126 or el > 126:
                 continue
             C = F(2.0 ** el)
@@ -191,6 +195,8 @@ def test_half_wave_layout_is_bit_exact(n):
             assert redone < 0.15 * ns
     for t in (np.zeros(64, F), np.full(3200, F(0.5)), (rng.integers(0, 4, 3200) * 0.25).astype(F),
               np.concatenate([np.full(100, F(1e-30)), chi2_like_terms(rng, 1000)]), (chi2_like_terms(rng, 3200) * F(2.0 ** 60)).astype(F),
-              (chi2_like_terms(rng, 3200) * F(2.0 ** -60)).astype(F)):
+              (chi2_like_terms(rng, 3200) * F(2.0 ** -60)).astype(F),
+              # 40 binades between the first slots' running sum and the end of the same 32-slot round
+              np.concatenate([np.full(16, F(2.0 ** -36)), chi2_like_terms(rng, 16 * 31) * F(64.0)]).astype(F)):
         got, _, _ = half_wave_sum(t)
         assert got.tobytes() == seq_sum(t).tobytes()

@@ -115,6 +115,9 @@ SWEEPS = [
     ("config2-one-wave-per-frame", 4300, 150, 640, 480, 200, 80, 4, 3, 1, 64),
     # config 3 at ITS benchmark shape (8192 streams -> two waves per frame: row-major slab, HBM planes, arming); the window holds seed 5348
     ("config3-two-waves-per-frame", 5320, 40, 1280, 720, 400, 150, 5, 4, 2, 128),
+    # config 3 at the shape `bench.py --config 3` runs since round 4 (16384 streams -> ONE wave per frame: tiled mirror, whose level 4 is
+    # 80 x 45 pixels = a partial tile row, HBM planes, arming); same window
+    ("config3-one-wave-per-frame", 5320, 40, 1280, 720, 400, 150, 5, 4, 2, 64),
 ]
 
 
@@ -125,6 +128,7 @@ TIE_CASES = [
     # inter-frame translation, 1.9e-4 / 3.2e-4 on T_f_w -- outside the bar.  The kernel now rebuilds the missing terms before deciding.
     (4373, 64, (640, 480, 200, 80, 4, 3, 1)),
     (5348, 128, (1280, 720, 400, 150, 5, 4, 2)),
+    (5348, 64, (1280, 720, 400, 150, 5, 4, 2)),     # the same frame at one wave per frame (config 3's benchmark shape since round 4)
 ]
 
 
@@ -623,29 +627,36 @@ def test_errors_are_reported_not_swallowed(P, gpu_ctx):
     assert r.n_meas > 0 and np.all(np.isfinite(r.T))
 
 
+# frame sizes of the launch-shape test: BASELINE configs 2 and 3 (1280 x 720 at five levels: level 4 is 80 x 45, a partial tile ROW of the
+# 16 x 8-pixel tiled mirror the one-wave shape reads) and a size whose coarsest level, 62 x 37, is a multiple of the tile in NEITHER dimension
+LAUNCH_SHAPE_FRAMES = [(640, 480, 4, 3, 1), (1280, 720, 5, 4, 2), (1000, 600, 5, 4, 2)]
+
+
+@pytest.mark.parametrize("frame", LAUNCH_SHAPE_FRAMES, ids=[f"{f[0]}x{f[1]}" for f in LAUNCH_SHAPE_FRAMES])
 @pytest.mark.parametrize("threads", [64, 128, 256, 512])
-def test_sparse_align_every_launch_shape(P, ob, gpu_ctx, threads):
+def test_sparse_align_every_launch_shape(P, ob, gpu_ctx, threads, frame):
     """the library picks 64 / 128 / 256 / 512 threads per frame from the batch size (64: one wave per frame, no workgroup barrier
     at all -- the shape of the 32768-frame benchmark); every shape must meet the bar on its own, follow the oracle's per-iteration
     trace, and give the same result wherever a job sits in the batch"""
     gpu_ctx.set_launch_shapes(align_threads=threads)
     try:
-        _every_launch_shape_body(P, ob, gpu_ctx, threads)
+        _every_launch_shape_body(P, ob, gpu_ctx, threads, *frame)
     finally:
         gpu_ctx.set_launch_shapes(align_threads=0)
 
 
-def _every_launch_shape_body(P, ob, gpu_ctx, threads):
-    B, W, H = 5, 640, 480
-    streams = [P.synth.make_align_stream(700 + i, W, H, 200 - 30 * i, 80 - 10 * i, max_level=3) for i in range(B)]
+def _every_launch_shape_body(P, ob, gpu_ctx, threads, W=640, H=480, nlev=4, maxl=3, minl=1):
+    B = 5
+    k = 2 if W > 640 else 1      # config 3 has twice the features of config 2
+    streams = [P.synth.make_align_stream(700 + i, W, H, k * (200 - 30 * i), k * (80 - 10 * i) - (5 if k == 2 else 0), max_level=maxl) for i in range(B)]
     imgs = P.synth.render_streams(streams).numpy()
-    gpu_ctx.config_pyramids(2 * B, W, H, 4)
+    gpu_ctx.config_pyramids(2 * B, W, H, nlev)
     pyr = []
     for i in range(B):
         gpu_ctx.build_pyramid(2 * i, imgs[i, 0], 0)
         gpu_ctx.build_pyramid(2 * i + 1, imgs[i, 1], 0)
         pyr.append((gpu_ctx.download_pyramid(2 * i), gpu_ctx.download_pyramid(2 * i + 1)))
-    jobs = [P.align_job_from_stream(s, 3, 1, ref_slot=2 * i, cur_slot=2 * i + 1) for i, s in enumerate(streams)]
+    jobs = [P.align_job_from_stream(s, maxl, minl, ref_slot=2 * i, cur_slot=2 * i + 1) for i, s in enumerate(streams)]
     gpu_ctx.align_set_trace(200)
     batch = gpu_ctx.sparse_align_batch(jobs)
     logs = [gpu_ctx.align_fetch_trace(i) for i in range(B)]

@@ -154,6 +154,19 @@ def test_resident_chain_applies_the_reprojection_grid_rule(P, ob, gpu_ctx, seqm)
     # the records a rank would publish for the resident step (plsvo_pack_pose_records / plsvo_fetch_pose_records): the pose the step ends with, run()'s return value,
     # the optimiser's surviving observations -- straight from the device state, equal to what the fetch returned
     recs = gpu_ctx.fetch_pose_records(len(jobs))
+    # a record count that is not the resident batch's is an argument error BEFORE anything is sized or launched (the pack kernel writes
+    # one record per resident stream: sizing the buffer for the caller's smaller n first would be a device heap overwrite)
+    with pytest.raises(P.capi.PlsvoError) as e:
+        gpu_ctx.fetch_pose_records(1)
+    assert e.value.code == abi.E_INVALID
+    # a frame step that was staged but has not run publishes nothing ("launches that have run", include/plsvo_hip.h)
+    gpu_ctx.chain_stage(jobs, cam, n_pyr_levels=3, cell_size=cell_size, cell_rule=False)
+    with pytest.raises(P.capi.PlsvoError) as e:
+        gpu_ctx.fetch_pose_records(len(jobs))
+    assert e.value.code == abi.E_STATE
+    gpu_ctx.chain_run()
+    recs2 = gpu_ctx.fetch_pose_records(len(jobs))
+    assert np.array_equal(recs2["T_f_w"], recs["T_f_w"])
     for s, f in enumerate(free):
         assert np.array_equal(recs[s]["T_f_w"], np.asarray(f.pose.T)) and int(recs[s]["n_tracked"]) == int(f.align.n_tracked)
         assert (int(recs[s]["num_obs_pt"]), int(recs[s]["num_obs_ls"])) == (int(f.pose.num_obs_pt), int(f.pose.num_obs_ls))
