@@ -166,7 +166,7 @@ __device__ __forceinline__ double fast_sqrt(double x) {   // x >= 0, finite; sqr
 // is written for instruction count: the pivot is a DPP max over the lanes' own |diagonal| keys + one ballot (no per-row
 // readlanes, no compare chain), its reciprocal comes from fast_rcp while the two ds_bpermute round trips (row p, column p)
 // are in flight, and the update is one multiply + one fma per lane.
-__device__ __forceinline__ void wave_solve6_core(double m, double* x, int flavour = 320);
+__device__ __forceinline__ void wave_solve6_core(double m, double* x, int flavour = 320, bool allow_static_order = true);
 
 __device__ __forceinline__ void wave_solve6(const double* tot, double* x) {
   const int lane = threadIdx.x & 63;
@@ -208,17 +208,54 @@ __device__ __forceinline__ double wave_max_to_lane63(double v) {
 // cutoff -- the factorisation never stops early, only an exactly zero pivot leaves its column unscaled, and solve() drops
 // |d| <= 1/DBL_MAX only.  Identical arithmetic on every full-rank system; on rank-deficient ones 330 divides rounding residue by
 // rounding residue (tests/test_solve_model.py), which no two implementations reproduce alike.
-__device__ __forceinline__ void wave_solve6_core(double m, double* x, int flavour) {
+__device__ __forceinline__ void wave_solve6_core(double m, double* x, int flavour, bool allow_static_order) {
   const int lane = threadIdx.x & 63;
   const int i = lane >> 3, j = lane & 7;
   const int addr_row = 4 * j, addr_col = 4 * 8 * i;      // byte addresses of lanes (p,j) / (i,p) once 32p / 4p is added
   bool diag_active = (i == j) && (i < 6);                // this lane holds a diagonal entry not yet used as pivot
   const bool in_system = (i < 6) && (j <= 6);
   const double key0 = fabs(m);                           // |original diagonal|: Eigen's pivot order is fixed by the input
-  int pos = diag_active ? i : 64;                        // current position of this diagonal entry under Eigen's transpositions
   unsigned zero_piv = 0u;
   double cutoff = 0.0;
   int last_p = 0;
+  // STATIC ORDER (the usual case): six distinct, non-NaN |diagonals| -- the pivot order is their descending sort, known before the first
+  // elimination step.  Lane (i,j) of the 6x6 block compares |H_jj| with |H_ii|; one ballot gives every diagonal its rank (the number of
+  // larger ones), and the six steps run without a search: pivot = v_readlane, its reciprocal under the two ds_bpermute round trips, one
+  // multiply + one fma per lane (~16 instructions per step; with the per-step DPP maximum, ballot and tie test it was ~50, and the
+  // solve 4.5 k of the 25 k cycles of a lone frame's Gauss-Newton iteration -- profiles/r05a_phase_ticks_b1.log).  Same arithmetic in
+  // the same order as the search below: bit-identical results (tests/test_wave_host.py compares the two on every system it solves).
+  // Exact ties (Eigen: the first in its PERMUTED order) and NaN diagonals take the search.
+  const bool in66 = (i < 6) && (j < 6);
+  const double k_i = bpermute_f64(4 * 9 * (i < 6 ? i : 0), key0), k_j = bpermute_f64(4 * 9 * (j < 6 ? j : 0), key0);
+  const unsigned long long larger = __ballot(in66 && k_j > k_i);
+  const unsigned long long odd = __ballot(in66 && ((i != j && k_j == k_i) || k_i != k_i));
+  if (allow_static_order && odd == 0ull) {               // wave-uniform
+    int ord[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const int rank = __popcll(larger & (0x3full << (8 * a)));
+#pragma unroll
+      for (int s_ = 0; s_ < 6; ++s_) if (rank == s_) ord[s_] = a;
+    }
+    const double kmax0 = readlane_f64(key0, 9 * ord[0]);
+    cutoff = flavour == 330 ? 0.0 : fabs(2.220446049250313e-16 * kmax0);
+#pragma unroll
+    for (int step = 0; step < 6; ++step) {
+      const int p = ord[step];
+      const double kmax = readlane_f64(key0, 9 * p);
+      const double piv = readlane_f64(m, 9 * p);
+      if (!(kmax < cutoff) && fabs(piv) > cutoff) {
+        const double mp_j = bpermute_f64(addr_row + 32 * p, m);   // M[p][j]
+        const double mi_p = bpermute_f64(addr_col + 4 * p, m);    // M[i][p]
+        const double rinv = fast_rcp(piv);
+        if (in_system && i != p) m = fma(-(mi_p * mp_j), rinv, m);
+      } else {
+        zero_piv |= 1u << p;
+      }
+      last_p = p;
+    }
+  } else {
+  int pos = diag_active ? i : 64;                        // current position of this diagonal entry under Eigen's transpositions
 #pragma unroll
   for (int step = 0; step < 6; ++step) {
     // pivot: largest original |diagonal| among the rows not yet eliminated
@@ -254,6 +291,7 @@ __device__ __forceinline__ void wave_solve6_core(double m, double* x, int flavou
     }
     diag_active = diag_active && (i != p);
     last_p = p;
+  }
   }
   const double dgi = bpermute_f64(addr_col + 4 * i, m);     // M[i][i]
   const double tolerance = 1.0 / 1.7976931348623157e308;

@@ -2,6 +2,7 @@
 // (tests/host/emu/wave_emu.hpp).  Driven by tests/test_wave_host.py.
 //   wave_host_test solve <flavour>   stdin: n x 27 doubles (upper triangle of H row-major, rhs)   stdout: n x 6 doubles (x)
 //   wave_host_test solve_reg <flavour>   the same through wave_solve6_reg (inputs in lanes 0..26)
+//   wave_host_test solve_search <flavour>  the same with the static pivot order switched off (every step searches its pivot)
 //   wave_host_test selfcheck         reductions, scans and the series exp against plain loops; prints "ok" or the first failure
 #include <hip/hip_runtime.h>
 
@@ -96,7 +97,7 @@ int main(int argc, char** argv) {
         double m = 0.0;
         if (i < 6 && j < 6) m = tot[sym6_index(i, j)];
         else if (i < 6 && j == 6) m = tot[21 + i];
-        wave_solve6_core(m, x, flavour);
+        wave_solve6_core(m, x, flavour, mode != "solve_search");   // solve_search: the per-step pivot search also where the static order applies
       }
       for (int k = 0; k < 6; ++k) xs[lane][k] = x[k];
     });

@@ -48,6 +48,7 @@ def test_full_rank_solve_agrees_with_ldlt(harness, ob):
     X = device_solve(harness, systems)
     Xr = device_solve(harness, systems, mode="solve_reg")
     assert np.array_equal(X, Xr)                       # inputs handed over in registers: the same solve
+    assert np.array_equal(X, device_solve(harness, systems, mode="solve_search"))   # static pivot order == per-step search, bit for bit
     for (H, b), x in zip(systems, X):
         xo = ob.ldlt_solve6(H, b)
         c = np.linalg.cond(H)
@@ -72,6 +73,7 @@ def test_rank_deficient_solve_returns_eigens_zero_components(harness, ob):
             H, b = J.T @ J, J.T @ rng.normal(0, 1, rank)
         systems.append((H, b)); ranks.append(rank)
     X = device_solve(harness, systems)
+    assert np.array_equal(X, device_solve(harness, systems, mode="solve_search"), equal_nan=True)   # zero-pivot rules included
     checked = 0
     for (H, b), rank, x in zip(systems, ranks, X):
         xm, xo = wave_solve6_model(H, b), ob.ldlt_solve6(H, b)
@@ -97,6 +99,7 @@ def test_special_systems_and_the_330_rule(harness, ob):
     systems = [(np.zeros((6, 6)), np.ones(6)), (np.full((6, 6), np.nan), nan6),
                (np.eye(6) * np.array([5.0, 4.0, 3.0, 2.0, 1.0, 0.5]) + 0.01, nan6), (Hinf, np.zeros(6)), (D, np.arange(6.0))]
     X = device_solve(harness, systems)
+    assert np.array_equal(X, device_solve(harness, systems, mode="solve_search"), equal_nan=True)
     assert np.array_equal(X[0], np.zeros(6))
     assert np.isnan(X[1][0]) and np.isnan(X[2][0])
     xo = ob.ldlt_solve6(Hinf, np.zeros(6))
