@@ -109,10 +109,15 @@ __host__ __device__ inline size_t align_chi_window_offset(int threads, int cap, 
   o += (size_t)cap * (sizeof(int2) + sizeof(float)) + (size_t)scap * sizeof(int) + ((size_t)2 * scap + 2) * sizeof(float);
   return (o + 15) & ~(size_t)15;
 }
+// the latency shapes' per-wave scratch follows the window / the planes: 64 slots x (32 B slot info + 56 B pixel sums) per wave
+__host__ __device__ inline size_t align_quad_offset(int threads, int cap, int scap, int chi_lds_pts) {
+  const size_t window = 1024 * sizeof(float), planes = (size_t)2 * chi_lds_pts * 16 * sizeof(float);
+  return (align_chi_window_offset(threads, cap, scap) + (planes > window ? planes : window) + 15) & ~(size_t)15;
+}
 // everything the kernel's own tables take
 __host__ __device__ inline size_t align_lds_used(int threads, int cap, int scap, int chi_lds_pts) {
-  const size_t window = 1024 * sizeof(float), planes = (size_t)2 * chi_lds_pts * 16 * sizeof(float);
-  return align_chi_window_offset(threads, cap, scap) + (planes > window ? planes : window) + 16;
+  const size_t quad = threads >= kQuadMinThreads ? (size_t)(threads / 64) * 64 * (32 + 56) : 0;
+  return align_quad_offset(threads, cap, scap, chi_lds_pts) + quad + 16;
 }
 // ------------------------------------------------------------------------------------------------
 // The chi2 the solver compares (`new_chi2 > chi2_`, [ext] vk::NLLSSolver::optimizeGaussNewton) is
@@ -335,6 +340,8 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
   int* s_dead = reinterpret_cast<int*>(s_abs + cap);                     // scap: per segment, 0 = alive, k + 1 = culled at iteration k of this level
   float* s_lterm = reinterpret_cast<float*>(s_dead + scap);              // 2 * scap + 2: exact chi2 term of every line, two iterations; the two sums
   float* s_win = reinterpret_cast<float*>(smem + align_chi_window_offset(T, cap, scap));   // 1024: two 32-slot windows of chi_terms, or the two planes themselves (chi_lds_pts)
+  constexpr bool kQuad = T >= kQuadMinThreads;
+  unsigned char* const s_quad = kQuad ? smem + align_quad_offset(T, cap, scap, b.chi_lds_pts) : smem;   // latency shapes: per-wave scratch of the quad pass
 
 #ifdef PLSVO_TIMING
   __shared__ unsigned long long s_time[8];
@@ -454,7 +461,30 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
     if (my_patches) atomicAdd(&s_ctl[5], my_patches);   // integer count: order-independent
     block_sync<T>();  // patch_uvref / patch_xyz (global) and s_meta (LDS) visible to the workgroup
 
-    // ---- reference patches (:236-264, :348-375): the byte record the iterations rebuild intensity and gradient from ----
+    // ---- reference patches (:236-264, :348-375) ----
+    if constexpr (kQuad) {
+      // latency shapes: interpolated intensity and central-difference gradient as FLOAT rows -- lane `row` of the slot's four writes
+      // {ref[4], dx[4], dy[4]} of patch row `row` (48 B; the precompute's own operations, align_refpatch.hpp::ref_row_direct, bit-identical to
+      // what the throughput shapes rebuild from their byte record: tests/test_refpatch_host.py) -- which the row's lane reads back every iteration
+      for (int pb = 0; pb < n_slots; pb += T / 4) {
+        const int p = pb + grp;
+        if (p < n_slots && s_meta[p].x != SLOT_HOLE) {
+          const float u = b.patch_uvref[2 * (pbase + p)], v = b.patch_uvref[2 * (pbase + p) + 1];
+          const PatchW pw = patch_weights(u, v);
+          float I[4][7];   // image rows vi-3+row .. vi+row, columns ui-3 .. ui+3
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const uint2 raw = load_row8_raw<false>(ref_img, pitch, pw.ui - 3, pw.vi - 3 + row + rr);
+            unpack_row7(raw.x, raw.y, I[rr]);
+          }
+          float4 vr, vx, vy;
+          ref_row_direct(I, pw.wTL, pw.wTR, pw.wBL, pw.wBR, vr, vx, vy);
+          float4* const dst = reinterpret_cast<float4*>(b.cache_ref) + ((pbase + p) * 4 + row) * 3;
+          dst[0] = vr; dst[1] = vx; dst[2] = vy;
+        }
+      }
+    } else {
+    // throughput shapes: the byte record the iterations rebuild intensity and gradient from
     for (int pb = 0; pb < n_slots; pb += T / 4) {
       const int p = pb + grp;
       if (p < n_slots && s_meta[p].x != SLOT_HOLE) {
@@ -467,6 +497,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
         if (row < 3) *reinterpret_cast<uint2*>(rec + 8 * (row + 4)) = load_row8_raw<kTiled>(ref_img, pitch, cx, ry + 4);
         else *reinterpret_cast<float2*>(rec + 56) = make_float2(u - floorf(u), v - floorf(v));
       }
+    }
     }
     if (tid == 0) { SE3d m = se3_load(s_pose + 12); quat_to_matrix(m.q, s_pose); s_pose[9] = m.t[0]; s_pose[10] = m.t[1]; s_pose[11] = m.t[2]; }
     block_sync<T>();  // slot tables, pose state and cache complete
@@ -507,6 +538,219 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
         const bool write_abs = (!long_lines || pass == 0) && !terms_only;
         const bool accumulate = pass == 1 && !terms_only;
         const int n_rounds_slots = terms_only ? min(n_slots, job.n_pts) : n_slots;   // a terms-only re-run visits the point slots only
+
+        if constexpr (kQuad) {
+        // ---- the pieces of the latency shape's pass ----
+        // the sums over a patch's pixels, in the reference's pixel order: A = sum w dx^2, B = sum w dx dy, C = sum w dy^2, D = sum w res dx,
+        // E = sum w res dy (points: w = robust weight; line pixels: w = 1), the chi2 terms and sum |res|
+        struct PixSums { double A, B, C, D, E, Chi; float Abs; };
+        auto unpack5 = [](uint32_t lo, uint32_t hi, int sh, float* o) {
+          const uint32_t w0 = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)sh);
+          o[0] = (float)(w0 & 0xffu); o[1] = (float)((w0 >> 8) & 0xffu); o[2] = (float)((w0 >> 16) & 0xffu); o[3] = (float)(w0 >> 24);
+          o[4] = (float)((hi >> (8 * sh)) & 0xffu);
+        };
+        // one patch row = four pixels.  WEIGHTED is decided per wave: the slot table lists points first, then line samples, so most rounds
+        // are homogeneous and the line-only ones skip the robust weight and the chi2 term.
+        // (a packed-FP32 form of this loop, two pixels per v_pk_* instruction, was measured 12 % slower)
+        // (every POINT pixel's chi2 term res*res*w goes to this iteration's plane of chi_terms, one float4 per patch row: what
+        //  exact_chi2_pair re-adds in the reference's order on a near tie)
+        auto row4 = [&](auto WEIGHTED, bool is_point, const PatchW& pw, const float* top, const float* bot, const float4& r4, const float4& x4,
+                        const float4& y4, float4& tv4, PixSums& ps) {
+          constexpr bool weighted = decltype(WEIGHTED)::value;
+          const float* pr = reinterpret_cast<const float*>(&r4);
+          const float* pxp = reinterpret_cast<const float*>(&x4);
+          const float* pyp = reinterpret_cast<const float*>(&y4);
+          float* tv = reinterpret_cast<float*>(&tv4);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const float c = bilinear(pw.wTL, pw.wTR, pw.wBL, pw.wBR, top[x], top[x + 1], bot[x], bot[x + 1]);
+            const float res = __fsub_rn(c, pr[x]);
+            const float ares = fabsf(res);
+            const double rd = (double)res, dx = (double)pxp[x], dy = (double)pyp[x];
+            if (weighted) {
+              // points: w = 1/(1+|r|) (:479); line pixels are accumulated unweighted (:627-629)
+              const float w = is_point ? robust_weight(ares) : 1.0f;
+              const double wd = (double)w;
+              const double wdx = wd * dx, wdy = wd * dy;
+              ps.A += wdx * dx; ps.B += wdx * dy; ps.C += wdy * dy;
+              ps.D += wdx * rd; ps.E += wdy * rd;
+              const float term = __fmul_rn(__fmul_rn(res, res), w);      // :484  chi2 += res*res*weight (float)
+              ps.Chi += (double)term;
+              tv[x] = is_point ? term : ares;
+            } else {
+              ps.A += dx * dx; ps.B += dx * dy; ps.C += dy * dy;
+              ps.D += dx * rd; ps.E += dy * rd;
+              tv[x] = ares;
+            }
+            ps.Abs += ares;
+          }
+        };
+        // The chi2 terms of a POINT slot (16 floats = 64 contiguous bytes) go to this iteration's plane of chi_terms, row by row (written
+        // while the solver is armed or a near tie is being re-run; line pixels are not stored: every byte written costs its time).
+        // (two explicit address spaces: one generic pointer would make these flat stores, which also wait for the LDS counter)
+        auto chi_store = [&](int p_, int r, const float4& t) {
+          const plsvo_v4f t4 = { t.x, t.y, t.z, t.w };
+          if (b.chi_lds_pts > 0) ((PLSVO_LDS plsvo_v4f*)(s_win + (iter & 1) * b.chi_lds_pts * 16 + p_ * 16))[r] = t4;   // small batches: the planes are in LDS (kernel-uniform)
+          else ((PLSVO_GLOBAL plsvo_v4f*)(chi_it + (unsigned)(p_ * 16)))[r] = t4;                                         // wave-uniform base + 32-bit lane offset
+        };
+        // what follows a slot's pixel sums: the weights -- points 1; a line's samples share w / mean|res| (H) and w (Jres), :640-688 -- and
+        // the slot's 6x6 contribution.  Called by every lane of the wave (wave-uniform branches and a wave-level LDS fence inside).
+        auto slot_finish = [&](int p, const int2& meta, bool is_line, bool cand, bool live, double X, double Y, double Z, const PixSums& ps) {
+          double wh = 0.0, wj = 0.0;
+          if (__any(is_line && cand)) {   // wave-uniform
+            if (write_abs) {
+              if (is_line && cand) s_abs[p] = live ? ps.Abs : -1.0f;
+              wave_lds_fence();   // all samples of a line sit in this wave's round (host layout); two-pass levels: see the barrier below
+            }
+            if (accumulate && is_line && cand) {
+              const int first = meta.y & 0xfffff, N = meta.y >> 20;
+              bool good = true; float sum = 0.0f;
+              for (int n = 0; n < N; ++n) { const float a = s_abs[first + n]; good = good && (a >= 0.0f); sum += a; }
+              const float res_ = (float)((double)sum / (double)N);                 // :647 (divides by #samples)
+              if (good && (double)res_ < 200.0) {                                  // :648
+                const float w = (float)(1.0 / (1.0 + (double)res_));               // :675
+                wh = (double)w / (double)res_;                                     // :681  H += H_ * w / res_
+                wj = (double)w;                                                    // :682  Jres += Jres_ * w
+                if (p == first) {                                                  // :683-684
+                  const float term = __fmul_rn(__fmul_rn(res_, res_), w);
+                  acc[27] += (double)term; acc[28] += 1.0;
+                  s_lterm[(iter & 1) * scap + (-1 - meta.x)] = term;               // this iteration's plane (exact_chi2_pair)
+                }
+              } else if (p == first) {
+                s_dead[-1 - meta.x] = iter + 1;                                    // :687-688 it->feat3D = NULL
+                b.seg_alive[job.seg_off + (-1 - meta.x)] = 0;
+              }
+            }
+          }
+          if (accumulate) {
+            if (!is_line && live) {
+              wh = 1.0; wj = 1.0;
+              acc[27] += ps.Chi; acc[28] += (double)PLSVO_PATCH_AREA;
+            }
+            if (live) { acc[29] += 1.0; if (!is_line && store_chi && b.chi_lds_pts == 0) acc[30] += 1.0; }
+            // -- 6x6 expansion: sum_pix w J J^T = fs^2 (r0 (A r0 + B r1)^T + r1 (B r0 + C r1)^T), sum_pix w res J = fs (D r0 + E r1)
+            if (wh != 0.0 || wj != 0.0) {
+              const double xyz[3] = { X, Y, Z };
+              double J[12];
+              jacobian_xyz2uv(xyz, J);
+              const double hs = wh * fs * fs, js = wj * fs;
+              const double hA = ps.A * hs, hB = ps.B * hs, hC = ps.C * hs, jD = ps.D * js, jE = ps.E * js;
+              double v0[6], v1[6];
+#pragma unroll
+              for (int k = 0; k < 6; ++k) { v0[k] = hA * J[k] + hB * J[6 + k]; v1[k] = hB * J[k] + hC * J[6 + k]; }
+              int k = 0;
+#pragma unroll
+              for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int jj = i; jj < 6; ++jj) { acc[k] += J[i] * v0[jj] + J[6 + i] * v1[jj]; ++k; }
+#pragma unroll
+              for (int i = 0; i < 6; ++i) acc[21 + i] -= jD * J[i] + jE * J[6 + i];
+            }
+          }
+        };
+        // warp + project a slot's 3-D point (:422-431, :583-594); the pose is re-read from LDS (twelve doubles that would otherwise stay in
+        // registers across the whole pass); Patch::isInFrame(halfsize=2) on floorf(u), floorf(v); NaN -> out of frame
+        auto project = [&](bool cand_, double X, double Y, double Z, float& u, float& v) -> bool {
+          const PLSVO_LDS double* const pq = (const PLSVO_LDS double*)pose_rt;
+          const double x_cam = pq[0] * X + pq[1] * Y + pq[2] * Z + pq[9];
+          const double y_cam = pq[3] * X + pq[4] * Y + pq[5] * Z + pq[10];
+          const double z_cam = pq[6] * X + pq[7] * Y + pq[8] * Z + pq[11];
+          u = (float)((job.fx * (x_cam / z_cam) + job.cx) * scale);
+          v = (float)((job.fy * (y_cam / z_cam) + job.cy) * scale);
+          return cand_ && (u >= 2.0f) && (v >= 2.0f) && (u < colmax) && (v < rowmax);
+        };
+
+          // LATENCY SHAPE (a frame owns a CU): FOUR LANES PER SLOT for the pixel arithmetic.  With a lane per slot a 512-thread workgroup
+          // spends a whole wave-round (~1800 instructions) on however few slots a wave holds -- 375 slots leave a quarter of the lanes idle,
+          // 544 cost one wave a second round for 32 slots -- and the two waves of a SIMD serialise on its issue port (measured, one frame:
+          // pass 9.5 k cycles + 5-6 k waiting for the partner wave of 25 k per iteration, profiles/r05a_phase_ticks_b1.log).  Here a wave
+          // takes UNITS of 64 slots: (A) a lane per slot projects the point and parks {window offset, flags, bilinear weights} in the wave's
+          // LDS scratch; (B) four quad-rounds of 16 slots: lane 4s+r evaluates patch row r of slot s -- two image rows, its 48 bytes of the
+          // float cache (reference intensity + gradient of ITS row, written once per level) -- and the quad adds its sums by DPP; empty
+          // quad-rounds are skipped; (C) the lane per slot again: line weights and the 6x6 expansion.  Only wave-level fences inside.
+          constexpr int NW = T / 64;
+          uint4* const q_info = reinterpret_cast<uint4*>(s_quad) + wave * 128;                                   // 32 B per slot of the unit
+          double* const q_sum = reinterpret_cast<double*>(s_quad + NW * 64 * 32) + wave * (64 * 7);              // 56 B per slot of the unit
+          const float4* const cache_f = reinterpret_cast<const float4*>(b.cache_ref);
+          const int n_units = (n_rounds_slots + 63) >> 6;
+          for (int unit = wave; unit < n_units; unit += NW) {
+            // -- (A) lane per slot
+            const int p = unit * 64 + lane;
+            int2 meta = make_int2(SLOT_HOLE, 0);
+            if (p < n_slots) meta = s_meta[p];
+            const bool hole = meta.x == SLOT_HOLE;
+            const bool is_line = !hole && meta.x < 0;
+            bool cand = !hole && p < n_rounds_slots;
+            if (cand && is_line && s_dead[-1 - meta.x]) cand = false;   // line culled at an earlier iteration of this level
+            double X = 0.0, Y = 0.0, Z = 1.0;
+            if (cand) { X = pxyz[3 * p]; Y = pxyz[3 * p + 1]; Z = pxyz[3 * p + 2]; }
+            float u, v;
+            const bool live = project(cand, X, Y, Z, u, v);
+            const bool chi_slot = (accumulate || terms_only) && store_chi && p < job.n_pts;
+            {
+              PatchW pw = { 0, 0, 0.f, 0.f, 0.f, 0.f };
+              if (live) pw = patch_weights(u, v);
+              const int off = (pw.vi - 2) * pitch + (pw.ui - 2);
+              const int flags = (live ? 1 : 0) | ((!is_line && !hole) ? 2 : 0) | (chi_slot ? 4 : 0);
+              q_info[2 * lane] = make_uint4((uint32_t)off, (uint32_t)flags, __float_as_uint(pw.wTL), __float_as_uint(pw.wTR));
+              q_info[2 * lane + 1] = make_uint4(__float_as_uint(pw.wBL), __float_as_uint(pw.wBR), 0u, 0u);
+            }
+            wave_lds_fence();
+            const unsigned long long need = __ballot(live || chi_slot);
+            // -- (B) four lanes per slot, sixteen slots per quad-round
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+              if (((need >> (16 * q)) & 0xffffull) == 0ull) continue;   // wave-uniform
+              const int sl = 16 * q + (lane >> 2), r = lane & 3;
+              const uint4 i0 = q_info[2 * sl], i1 = q_info[2 * sl + 1];
+              const int pq_ = unit * 64 + sl;
+              const bool live_q = (i0.y & 1u) != 0, point_q = (i0.y & 2u) != 0, chi_q = (i0.y & 4u) != 0;
+              const bool any_point = __any(live_q && point_q) != 0;   // wave-uniform
+              PixSums ps = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0f };
+              float4 chi_t = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (live_q) {
+                PatchW pw;
+                pw.ui = 0; pw.vi = 0;
+                pw.wTL = __uint_as_float(i0.z); pw.wTR = __uint_as_float(i0.w); pw.wBL = __uint_as_float(i1.x); pw.wBR = __uint_as_float(i1.y);
+                const int o0 = (int)i0.x + r * pitch, o1 = o0 + pitch;     // image rows vi-2+r and vi-1+r of the 5x5 window, from column ui-2
+                const uint32_t lo0 = *reinterpret_cast<const uint32_t*>(cur_img + (o0 & ~3)), hi0 = *reinterpret_cast<const uint32_t*>(cur_img + (o0 & ~3) + 4);
+                const uint32_t lo1 = *reinterpret_cast<const uint32_t*>(cur_img + (o1 & ~3)), hi1 = *reinterpret_cast<const uint32_t*>(cur_img + (o1 & ~3) + 4);
+                const float4* const cf = cache_f + ((pbase + pq_) * 4 + r) * 3;
+                const float4 r4 = cf[0], x4 = cf[1], y4 = cf[2];
+                float top[5], bot[5];
+                unpack5(lo0, hi0, o0 & 3, top);
+                unpack5(lo1, hi1, o1 & 3, bot);
+                if (any_point) row4(std::true_type{}, point_q, pw, top, bot, r4, x4, y4, chi_t, ps);
+                else row4(std::false_type{}, point_q, pw, top, bot, r4, x4, y4, chi_t, ps);
+              }
+              if (chi_q) chi_store(pq_, r, chi_t);   // (a patch outside the current image contributes nothing, :432-433: +0)
+              // the quad's totals: rows 0+1 and 2+3 first, then the two halves (double: 1e-16 of the sequential sum; the line residual's
+              // float sum carries ~1e-7 of its own either way)
+              ps.A = quad_sum(ps.A); ps.B = quad_sum(ps.B); ps.C = quad_sum(ps.C); ps.D = quad_sum(ps.D); ps.E = quad_sum(ps.E);
+              ps.Chi = quad_sum(ps.Chi);
+              ps.Abs += dpp_mov_f32<DPP_QUAD_XOR1>(ps.Abs);
+              ps.Abs += dpp_mov_f32<DPP_QUAD_XOR2>(ps.Abs);
+              if (live_q && r == 0) {
+                double* const d = q_sum + sl * 7;
+                d[0] = ps.A; d[1] = ps.B; d[2] = ps.C; d[3] = ps.D; d[4] = ps.E; d[5] = ps.Chi;
+                reinterpret_cast<float*>(d + 6)[0] = ps.Abs;
+              }
+            }
+            wave_lds_fence();
+            // -- (C) lane per slot: weights and expansion
+            if (!terms_only) {
+              PixSums ps = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0f };
+              if (live) {
+                const double* const d = q_sum + lane * 7;
+                ps.A = d[0]; ps.B = d[1]; ps.C = d[2]; ps.D = d[3]; ps.E = d[4]; ps.Chi = d[5];
+                ps.Abs = reinterpret_cast<const float*>(d + 6)[0];
+              }
+              slot_finish(p, meta, is_line, cand, live, X, Y, Z, ps);
+            }
+            wave_lds_fence();   // the unit's scratch is free again
+          }
+        } else {
+        // THROUGHPUT SHAPE (unchanged since round 4; its 255-256 registers leave no room for another formulation of the same code)
         // ONE LANE PER SLOT.  Per round a lane (a) reads its table entry and 3-D point, (b) warps and projects the point and requests the
         // 5x5 window of the current image (five rows, two aligned dwords each), (c) reads the four cached rows of reference intensity and
         // gradient, then evaluates the 16 pixels row by row -- the sums over a patch in the reference's own pixel order -- exchanges the
@@ -734,6 +978,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
             }
           }
         }
+        }
         if (long_lines && pass == 0) block_sync<T>();   // every sample's |res| sum is in LDS before any line is weighted
       }
       TICK(1);
@@ -756,7 +1001,9 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
         if (lane < 32 && !terms_only) s_tot[lane] = tot;   // (0..26 the system, 27..30 chi2 / n_meas / work counters: a terms-only re-run reads them back)
         TICK(3);
         double x[6];
-        wave_solve6_reg(tot, x, job.ldlt_flavour);                             // solve() :699
+        // (static pivot order in the latency shapes only: the throughput shapes sit at 255-256 registers without scratch, and the few
+        //  values the shorter solve keeps live across the iteration tip them into spilling -- there the solve is 2 % of a launch)
+        wave_solve6_reg(tot, x, job.ldlt_flavour, kQuad);                      // solve() :699
         TICK(4);
         const double chi_sum = readlane_f64(tot, 27), nm_d = readlane_f64(tot, 28), ev_d = readlane_f64(tot, 29), ev_pt = readlane_f64(tot, 30);
         const unsigned long long nm = (unsigned long long)(nm_d + 0.5);

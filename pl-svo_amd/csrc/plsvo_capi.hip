@@ -107,6 +107,7 @@ struct plsvo_ctx {
   int a_trace_cap = 0;
   DevBuf a_d_state, a_d_alive;   // (inputs: a_d_blob)
   DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_chi, a_d_log, a_d_poses;
+  size_t a_patch_total = 0;                 // patch slots of the staged batch (all jobs, all levels' maximum)
   AlignBatchDev a_b{};
 
   // pose-opt batch
@@ -584,7 +585,8 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   const size_t pt = std::max(patch_total, (size_t)4);
   HIP_TRY(c, c->a_d_pxyz.ensure(pt * 3 * sizeof(double)));
   HIP_TRY(c, c->a_d_puv.ensure(pt * 2 * sizeof(float)));
-  HIP_TRY(c, c->a_d_cref.ensure(pt * 64));   // one 64-byte record per patch slot
+  HIP_TRY(c, c->a_d_cref.ensure(pt * 64));   // one 64-byte record per patch slot (latency shapes: 192 B of float rows, sized in plsvo_align_run)
+  c->a_patch_total = pt;
   const size_t npt_total = ptpx.size() / 2 + 32;
   HIP_TRY(c, c->a_d_chi.ensure(2 * npt_total * 16 * sizeof(float)));   // two planes of the points' per-pixel chi2 terms
   if (c->a_trace_cap > 0) HIP_TRY(c, c->a_d_log.ensure((size_t)n * c->a_trace_cap * sizeof(plsvo_align_iterlog)));
@@ -677,6 +679,10 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
   pick_align_config(c, c->a_n, cap, scap, max_pts, &threads, &lds, &chi_lds_pts);
   c->a_b.chi_lds_pts = chi_lds_pts;
   if (lds > c->lds_per_block) return fail(c, PLSVO_E_CAPACITY, "align_run: slot tables do not fit in LDS (too many features in one job)");
+  if (threads >= kQuadMinThreads) {   // latency shapes keep the reference patches as float rows: 192 B per slot (small batches only: <= 4 frames per CU)
+    HIP_TRY(c, c->a_d_cref.ensure(c->a_patch_total * 192));
+    c->a_b.cache_ref = c->a_d_cref.as<float>();
+  }
   const bool per_level = c->env_align_per_level;
   if (!per_level || !have_levels) {
     EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);

@@ -48,6 +48,10 @@ __device__ __forceinline__ int tiled_row_offset(int tiles_x, int y) { return (((
 __device__ __forceinline__ int tiled_col_offset(int x) { return ((x >> 4) << 7) + (x & 15); }
 #endif
 
+// alignment launch shapes from this many threads per frame on are LATENCY shapes (a frame owns most of a CU): four lanes per slot in the
+// pixel pass, the reference patches kept as FLOAT rows (192 B per slot, L2-resident) instead of the 64-byte record the throughput shapes rebuild
+constexpr int kQuadMinThreads = 256;
+
 struct PyrDesc {
   const uint8_t* base;
   unsigned long long slot_bytes;
@@ -107,7 +111,8 @@ struct AlignBatchDev {
   // per-level patch cache (capacity = sum over jobs of patch_cap slots)
   double* patch_xyz;           // 3 per slot: 3-D point in the ref frame
   float* patch_uvref;          // 2 per slot: ref pixel position at the level (float, as Patch::setPosition)
-  float* cache_ref;            // 64 bytes per slot: the reference patch's byte record (7 rows of 8 image bytes + the two sub-pixel fractions, align_refpatch.hpp)
+  float* cache_ref;            // 64 bytes per slot: the reference patch's byte record (7 rows of 8 image bytes + the two sub-pixel fractions, align_refpatch.hpp);
+                               // latency shapes (>= kQuadMinThreads threads per frame): 192 bytes per slot, four rows of {ref[4], dx[4], dy[4]} floats
   // per-pixel terms of the solver's chi2 for the POINT features, double-buffered by iteration parity (plane 0 / 1, chi_plane
   // floats apart): 16 per point of the batch, res*res*w (src/sparse_img_align.cpp:484).  Written by every iteration, read only when
   // two successive chi2 values are too close for the double-precision sums to order them the way the reference's sequential

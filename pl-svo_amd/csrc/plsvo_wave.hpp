@@ -178,13 +178,13 @@ __device__ __forceinline__ void wave_solve6(const double* tot, double* x) {
 }
 
 // the same, with the 27 inputs held in registers: lane k (k < 27) passes tot[k] in `tot_lane`
-__device__ __forceinline__ void wave_solve6_reg(double tot_lane, double* x, int flavour = 320) {
+__device__ __forceinline__ void wave_solve6_reg(double tot_lane, double* x, int flavour = 320, bool allow_static_order = true) {
   const int lane = threadIdx.x & 63;
   const int i = lane >> 3, j = lane & 7;
   const int src = (i < 6 && j < 6) ? sym6_index(i, j) : ((i < 6 && j == 6) ? 21 + i : 0);
   double m = __shfl(tot_lane, src, 64);
   if (!(i < 6 && j <= 6)) m = 0.0;
-  wave_solve6_core(m, x, flavour);
+  wave_solve6_core(m, x, flavour, allow_static_order);
 }
 
 __device__ __forceinline__ double bpermute_f64(int byte_addr, double v) {
