@@ -116,7 +116,8 @@ __host__ __device__ inline size_t align_quad_offset(int threads, int cap, int sc
 }
 // everything the kernel's own tables take
 __host__ __device__ inline size_t align_lds_used(int threads, int cap, int scap, int chi_lds_pts) {
-  const size_t quad = threads >= kQuadMinThreads ? (size_t)(threads / 64) * 64 * (32 + 56) : 0;
+  // latency shapes: the per-wave scratch, then every slot's 3-D point (24 B) and reference pixel position (8 B) -- global arrays in the throughput shapes
+  const size_t quad = threads >= kQuadMinThreads ? (size_t)(threads / 64) * 64 * (32 + 56) + (size_t)cap * 32 : 0;
   return align_quad_offset(threads, cap, scap, chi_lds_pts) + quad + 16;
 }
 // ------------------------------------------------------------------------------------------------
@@ -342,6 +343,8 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
   float* s_win = reinterpret_cast<float*>(smem + align_chi_window_offset(T, cap, scap));   // 1024: two 32-slot windows of chi_terms, or the two planes themselves (chi_lds_pts)
   constexpr bool kQuad = T >= kQuadMinThreads;
   unsigned char* const s_quad = kQuad ? smem + align_quad_offset(T, cap, scap, b.chi_lds_pts) : smem;   // latency shapes: per-wave scratch of the quad pass
+  double* const s_xyz = reinterpret_cast<double*>(s_quad + (T / 64) * 64 * (32 + 56));                  //   cap x 3: every slot's 3-D point (ref frame)
+  float* const s_uvr = reinterpret_cast<float*>(s_xyz + 3 * (kQuad ? cap : 0));                         //   cap x 2: every slot's reference pixel position at the level
 
 #ifdef PLSVO_TIMING
   __shared__ unsigned long long s_time[8];
@@ -416,11 +419,16 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
         const float u = (float)(b.pt_px[2 * i] * scale), v = (float)(b.pt_px[2 * i + 1] * scale);
         if (u >= 3.0f && v >= 3.0f && u < (float)(W - 3) && v < (float)(Hh - 3)) {
           s_meta[f] = make_int2(f, f | (1 << 20));
+          if constexpr (kQuad) {
+            s_uvr[2 * f] = u; s_uvr[2 * f + 1] = v;
+            s_xyz[3 * f] = b.pt_xyz[3 * i]; s_xyz[3 * f + 1] = b.pt_xyz[3 * i + 1]; s_xyz[3 * f + 2] = b.pt_xyz[3 * i + 2];
+          } else {
           b.patch_uvref[2 * (pbase + f)] = u;
           b.patch_uvref[2 * (pbase + f) + 1] = v;
           pxyz[3 * f] = b.pt_xyz[3 * i];
           pxyz[3 * f + 1] = b.pt_xyz[3 * i + 1];
           pxyz[3 * f + 2] = b.pt_xyz[3 * i + 2];
+          }
           ++my_patches;
         }
       } else {
@@ -446,11 +454,16 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
           for (int n = 0; n < N; ++n) {
             const int p = p0 + n;
             s_meta[p] = make_int2(-1 - sl, p0 | (N << 20));
+            if constexpr (kQuad) {
+              s_uvr[2 * p] = (float)px; s_uvr[2 * p + 1] = (float)py;
+              s_xyz[3 * p] = xr[0]; s_xyz[3 * p + 1] = xr[1]; s_xyz[3 * p + 2] = xr[2];
+            } else {
             b.patch_uvref[2 * (pbase + p)] = (float)px;
             b.patch_uvref[2 * (pbase + p) + 1] = (float)py;
             pxyz[3 * p] = xr[0];
             pxyz[3 * p + 1] = xr[1];
             pxyz[3 * p + 2] = xr[2];
+            }
             px += inc2x; py += inc2y;
             xr[0] += inc3[0]; xr[1] += inc3[1]; xr[2] += inc3[2];
           }
@@ -469,7 +482,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
       for (int pb = 0; pb < n_slots; pb += T / 4) {
         const int p = pb + grp;
         if (p < n_slots && s_meta[p].x != SLOT_HOLE) {
-          const float u = b.patch_uvref[2 * (pbase + p)], v = b.patch_uvref[2 * (pbase + p) + 1];
+          const float u = s_uvr[2 * p], v = s_uvr[2 * p + 1];
           const PatchW pw = patch_weights(u, v);
           float I[4][7];   // image rows vi-3+row .. vi+row, columns ui-3 .. ui+3
 #pragma unroll
@@ -595,7 +608,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
         };
         // what follows a slot's pixel sums: the weights -- points 1; a line's samples share w / mean|res| (H) and w (Jres), :640-688 -- and
         // the slot's 6x6 contribution.  Called by every lane of the wave (wave-uniform branches and a wave-level LDS fence inside).
-        auto slot_finish = [&](int p, const int2& meta, bool is_line, bool cand, bool live, double X, double Y, double Z, const PixSums& ps) {
+        auto slot_finish = [&](int p, const int2& meta, bool is_line, bool cand, bool live, double X, double Y, double Z, double z_inv, const PixSums& ps) {
           double wh = 0.0, wj = 0.0;
           if (__any(is_line && cand)) {   // wave-uniform
             if (write_abs) {
@@ -630,9 +643,13 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
             if (live) { acc[29] += 1.0; if (!is_line && store_chi && b.chi_lds_pts == 0) acc[30] += 1.0; }
             // -- 6x6 expansion: sum_pix w J J^T = fs^2 (r0 (A r0 + B r1)^T + r1 (B r0 + C r1)^T), sum_pix w res J = fs (D r0 + E r1)
             if (wh != 0.0 || wj != 0.0) {
-              const double xyz[3] = { X, Y, Z };
+              // Frame::jacobian_xyz2uv (include/plsvo/frame.h:138-160) with its z_inv = 1. / z handed in (plsvo_math.hpp::jacobian_xyz2uv: the same operations)
               double J[12];
-              jacobian_xyz2uv(xyz, J);
+              {
+                const double z_inv_2 = z_inv * z_inv;
+                J[0] = -z_inv; J[1] = 0.0; J[2] = X * z_inv_2; J[3] = Y * J[2]; J[4] = -(1.0 + X * J[2]); J[5] = Y * z_inv;
+                J[6] = 0.0; J[7] = -z_inv; J[8] = Y * z_inv_2; J[9] = 1.0 + Y * J[8]; J[10] = -J[3]; J[11] = -X * z_inv;
+              }
               const double hs = wh * fs * fs, js = wj * fs;
               const double hA = ps.A * hs, hB = ps.B * hs, hC = ps.C * hs, jD = ps.D * js, jE = ps.E * js;
               double v0[6], v1[6];
@@ -673,7 +690,35 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
           double* const q_sum = reinterpret_cast<double*>(s_quad + NW * 64 * 32) + wave * (64 * 7);              // 56 B per slot of the unit
           const float4* const cache_f = reinterpret_cast<const float4*>(b.cache_ref);
           const int n_units = (n_rounds_slots + 63) >> 6;
+          const int r = lane & 3, qs = lane >> 2;       // phase B: patch row and slot (inside the quad-round) of this lane
           for (int unit = wave; unit < n_units; unit += NW) {
+            // what phase B reads from memory, requested a quad-round (the float rows: two) ahead of its arithmetic
+            struct QRows { float4 r4, x4, y4; };
+            struct QWin { uint4 i0, i1; uint32_t lo0, hi0, lo1, hi1; int sh0, sh1; };
+            auto load_rows = [&](int q) -> QRows {          // the slot's cached patch row r: does not depend on the pose
+              QRows c;
+              c.r4 = make_float4(0.f, 0.f, 0.f, 0.f); c.x4 = c.r4; c.y4 = c.r4;
+              const int pq_ = unit * 64 + 16 * q + qs;
+              if (pq_ < n_rounds_slots) {
+                const float4* const cf = cache_f + ((pbase + pq_) * 4 + r) * 3;
+                c.r4 = cf[0]; c.x4 = cf[1]; c.y4 = cf[2];
+              }
+              return c;
+            };
+            auto load_win = [&](int q) -> QWin {            // what phase A parked for the slot + image rows vi-2+r, vi-1+r of its 5x5 window
+              QWin w;
+              const int sl = 16 * q + qs;
+              w.i0 = q_info[2 * sl]; w.i1 = q_info[2 * sl + 1];
+              w.lo0 = 0u; w.hi0 = 0u; w.lo1 = 0u; w.hi1 = 0u; w.sh0 = 0; w.sh1 = 0;
+              if (w.i0.y & 1u) {
+                const int o0 = (int)w.i0.x + r * pitch, o1 = o0 + pitch;
+                w.sh0 = o0 & 3; w.sh1 = o1 & 3;
+                w.lo0 = *reinterpret_cast<const uint32_t*>(cur_img + (o0 & ~3)); w.hi0 = *reinterpret_cast<const uint32_t*>(cur_img + (o0 & ~3) + 4);
+                w.lo1 = *reinterpret_cast<const uint32_t*>(cur_img + (o1 & ~3)); w.hi1 = *reinterpret_cast<const uint32_t*>(cur_img + (o1 & ~3) + 4);
+              }
+              return w;
+            };
+            QRows rows_cur = load_rows(0);                  // (under phase A's arithmetic)
             // -- (A) lane per slot
             const int p = unit * 64 + lane;
             int2 meta = make_int2(SLOT_HOLE, 0);
@@ -683,7 +728,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
             bool cand = !hole && p < n_rounds_slots;
             if (cand && is_line && s_dead[-1 - meta.x]) cand = false;   // line culled at an earlier iteration of this level
             double X = 0.0, Y = 0.0, Z = 1.0;
-            if (cand) { X = pxyz[3 * p]; Y = pxyz[3 * p + 1]; Z = pxyz[3 * p + 2]; }
+            if (cand) { X = s_xyz[3 * p]; Y = s_xyz[3 * p + 1]; Z = s_xyz[3 * p + 2]; }
             float u, v;
             const bool live = project(cand, X, Y, Z, u, v);
             const bool chi_slot = (accumulate || terms_only) && store_chi && p < job.n_pts;
@@ -697,43 +742,43 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
             }
             wave_lds_fence();
             const unsigned long long need = __ballot(live || chi_slot);
-            // -- (B) four lanes per slot, sixteen slots per quad-round
+            // -- (B) four lanes per slot, sixteen slots per quad-round; the next round's window is in flight under this round's arithmetic
+            QWin win_cur = load_win(0);
+            const double z_inv = 1.0 / Z;          // (phase C's Jacobian: the division's latency goes under phase B)
 #pragma unroll 1
             for (int q = 0; q < 4; ++q) {
-              if (((need >> (16 * q)) & 0xffffull) == 0ull) continue;   // wave-uniform
-              const int sl = 16 * q + (lane >> 2), r = lane & 3;
-              const uint4 i0 = q_info[2 * sl], i1 = q_info[2 * sl + 1];
-              const int pq_ = unit * 64 + sl;
-              const bool live_q = (i0.y & 1u) != 0, point_q = (i0.y & 2u) != 0, chi_q = (i0.y & 4u) != 0;
-              const bool any_point = __any(live_q && point_q) != 0;   // wave-uniform
-              PixSums ps = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0f };
-              float4 chi_t = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (live_q) {
-                PatchW pw;
-                pw.ui = 0; pw.vi = 0;
-                pw.wTL = __uint_as_float(i0.z); pw.wTR = __uint_as_float(i0.w); pw.wBL = __uint_as_float(i1.x); pw.wBR = __uint_as_float(i1.y);
-                const int o0 = (int)i0.x + r * pitch, o1 = o0 + pitch;     // image rows vi-2+r and vi-1+r of the 5x5 window, from column ui-2
-                const uint32_t lo0 = *reinterpret_cast<const uint32_t*>(cur_img + (o0 & ~3)), hi0 = *reinterpret_cast<const uint32_t*>(cur_img + (o0 & ~3) + 4);
-                const uint32_t lo1 = *reinterpret_cast<const uint32_t*>(cur_img + (o1 & ~3)), hi1 = *reinterpret_cast<const uint32_t*>(cur_img + (o1 & ~3) + 4);
-                const float4* const cf = cache_f + ((pbase + pq_) * 4 + r) * 3;
-                const float4 r4 = cf[0], x4 = cf[1], y4 = cf[2];
-                float top[5], bot[5];
-                unpack5(lo0, hi0, o0 & 3, top);
-                unpack5(lo1, hi1, o1 & 3, bot);
-                if (any_point) row4(std::true_type{}, point_q, pw, top, bot, r4, x4, y4, chi_t, ps);
-                else row4(std::false_type{}, point_q, pw, top, bot, r4, x4, y4, chi_t, ps);
-              }
-              if (chi_q) chi_store(pq_, r, chi_t);   // (a patch outside the current image contributes nothing, :432-433: +0)
-              // the quad's totals: rows 0+1 and 2+3 first, then the two halves (double: 1e-16 of the sequential sum; the line residual's
-              // float sum carries ~1e-7 of its own either way)
-              ps.A = quad_sum(ps.A); ps.B = quad_sum(ps.B); ps.C = quad_sum(ps.C); ps.D = quad_sum(ps.D); ps.E = quad_sum(ps.E);
-              ps.Chi = quad_sum(ps.Chi);
-              ps.Abs += dpp_mov_f32<DPP_QUAD_XOR1>(ps.Abs);
-              ps.Abs += dpp_mov_f32<DPP_QUAD_XOR2>(ps.Abs);
-              if (live_q && r == 0) {
-                double* const d = q_sum + sl * 7;
-                d[0] = ps.A; d[1] = ps.B; d[2] = ps.C; d[3] = ps.D; d[4] = ps.E; d[5] = ps.Chi;
-                reinterpret_cast<float*>(d + 6)[0] = ps.Abs;
+              const QWin w = win_cur;
+              const QRows c = rows_cur;
+              if (q < 3) { rows_cur = load_rows(q + 1); win_cur = load_win(q + 1); }
+              if (((need >> (16 * q)) & 0xffffull) != 0ull) {   // wave-uniform: empty quad-rounds cost nothing
+                const int sl = 16 * q + qs;
+                const int pq_ = unit * 64 + sl;
+                const bool live_q = (w.i0.y & 1u) != 0, point_q = (w.i0.y & 2u) != 0, chi_q = (w.i0.y & 4u) != 0;
+                const bool any_point = __any(live_q && point_q) != 0;   // wave-uniform
+                PixSums ps = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0f };
+                float4 chi_t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live_q) {
+                  PatchW pw;
+                  pw.ui = 0; pw.vi = 0;
+                  pw.wTL = __uint_as_float(w.i0.z); pw.wTR = __uint_as_float(w.i0.w); pw.wBL = __uint_as_float(w.i1.x); pw.wBR = __uint_as_float(w.i1.y);
+                  float top[5], bot[5];
+                  unpack5(w.lo0, w.hi0, w.sh0, top);
+                  unpack5(w.lo1, w.hi1, w.sh1, bot);
+                  if (any_point) row4(std::true_type{}, point_q, pw, top, bot, c.r4, c.x4, c.y4, chi_t, ps);
+                  else row4(std::false_type{}, point_q, pw, top, bot, c.r4, c.x4, c.y4, chi_t, ps);
+                }
+                if (chi_q) chi_store(pq_, r, chi_t);   // (a patch outside the current image contributes nothing, :432-433: +0)
+                // the quad's totals: rows 0+1 and 2+3 first, then the two halves (double: 1e-16 of the sequential sum; the line residual's
+                // float sum carries ~1e-7 of its own either way)
+                ps.A = quad_sum(ps.A); ps.B = quad_sum(ps.B); ps.C = quad_sum(ps.C); ps.D = quad_sum(ps.D); ps.E = quad_sum(ps.E);
+                ps.Chi = quad_sum(ps.Chi);
+                ps.Abs += dpp_mov_f32<DPP_QUAD_XOR1>(ps.Abs);
+                ps.Abs += dpp_mov_f32<DPP_QUAD_XOR2>(ps.Abs);
+                if (live_q && r == 0) {
+                  double* const d = q_sum + sl * 7;
+                  d[0] = ps.A; d[1] = ps.B; d[2] = ps.C; d[3] = ps.D; d[4] = ps.E; d[5] = ps.Chi;
+                  reinterpret_cast<float*>(d + 6)[0] = ps.Abs;
+                }
               }
             }
             wave_lds_fence();
@@ -745,7 +790,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
                 ps.A = d[0]; ps.B = d[1]; ps.C = d[2]; ps.D = d[3]; ps.E = d[4]; ps.Chi = d[5];
                 ps.Abs = reinterpret_cast<const float*>(d + 6)[0];
               }
-              slot_finish(p, meta, is_line, cand, live, X, Y, Z, ps);
+              slot_finish(p, meta, is_line, cand, live, X, Y, Z, z_inv, ps);
             }
             wave_lds_fence();   // the unit's scratch is free again
           }
