@@ -84,11 +84,23 @@ __device__ __forceinline__ uint2 load_row8_raw(const uint8_t* img, int pitch, in
 }
 // optional per-phase timing (compile with -DPLSVO_TIMING): thread 0 accumulates s_memtime deltas
 #ifdef PLSVO_TIMING
-#define TICK(slot) do { if (tid == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); s_time[slot] += t__ - s_tlast; s_tlast = t__; } } while (0)
+#define TICK_RAW(slot) do { if (tid == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); s_time[slot] += t__ - s_tlast; s_tlast = t__; } } while (0)
+#if PLSVO_TIMING == 2
+// sub-phases of the latency shapes' pass (thread 0's wave): slot 1 = rest of the pass, 3 = phase A, 4 = phase B, 5 = phase C; everything after the pass -> slot 2
+#define TICK(slot) TICK_RAW((slot) >= 2 && (slot) <= 6 ? 2 : (slot))
+#define TICKQ(slot) TICK_RAW(slot)
+#else
+#define TICK(slot) TICK_RAW(slot)
+#define TICKQ(slot) do { } while (0)
+#endif
 #else
 #define TICK(slot) do { } while (0)
+#define TICKQ(slot) do { } while (0)
 #endif
 
+#ifndef PLSVO_Q_PIPE
+#define PLSVO_Q_PIPE 1   // latency shapes: phase B's loads requested a quad-round ahead (0: at the head of their own round; A/B builds)
+#endif
 #define SLOT_HOLE ((int)0x80000000)   // s_meta[p].x of a slot no live feature owns at this level
 
 // workgroup barrier; a one-wave workgroup needs only the wave-level form
@@ -742,14 +754,20 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
             }
             wave_lds_fence();
             const unsigned long long need = __ballot(live || chi_slot);
+            TICKQ(3);
             // -- (B) four lanes per slot, sixteen slots per quad-round; the next round's window is in flight under this round's arithmetic
             QWin win_cur = load_win(0);
             const double z_inv = 1.0 / Z;          // (phase C's Jacobian: the division's latency goes under phase B)
 #pragma unroll 1
             for (int q = 0; q < 4; ++q) {
+#if PLSVO_Q_PIPE
               const QWin w = win_cur;
               const QRows c = rows_cur;
               if (q < 3) { rows_cur = load_rows(q + 1); win_cur = load_win(q + 1); }
+#else
+              const QWin w = q == 0 ? win_cur : load_win(q);
+              const QRows c = q == 0 ? rows_cur : load_rows(q);
+#endif
               if (((need >> (16 * q)) & 0xffffull) != 0ull) {   // wave-uniform: empty quad-rounds cost nothing
                 const int sl = 16 * q + qs;
                 const int pq_ = unit * 64 + sl;
@@ -782,6 +800,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
               }
             }
             wave_lds_fence();
+            TICKQ(4);
             // -- (C) lane per slot: weights and expansion
             if (!terms_only) {
               PixSums ps = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0f };
@@ -793,6 +812,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
               slot_finish(p, meta, is_line, cand, live, X, Y, Z, z_inv, ps);
             }
             wave_lds_fence();   // the unit's scratch is free again
+            TICKQ(5);
           }
         } else {
         // THROUGHPUT SHAPE (unchanged since round 4; its 255-256 registers leave no room for another formulation of the same code)
