@@ -84,23 +84,11 @@ __device__ __forceinline__ uint2 load_row8_raw(const uint8_t* img, int pitch, in
 }
 // optional per-phase timing (compile with -DPLSVO_TIMING): thread 0 accumulates s_memtime deltas
 #ifdef PLSVO_TIMING
-#define TICK_RAW(slot) do { if (tid == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); s_time[slot] += t__ - s_tlast; s_tlast = t__; } } while (0)
-#if PLSVO_TIMING == 2
-// sub-phases of the latency shapes' pass (thread 0's wave): slot 1 = rest of the pass, 3 = phase A, 4 = phase B, 5 = phase C; everything after the pass -> slot 2
-#define TICK(slot) TICK_RAW((slot) >= 2 && (slot) <= 6 ? 2 : (slot))
-#define TICKQ(slot) TICK_RAW(slot)
-#else
-#define TICK(slot) TICK_RAW(slot)
-#define TICKQ(slot) do { } while (0)
-#endif
+#define TICK(slot) do { if (tid == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); s_time[slot] += t__ - s_tlast; s_tlast = t__; } } while (0)
 #else
 #define TICK(slot) do { } while (0)
-#define TICKQ(slot) do { } while (0)
 #endif
 
-#ifndef PLSVO_Q_PIPE
-#define PLSVO_Q_PIPE 1   // latency shapes: phase B's loads requested a quad-round ahead (0: at the head of their own round; A/B builds)
-#endif
 #define SLOT_HOLE ((int)0x80000000)   // s_meta[p].x of a slot no live feature owns at this level
 
 // workgroup barrier; a one-wave workgroup needs only the wave-level form
@@ -121,15 +109,15 @@ __host__ __device__ inline size_t align_chi_window_offset(int threads, int cap, 
   o += (size_t)cap * (sizeof(int2) + sizeof(float)) + (size_t)scap * sizeof(int) + ((size_t)2 * scap + 2) * sizeof(float);
   return (o + 15) & ~(size_t)15;
 }
-// the latency shapes' per-wave scratch follows the window / the planes: 64 slots x (32 B slot info + 56 B pixel sums) per wave
+// the latency shapes' slot tables follow the window / the planes
 __host__ __device__ inline size_t align_quad_offset(int threads, int cap, int scap, int chi_lds_pts) {
   const size_t window = 1024 * sizeof(float), planes = (size_t)2 * chi_lds_pts * 16 * sizeof(float);
   return (align_chi_window_offset(threads, cap, scap) + (planes > window ? planes : window) + 15) & ~(size_t)15;
 }
 // everything the kernel's own tables take
 __host__ __device__ inline size_t align_lds_used(int threads, int cap, int scap, int chi_lds_pts) {
-  // latency shapes: the per-wave scratch, then every slot's 3-D point (24 B) and reference pixel position (8 B) -- global arrays in the throughput shapes
-  const size_t quad = threads >= kQuadMinThreads ? (size_t)(threads / 64) * 64 * (32 + 56) + (size_t)cap * 32 : 0;
+  // latency shapes: every slot's 3-D point (24 B) and reference pixel position (8 B) -- global arrays in the throughput shapes
+  const size_t quad = threads >= kQuadMinThreads ? (size_t)cap * 32 : 0;
   return align_quad_offset(threads, cap, scap, chi_lds_pts) + quad + 16;
 }
 // ------------------------------------------------------------------------------------------------
@@ -354,8 +342,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
   float* s_lterm = reinterpret_cast<float*>(s_dead + scap);              // 2 * scap + 2: exact chi2 term of every line, two iterations; the two sums
   float* s_win = reinterpret_cast<float*>(smem + align_chi_window_offset(T, cap, scap));   // 1024: two 32-slot windows of chi_terms, or the two planes themselves (chi_lds_pts)
   constexpr bool kQuad = T >= kQuadMinThreads;
-  unsigned char* const s_quad = kQuad ? smem + align_quad_offset(T, cap, scap, b.chi_lds_pts) : smem;   // latency shapes: per-wave scratch of the quad pass
-  double* const s_xyz = reinterpret_cast<double*>(s_quad + (T / 64) * 64 * (32 + 56));                  //   cap x 3: every slot's 3-D point (ref frame)
+  double* const s_xyz = reinterpret_cast<double*>(kQuad ? smem + align_quad_offset(T, cap, scap, b.chi_lds_pts) : smem);   // latency shapes: cap x 3, every slot's 3-D point (ref frame)
   float* const s_uvr = reinterpret_cast<float*>(s_xyz + 3 * (kQuad ? cap : 0));                         //   cap x 2: every slot's reference pixel position at the level
 
 #ifdef PLSVO_TIMING
@@ -689,50 +676,28 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
           return cand_ && (u >= 2.0f) && (v >= 2.0f) && (u < colmax) && (v < rowmax);
         };
 
-          // LATENCY SHAPE (a frame owns a CU): FOUR LANES PER SLOT for the pixel arithmetic.  With a lane per slot a 512-thread workgroup
-          // spends a whole wave-round (~1800 instructions) on however few slots a wave holds -- 375 slots leave a quarter of the lanes idle,
-          // 544 cost one wave a second round for 32 slots -- and the two waves of a SIMD serialise on its issue port (measured, one frame:
-          // pass 9.5 k cycles + 5-6 k waiting for the partner wave of 25 k per iteration, profiles/r05a_phase_ticks_b1.log).  Here a wave
-          // takes UNITS of 64 slots: (A) a lane per slot projects the point and parks {window offset, flags, bilinear weights} in the wave's
-          // LDS scratch; (B) four quad-rounds of 16 slots: lane 4s+r evaluates patch row r of slot s -- two image rows, its 48 bytes of the
-          // float cache (reference intensity + gradient of ITS row, written once per level) -- and the quad adds its sums by DPP; empty
-          // quad-rounds are skipped; (C) the lane per slot again: line weights and the 6x6 expansion.  Only wave-level fences inside.
-          constexpr int NW = T / 64;
-          uint4* const q_info = reinterpret_cast<uint4*>(s_quad) + wave * 128;                                   // 32 B per slot of the unit
-          double* const q_sum = reinterpret_cast<double*>(s_quad + NW * 64 * 32) + wave * (64 * 7);              // 56 B per slot of the unit
+          // LATENCY SHAPE (a frame owns most of a CU): a lane per slot like the throughput shape, but with what a lone frame can afford --
+          // the reference patch as FLOAT rows (192 B per slot, written once per level; no rebuild from the byte record: -340 float
+          // instructions per slot and iteration), the slot's 3-D point from LDS, the Jacobian's 1/z issued before the pixel arithmetic.
+          // A wave takes the slots [64 u, 64 u + 64) of its units u = wave, wave + NW, ...
+          // (Round 5 also built and measured the pass with FOUR LANES PER SLOT -- project / four quad-rounds of 16 slots / expand, through
+          //  per-wave LDS scratch: 330 instructions per quad-round against ~700 per 64-slot round here, i.e. twice the issue slots per
+          //  slot; a wave's unit took 12 k cycles, the two waves of a SIMD serialise on its issue port and the pass got SLOWER, 15.3 k ->
+          //  16.8 k cycles per iteration incl. the wait for the partner wave.  profiles/r05_quad_pass_phase_ticks.log)
           const float4* const cache_f = reinterpret_cast<const float4*>(b.cache_ref);
-          const int n_units = (n_rounds_slots + 63) >> 6;
-          const int r = lane & 3, qs = lane >> 2;       // phase B: patch row and slot (inside the quad-round) of this lane
-          for (int unit = wave; unit < n_units; unit += NW) {
-            // what phase B reads from memory, requested a quad-round (the float rows: two) ahead of its arithmetic
-            struct QRows { float4 r4, x4, y4; };
-            struct QWin { uint4 i0, i1; uint32_t lo0, hi0, lo1, hi1; int sh0, sh1; };
-            auto load_rows = [&](int q) -> QRows {          // the slot's cached patch row r: does not depend on the pose
-              QRows c;
+          for (int pb = wave * 64; pb < n_rounds_slots; pb += T) {
+            const int p = pb + lane;
+            struct Rows3 { float4 r4, x4, y4; };
+            auto load_row = [&](int r) -> Rows3 {          // patch row r of the slot's cached reference patch: does not depend on the pose
+              Rows3 c;
               c.r4 = make_float4(0.f, 0.f, 0.f, 0.f); c.x4 = c.r4; c.y4 = c.r4;
-              const int pq_ = unit * 64 + 16 * q + qs;
-              if (pq_ < n_rounds_slots) {
-                const float4* const cf = cache_f + ((pbase + pq_) * 4 + r) * 3;
+              if (p < n_rounds_slots) {
+                const float4* const cf = cache_f + ((pbase + p) * 4 + r) * 3;
                 c.r4 = cf[0]; c.x4 = cf[1]; c.y4 = cf[2];
               }
               return c;
             };
-            auto load_win = [&](int q) -> QWin {            // what phase A parked for the slot + image rows vi-2+r, vi-1+r of its 5x5 window
-              QWin w;
-              const int sl = 16 * q + qs;
-              w.i0 = q_info[2 * sl]; w.i1 = q_info[2 * sl + 1];
-              w.lo0 = 0u; w.hi0 = 0u; w.lo1 = 0u; w.hi1 = 0u; w.sh0 = 0; w.sh1 = 0;
-              if (w.i0.y & 1u) {
-                const int o0 = (int)w.i0.x + r * pitch, o1 = o0 + pitch;
-                w.sh0 = o0 & 3; w.sh1 = o1 & 3;
-                w.lo0 = *reinterpret_cast<const uint32_t*>(cur_img + (o0 & ~3)); w.hi0 = *reinterpret_cast<const uint32_t*>(cur_img + (o0 & ~3) + 4);
-                w.lo1 = *reinterpret_cast<const uint32_t*>(cur_img + (o1 & ~3)); w.hi1 = *reinterpret_cast<const uint32_t*>(cur_img + (o1 & ~3) + 4);
-              }
-              return w;
-            };
-            QRows rows_cur = load_rows(0);                  // (under phase A's arithmetic)
-            // -- (A) lane per slot
-            const int p = unit * 64 + lane;
+            Rows3 row_cur = load_row(0);                   // (under the projection)
             int2 meta = make_int2(SLOT_HOLE, 0);
             if (p < n_slots) meta = s_meta[p];
             const bool hole = meta.x == SLOT_HOLE;
@@ -743,76 +708,47 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
             if (cand) { X = s_xyz[3 * p]; Y = s_xyz[3 * p + 1]; Z = s_xyz[3 * p + 2]; }
             float u, v;
             const bool live = project(cand, X, Y, Z, u, v);
-            const bool chi_slot = (accumulate || terms_only) && store_chi && p < job.n_pts;
-            {
-              PatchW pw = { 0, 0, 0.f, 0.f, 0.f, 0.f };
-              if (live) pw = patch_weights(u, v);
-              const int off = (pw.vi - 2) * pitch + (pw.ui - 2);
-              const int flags = (live ? 1 : 0) | ((!is_line && !hole) ? 2 : 0) | (chi_slot ? 4 : 0);
-              q_info[2 * lane] = make_uint4((uint32_t)off, (uint32_t)flags, __float_as_uint(pw.wTL), __float_as_uint(pw.wTR));
-              q_info[2 * lane + 1] = make_uint4(__float_as_uint(pw.wBL), __float_as_uint(pw.wBR), 0u, 0u);
+            // the 5x5 window of the current image: rows vi-2 .. vi+2, columns ui-2 .. ui+2, two aligned dwords per row
+            uint32_t wlo[5], whi[5]; int wsh[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) { wlo[r] = 0u; whi[r] = 0u; wsh[r] = 0; }
+            PatchW pw = { 0, 0, 0.f, 0.f, 0.f, 0.f };
+            if (live) {
+              pw = patch_weights(u, v);
+#pragma unroll
+              for (int r = 0; r < 5; ++r) {
+                const int off = (pw.vi - 2 + r) * pitch + (pw.ui - 2);
+                wsh[r] = off & 3;
+                wlo[r] = *reinterpret_cast<const uint32_t*>(cur_img + (off & ~3)); whi[r] = *reinterpret_cast<const uint32_t*>(cur_img + (off & ~3) + 4);
+              }
             }
-            wave_lds_fence();
-            const unsigned long long need = __ballot(live || chi_slot);
-            TICKQ(3);
-            // -- (B) four lanes per slot, sixteen slots per quad-round; the next round's window is in flight under this round's arithmetic
-            QWin win_cur = load_win(0);
-            const double z_inv = 1.0 / Z;          // (phase C's Jacobian: the division's latency goes under phase B)
-#pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
-#if PLSVO_Q_PIPE
-              const QWin w = win_cur;
-              const QRows c = rows_cur;
-              if (q < 3) { rows_cur = load_rows(q + 1); win_cur = load_win(q + 1); }
-#else
-              const QWin w = q == 0 ? win_cur : load_win(q);
-              const QRows c = q == 0 ? rows_cur : load_rows(q);
-#endif
-              if (((need >> (16 * q)) & 0xffffull) != 0ull) {   // wave-uniform: empty quad-rounds cost nothing
-                const int sl = 16 * q + qs;
-                const int pq_ = unit * 64 + sl;
-                const bool live_q = (w.i0.y & 1u) != 0, point_q = (w.i0.y & 2u) != 0, chi_q = (w.i0.y & 4u) != 0;
-                const bool any_point = __any(live_q && point_q) != 0;   // wave-uniform
-                PixSums ps = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0f };
-                float4 chi_t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (live_q) {
-                  PatchW pw;
-                  pw.ui = 0; pw.vi = 0;
-                  pw.wTL = __uint_as_float(w.i0.z); pw.wTR = __uint_as_float(w.i0.w); pw.wBL = __uint_as_float(w.i1.x); pw.wBR = __uint_as_float(w.i1.y);
-                  float top[5], bot[5];
-                  unpack5(w.lo0, w.hi0, w.sh0, top);
-                  unpack5(w.lo1, w.hi1, w.sh1, bot);
-                  if (any_point) row4(std::true_type{}, point_q, pw, top, bot, c.r4, c.x4, c.y4, chi_t, ps);
-                  else row4(std::false_type{}, point_q, pw, top, bot, c.r4, c.x4, c.y4, chi_t, ps);
-                }
-                if (chi_q) chi_store(pq_, r, chi_t);   // (a patch outside the current image contributes nothing, :432-433: +0)
-                // the quad's totals: rows 0+1 and 2+3 first, then the two halves (double: 1e-16 of the sequential sum; the line residual's
-                // float sum carries ~1e-7 of its own either way)
-                ps.A = quad_sum(ps.A); ps.B = quad_sum(ps.B); ps.C = quad_sum(ps.C); ps.D = quad_sum(ps.D); ps.E = quad_sum(ps.E);
-                ps.Chi = quad_sum(ps.Chi);
-                ps.Abs += dpp_mov_f32<DPP_QUAD_XOR1>(ps.Abs);
-                ps.Abs += dpp_mov_f32<DPP_QUAD_XOR2>(ps.Abs);
-                if (live_q && r == 0) {
-                  double* const d = q_sum + sl * 7;
-                  d[0] = ps.A; d[1] = ps.B; d[2] = ps.C; d[3] = ps.D; d[4] = ps.E; d[5] = ps.Chi;
-                  reinterpret_cast<float*>(d + 6)[0] = ps.Abs;
+            const double z_inv = 1.0 / Z;          // (the Jacobian's division: its latency goes under the pixel arithmetic)
+            PixSums ps = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0f };
+            const bool any_point = __any(live && !is_line) != 0;   // wave-uniform
+            const bool chi_out = (accumulate || terms_only) && store_chi && p < job.n_pts;
+            if (chi_out && !live) {   // a patch outside the current image contributes nothing (:432-433): +0
+#pragma unroll
+              for (int r = 0; r < 4; ++r) chi_store(p, r, make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+            if (__any(live)) {        // wave-uniform (the rows' loads sit outside the divergent part: one request stream per wave)
+              float ra[5], rb[5];
+              unpack5(wlo[0], whi[0], wsh[0], ra);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const Rows3 c = row_cur;
+                if (r < 3) row_cur = load_row(r + 1);     // the next patch row is in flight under this row's arithmetic
+                float* const top = (r & 1) ? rb : ra;
+                float* const bot = (r & 1) ? ra : rb;
+                unpack5(wlo[r + 1], whi[r + 1], wsh[r + 1], bot);
+                if (live) {
+                  float4 chi_t = make_float4(0.f, 0.f, 0.f, 0.f);
+                  if (any_point) row4(std::true_type{}, !is_line, pw, top, bot, c.r4, c.x4, c.y4, chi_t, ps);
+                  else row4(std::false_type{}, !is_line, pw, top, bot, c.r4, c.x4, c.y4, chi_t, ps);
+                  if (chi_out) chi_store(p, r, chi_t);
                 }
               }
             }
-            wave_lds_fence();
-            TICKQ(4);
-            // -- (C) lane per slot: weights and expansion
-            if (!terms_only) {
-              PixSums ps = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0f };
-              if (live) {
-                const double* const d = q_sum + lane * 7;
-                ps.A = d[0]; ps.B = d[1]; ps.C = d[2]; ps.D = d[3]; ps.E = d[4]; ps.Chi = d[5];
-                ps.Abs = reinterpret_cast<const float*>(d + 6)[0];
-              }
-              slot_finish(p, meta, is_line, cand, live, X, Y, Z, z_inv, ps);
-            }
-            wave_lds_fence();   // the unit's scratch is free again
-            TICKQ(5);
+            if (!terms_only) slot_finish(p, meta, is_line, cand, live, X, Y, Z, z_inv, ps);
           }
         } else {
         // THROUGHPUT SHAPE (unchanged since round 4; its 255-256 registers leave no room for another formulation of the same code)
