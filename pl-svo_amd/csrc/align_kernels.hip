@@ -415,12 +415,14 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
       if (f < job.n_pts) {
         // precomputeGaussNewtonParamsPoints :216-219: floor of the float position, 3 px border
         const int i = job.pt_off + f;
+        double x3 = 0.0, y3 = 0.0, z3 = 0.0;
+        if constexpr (kQuad) { x3 = b.pt_xyz[3 * i]; y3 = b.pt_xyz[3 * i + 1]; z3 = b.pt_xyz[3 * i + 2]; }   // (latency shapes: one round trip, not two)
         const float u = (float)(b.pt_px[2 * i] * scale), v = (float)(b.pt_px[2 * i + 1] * scale);
         if (u >= 3.0f && v >= 3.0f && u < (float)(W - 3) && v < (float)(Hh - 3)) {
           s_meta[f] = make_int2(f, f | (1 << 20));
           if constexpr (kQuad) {
             s_uvr[2 * f] = u; s_uvr[2 * f + 1] = v;
-            s_xyz[3 * f] = b.pt_xyz[3 * i]; s_xyz[3 * f + 1] = b.pt_xyz[3 * i + 1]; s_xyz[3 * f + 2] = b.pt_xyz[3 * i + 2];
+            s_xyz[3 * f] = x3; s_xyz[3 * f + 1] = y3; s_xyz[3 * f + 2] = z3;
           } else {
           b.patch_uvref[2 * (pbase + f)] = u;
           b.patch_uvref[2 * (pbase + f) + 1] = v;
@@ -477,22 +479,44 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
     if constexpr (kQuad) {
       // latency shapes: interpolated intensity and central-difference gradient as FLOAT rows -- lane `row` of the slot's four writes
       // {ref[4], dx[4], dy[4]} of patch row `row` (48 B; the precompute's own operations, align_refpatch.hpp::ref_row_direct, bit-identical to
-      // what the throughput shapes rebuild from their byte record: tests/test_refpatch_host.py) -- which the row's lane reads back every iteration
-      for (int pb = 0; pb < n_slots; pb += T / 4) {
-        const int p = pb + grp;
-        if (p < n_slots && s_meta[p].x != SLOT_HOLE) {
-          const float u = s_uvr[2 * p], v = s_uvr[2 * p + 1];
-          const PatchW pw = patch_weights(u, v);
-          float I[4][7];   // image rows vi-3+row .. vi+row, columns ui-3 .. ui+3
+      // what the throughput shapes rebuild from their byte record: tests/test_refpatch_host.py) -- which the slot's lane reads back every
+      // iteration.  A lone frame waits for every image row it asks for (first touch of the level: HBM), so the requests of FOUR rounds of
+      // slots (48 dwords per lane) go out before the first of them is consumed.
+      constexpr int PC = 4;
+      for (int pb0 = 0; pb0 < n_slots; pb0 += PC * (T / 4)) {
+        uint32_t d[PC][4][3]; int sh[PC][4]; PatchW pws[PC]; bool on[PC];
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const uint2 raw = load_row8_raw<false>(ref_img, pitch, pw.ui - 3, pw.vi - 3 + row + rr);
-            unpack_row7(raw.x, raw.y, I[rr]);
+        for (int k = 0; k < PC; ++k) {
+          const int p = pb0 + k * (T / 4) + grp;
+          on[k] = p < n_slots && s_meta[p].x != SLOT_HOLE;
+          pws[k] = PatchW{ 0, 0, 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) { d[k][rr][0] = 0u; d[k][rr][1] = 0u; d[k][rr][2] = 0u; sh[k][rr] = 0; }
+          if (on[k]) {
+            pws[k] = patch_weights(s_uvr[2 * p], s_uvr[2 * p + 1]);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {   // image rows vi-3+row .. vi+row, columns ui-3 .. ui+3 (row-major slab: aligned dwords + v_alignbyte)
+              const int off = (pws[k].vi - 3 + row + rr) * pitch + (pws[k].ui - 3), a = off & ~3;
+              sh[k][rr] = off & 3;
+              d[k][rr][0] = *reinterpret_cast<const uint32_t*>(ref_img + a);
+              d[k][rr][1] = *reinterpret_cast<const uint32_t*>(ref_img + a + 4);
+              d[k][rr][2] = *reinterpret_cast<const uint32_t*>(ref_img + a + 8);
+            }
           }
-          float4 vr, vx, vy;
-          ref_row_direct(I, pw.wTL, pw.wTR, pw.wBL, pw.wBR, vr, vx, vy);
-          float4* const dst = reinterpret_cast<float4*>(b.cache_ref) + ((pbase + p) * 4 + row) * 3;
-          dst[0] = vr; dst[1] = vx; dst[2] = vy;
+        }
+#pragma unroll
+        for (int k = 0; k < PC; ++k) {
+          const int p = pb0 + k * (T / 4) + grp;
+          if (on[k]) {
+            float I[4][7];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+              unpack_row7(__builtin_amdgcn_alignbyte(d[k][rr][1], d[k][rr][0], (uint32_t)sh[k][rr]), __builtin_amdgcn_alignbyte(d[k][rr][2], d[k][rr][1], (uint32_t)sh[k][rr]), I[rr]);
+            float4 vr, vx, vy;
+            ref_row_direct(I, pws[k].wTL, pws[k].wTR, pws[k].wBL, pws[k].wBR, vr, vx, vy);
+            float4* const dst = reinterpret_cast<float4*>(b.cache_ref) + ((pbase + p) * 4 + row) * 3;
+            dst[0] = vr; dst[1] = vx; dst[2] = vy;
+          }
         }
       }
     } else {
@@ -1038,6 +1062,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
           new_chi2 = (double)(FA / (float)nm);
           old_chi2 = (double)(FB / (float)(unsigned long long)(s_pose[30] + 0.5));
         }
+        TICK(7);
         if (lane == 0 && !defer) {
           s_ctl[10] = 0;
           s_pose[27] += ev_d;

@@ -15,7 +15,7 @@ torch.cuda.synchronize()   # the library enqueues on its own stream
 ctx.config_pyramids(2 * B, 640, 480, 4)
 ctx.build_pyramids_dev(0, 2 * B, imgs.data_ptr(), 640, 640 * 480, 0)
 ctx.synchronize()
-names = ["setup+precompute", "fused pass", "reduce", "rows finish", "solve6", "update", "barrier"]
+names = ["setup+precompute", "fused pass", "reduce", "rows finish", "solve6", "update", "barrier", "chi2 near-tie test + exact sums"]
 L = ctx.L
 L.plsvo_align_phase_ticks.restype = C.c_int
 L.plsvo_align_phase_ticks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -33,7 +33,7 @@ for threads in [os.environ.get("PLSVO_ALIGN_THREADS", "default")]:   # (the libr
         pl, pi = ctx.align_work()
         t = (C.c_uint64 * 8)()
         L.plsvo_align_phase_ticks(ctx.h, t)
-        t = np.array(t[:7], dtype=np.float64)
+        t = np.array(t[:8], dtype=np.float64)
         per_iter = t.copy(); per_iter[0] /= B; per_iter[1:] /= max(iters, 1)
         print(f"T={threads} level {level}: kernel {ms:.3f} ms, B={B}, mean iters {iters / B:.2f}, patches/frame {pl / B:.0f}, "
               f"ticks: " + ", ".join(f"{nm} {v:.0f}" for nm, v in zip(names, per_iter)) +
