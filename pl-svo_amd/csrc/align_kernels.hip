@@ -84,9 +84,18 @@ __device__ __forceinline__ uint2 load_row8_raw(const uint8_t* img, int pitch, in
 }
 // optional per-phase timing (compile with -DPLSVO_TIMING): thread 0 accumulates s_memtime deltas
 #ifdef PLSVO_TIMING
-#define TICK(slot) do { if (tid == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); s_time[slot] += t__ - s_tlast; s_tlast = t__; } } while (0)
+#define TICK_RAW(slot) do { if (tid == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); s_time[slot] += t__ - s_tlast; s_tlast = t__; } } while (0)
+#if PLSVO_TIMING == 3
+// the per-level set-up split into its steps (slots 1..5; the iterations all land in slot 6): -DPLSVO_TIMING=3, tools/gpu_phase_timing.py SETUP=1
+#define TICK(slot) TICK_RAW((slot) == 0 ? 5 : 6)
+#define TICKS(slot) TICK_RAW(slot)
+#else
+#define TICK(slot) TICK_RAW(slot)
+#define TICKS(slot) do { } while (0)
+#endif
 #else
 #define TICK(slot) do { } while (0)
+#define TICKS(slot) do { } while (0)
 #endif
 
 #define SLOT_HOLE ((int)0x80000000)   // s_meta[p].x of a slot no live feature owns at this level
@@ -403,10 +412,12 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
       return;
     }
     block_sync<T>();  // previous level done with every LDS table
+    TICKS(0);
 
     if (tid == 0) { s_ctl[0] = 0; s_ctl[2] = 0; s_ctl[5] = 0; s_ctl[7] = 0; s_ctl[8] = 0; s_pose[27] = 0.0; }
     for (int p = tid; p < n_slots; p += T) s_meta[p] = make_int2(SLOT_HOLE, 0);
     block_sync<T>();
+    TICKS(1);
 
     // ---- slot table: every feature fills the slots the host layout gives it ----
     const double scale = 1.0 / (double)(1 << level);  // the reference's float scale is a power of two: exact
@@ -473,7 +484,9 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
       }
     }
     if (my_patches) atomicAdd(&s_ctl[5], my_patches);   // integer count: order-independent
+    TICKS(2);
     block_sync<T>();  // patch_uvref / patch_xyz (global) and s_meta (LDS) visible to the workgroup
+    TICKS(3);
 
     // ---- reference patches (:236-264, :348-375) ----
     if constexpr (kQuad) {
@@ -535,6 +548,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
       }
     }
     }
+    TICKS(4);
     if (tid == 0) { SE3d m = se3_load(s_pose + 12); quat_to_matrix(m.q, s_pose); s_pose[9] = m.t[0]; s_pose[10] = m.t[1]; s_pose[11] = m.t[2]; }
     block_sync<T>();  // slot tables, pose state and cache complete
     TICK(0);

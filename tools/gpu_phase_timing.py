@@ -19,6 +19,9 @@ names = ["setup+precompute", "fused pass", "reduce", "rows finish", "solve6", "u
 L = ctx.L
 L.plsvo_align_phase_ticks.restype = C.c_int
 L.plsvo_align_phase_ticks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+if os.environ.get("SETUP") == "1":   # a -DPLSVO_TIMING=3 build (tools/build_variant.sh <suffix> "-DPLSVO_TIMING=3" timing): the level set-up split into its steps
+    names = ["before the level (kernel start / previous level's tail)", "s_meta reset + barrier", "slot table (thread 0's features)", "barrier after the table",
+             "reference patches (thread 0's slots)", "pose matrix + barrier", "all iterations", "-"]
 for threads in [os.environ.get("PLSVO_ALIGN_THREADS", "default")]:   # (the library reads the override once, at context creation)
     for level in (3, 2, 1):
         jobs = [P.align_job_from_stream(s, level, level, ref_slot=2 * i, cur_slot=2 * i + 1) for i, s in enumerate(streams)]
@@ -35,6 +38,8 @@ for threads in [os.environ.get("PLSVO_ALIGN_THREADS", "default")]:   # (the libr
         L.plsvo_align_phase_ticks(ctx.h, t)
         t = np.array(t[:8], dtype=np.float64)
         per_iter = t.copy(); per_iter[0] /= B; per_iter[1:] /= max(iters, 1)
+        if os.environ.get("SETUP") == "1":
+            per_iter = t / B
         print(f"T={threads} level {level}: kernel {ms:.3f} ms, B={B}, mean iters {iters / B:.2f}, patches/frame {pl / B:.0f}, "
               f"ticks: " + ", ".join(f"{nm} {v:.0f}" for nm, v in zip(names, per_iter)) +
               f" | per-iteration total {per_iter[1:].sum():.0f} ticks, setup {per_iter[0]:.0f} (per frame)")
