@@ -365,25 +365,38 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
     // solver reset() ([ext] vk::NLLSSolver::reset) and the working copy of the segment flags
     for (int s = tid; s < job.n_seg; s += T)
       b.seg_alive[job.seg_off + s] = b.seg_alive_in ? (b.seg_alive_in[job.seg_off + s] != 0) : 1;
-    if (tid == 0) {
-      for (int k = 0; k < 7; ++k) st->T[k] = b.T0[7 * job_id + k];
+  }
+  if (tid == 0) {
+    // (the seven pose values are requested together and go to LDS from registers: written to the state and read back one by one, each
+    //  of the fourteen accesses waited for the one before -- a lone frame pays a microsecond per dependent first touch)
+    double T_in[7], chi_in = 1e10; int stop_in = 0;
+    if (do_init) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) T_in[k] = b.T0[7 * job_id + k];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) st->T[k] = T_in[k];
       st->chi2 = 1e10; st->n_meas = 0; st->stop = 0; st->log_count = 0; st->error = 0;
       for (int k = 0; k < 36; ++k) st->H[k] = 0.0;
       for (int k = 0; k < PLSVO_MAX_LEVELS; ++k) st->iters[k] = 0;
       st->patch_levels = 0; st->patch_iters = 0; st->patch_iters_pt = 0; st->chi2_ties = 0; st->chi2_unarmed = 0;
       for (int k = 0; k < 8; ++k) st->phase_ticks[k] = 0;
-      if (nothing && b.poses) for (int k = 0; k < 7; ++k) b.poses[7 * job_id + k] = b.T0[7 * job_id + k];
+      if (nothing && b.poses) for (int k = 0; k < 7; ++k) b.poses[7 * job_id + k] = T_in[k];
+    } else if (!nothing) {   // per-level debug launches: the state crosses launches in HBM
+#pragma unroll
+      for (int k = 0; k < 7; ++k) T_in[k] = st->T[k];
+      chi_in = st->chi2; stop_in = st->stop;
+    }
+    if (!nothing) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) { s_pose[12 + k] = T_in[k]; s_pose[19 + k] = T_in[k]; }
+      s_pose[26] = chi_in; s_pose[28] = 0.0; s_pose[29] = 0.0; s_pose[31] = 0.0;
+      for (int k = 0; k < 32; ++k) s_tot[k] = 0.0;
+      s_ctl[1] = stop_in; s_ctl[3] = 0; s_ctl[6] = 0; s_ctl[9] = 0;
+      s_ctl[10] = 0;
     }
   }
   if (nothing) return;
   block_sync<T>();   // seg_alive / state of this job initialised (same workgroup: visible after the barrier)
-  if (tid == 0) {
-    for (int k = 0; k < 7; ++k) { s_pose[12 + k] = st->T[k]; s_pose[19 + k] = st->T[k]; }
-    s_pose[26] = st->chi2; s_pose[28] = 0.0; s_pose[29] = 0.0; s_pose[31] = 0.0;
-    for (int k = 0; k < 32; ++k) s_tot[k] = 0.0;
-    s_ctl[1] = st->stop; s_ctl[3] = 0; s_ctl[6] = 0; s_ctl[9] = 0;
-    s_ctl[10] = 0;
-  }
   if (b.chi_lds_pts > 0) {   // LDS planes: the slots between the last point and the next multiple of 4 are read by the exact sums: +0
     const int tail0 = job.n_pts * 16, tail1 = ((job.n_pts + 3) & ~3) * 16;
     for (int k = tail0 + tid; k < tail1; k += T) { s_win[k] = 0.0f; s_win[b.chi_lds_pts * 16 + k] = 0.0f; }
@@ -426,14 +439,14 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
       if (f < job.n_pts) {
         // precomputeGaussNewtonParamsPoints :216-219: floor of the float position, 3 px border
         const int i = job.pt_off + f;
-        double x3 = 0.0, y3 = 0.0, z3 = 0.0;
-        if constexpr (kQuad) { x3 = b.pt_xyz[3 * i]; y3 = b.pt_xyz[3 * i + 1]; z3 = b.pt_xyz[3 * i + 2]; }   // (latency shapes: one round trip, not two)
+        if constexpr (kQuad) {   // (latency shapes: position and 3-D point are ONE round trip -- the point's table entries are written whether or not its slot is used)
+          s_xyz[3 * f] = b.pt_xyz[3 * i]; s_xyz[3 * f + 1] = b.pt_xyz[3 * i + 1]; s_xyz[3 * f + 2] = b.pt_xyz[3 * i + 2];
+        }
         const float u = (float)(b.pt_px[2 * i] * scale), v = (float)(b.pt_px[2 * i + 1] * scale);
+        if constexpr (kQuad) { s_uvr[2 * f] = u; s_uvr[2 * f + 1] = v; }
         if (u >= 3.0f && v >= 3.0f && u < (float)(W - 3) && v < (float)(Hh - 3)) {
           s_meta[f] = make_int2(f, f | (1 << 20));
           if constexpr (kQuad) {
-            s_uvr[2 * f] = u; s_uvr[2 * f + 1] = v;
-            s_xyz[3 * f] = x3; s_xyz[3 * f + 1] = y3; s_xyz[3 * f + 2] = z3;
           } else {
           b.patch_uvref[2 * (pbase + f)] = u;
           b.patch_uvref[2 * (pbase + f) + 1] = v;
@@ -449,18 +462,25 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
         // host layout: first slot | N << 20, or -1 when the segment has no landmark on entry or fails
         // precomputeGaussNewtonParamsSegments :299-301 ((px*scale).cast<int>() against cam->isInFrame(.,3,level));
         // N = 1 + (N0-1)/2^level samples (:320, LineFeat::setupSampling src/feature.cpp:160-173)
+        // (latency shapes: the segment's ten doubles are requested together with its slot code and its flag, not after them)
+        double g_s[2] = { 0.0, 0.0 }, g_e[2] = { 0.0, 0.0 }, g_p[3] = { 0.0, 0.0, 0.0 }, g_q[3] = { 0.0, 0.0, 0.0 };
+        if constexpr (kQuad) {
+          g_s[0] = b.seg_spx[2 * s]; g_s[1] = b.seg_spx[2 * s + 1]; g_e[0] = b.seg_epx[2 * s]; g_e[1] = b.seg_epx[2 * s + 1];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { g_p[c] = b.seg_p[3 * s + c]; g_q[c] = b.seg_q[3 * s + c]; }
+        }
         const int code = b.seg_slot[(size_t)(level - b.slot_level0) * b.slot_stride + s];
         if (code >= 0 && b.seg_alive[s]) {
           const int p0 = code & 0xfffff, N = code >> 20;
           // :316-332: 2-D step on the level image, 3-D step between the end points, both accumulated
-          const double sx = b.seg_spx[2 * s], sy = b.seg_spx[2 * s + 1];
-          double inc2x = (b.seg_epx[2 * s] - sx) * scale / (double)(N - 1);
-          double inc2y = (b.seg_epx[2 * s + 1] - sy) * scale / (double)(N - 1);
+          const double sx = kQuad ? g_s[0] : b.seg_spx[2 * s], sy = kQuad ? g_s[1] : b.seg_spx[2 * s + 1];
+          double inc2x = ((kQuad ? g_e[0] : b.seg_epx[2 * s]) - sx) * scale / (double)(N - 1);
+          double inc2y = ((kQuad ? g_e[1] : b.seg_epx[2 * s + 1]) - sy) * scale / (double)(N - 1);
           double px = sx * scale, py = sy * scale;
           double xr[3], inc3[3];
           for (int c = 0; c < 3; ++c) {
-            const double pr = b.seg_p[3 * s + c];
-            inc3[c] = (b.seg_q[3 * s + c] - pr) / (double)(N - 1);
+            const double pr = kQuad ? g_p[c] : b.seg_p[3 * s + c];
+            inc3[c] = ((kQuad ? g_q[c] : b.seg_q[3 * s + c]) - pr) / (double)(N - 1);
             xr[c] = pr;
           }
           for (int n = 0; n < N; ++n) {
