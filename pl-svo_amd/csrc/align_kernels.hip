@@ -87,7 +87,7 @@ __device__ __forceinline__ uint2 load_row8_raw(const uint8_t* img, int pitch, in
 #define TICK_RAW(slot) do { if (tid == 0) { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); s_time[slot] += t__ - s_tlast; s_tlast = t__; } } while (0)
 #if PLSVO_TIMING == 3
 // the per-level set-up split into its steps (slots 1..5; the iterations all land in slot 6): -DPLSVO_TIMING=3, tools/gpu_phase_timing.py SETUP=1
-#define TICK(slot) TICK_RAW((slot) == 0 ? 5 : 6)
+#define TICK(slot) do { if ((slot) == 0) TICK_RAW(5); } while (0)
 #define TICKS(slot) TICK_RAW(slot)
 #else
 #define TICK(slot) TICK_RAW(slot)
@@ -503,53 +503,58 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
         }
       }
     }
-    if (my_patches) atomicAdd(&s_ctl[5], my_patches);   // integer count: order-independent
+    // integer count: order-independent.  (One atomic per WAVE: sixty-four lanes adding to the same LDS word serialise -- measured 4.6 k
+    //  cycles per level for a lone frame, a fifth of its set-up.)
+    if constexpr (kQuad) {
+      const int wave_patches = wave_sum_i32_to_lane63(my_patches);
+      if (lane == 63 && wave_patches) atomicAdd(&s_ctl[5], wave_patches);
+    } else {
+    if (my_patches) atomicAdd(&s_ctl[5], my_patches);
+    }
     TICKS(2);
     block_sync<T>();  // patch_uvref / patch_xyz (global) and s_meta (LDS) visible to the workgroup
     TICKS(3);
 
     // ---- reference patches (:236-264, :348-375) ----
     if constexpr (kQuad) {
-      // latency shapes: interpolated intensity and central-difference gradient as FLOAT rows -- lane `row` of the slot's four writes
-      // {ref[4], dx[4], dy[4]} of patch row `row` (48 B; the precompute's own operations, align_refpatch.hpp::ref_row_direct, bit-identical to
-      // what the throughput shapes rebuild from their byte record: tests/test_refpatch_host.py) -- which the slot's lane reads back every
-      // iteration.  A lone frame waits for every image row it asks for (first touch of the level: HBM), so the requests of FOUR rounds of
-      // slots (48 dwords per lane) go out before the first of them is consumed.
-      constexpr int PC = 4;
-      for (int pb0 = 0; pb0 < n_slots; pb0 += PC * (T / 4)) {
-        uint32_t d[PC][4][3]; int sh[PC][4]; PatchW pws[PC]; bool on[PC];
+      // latency shapes: interpolated intensity and central-difference gradient as FLOAT rows, {ref[4], dx[4], dy[4]} per patch row (192 B per
+      // slot), which the slot's lane reads back every iteration.  ONE LANE PER SLOT: it gathers the 7x7 window of reference-image bytes
+      // (seven rows of aligned dwords + v_alignbyte) into the 64-byte record form in registers and lets align_refpatch.hpp::RecordRows produce
+      // the four rows -- the operations the throughput shapes repeat every iteration, bit-identical to the reference's precompute
+      // (tests/test_refpatch_host.py) -- sharing every interpolated value between the rows that need it: 340 float instructions per slot
+      // where four lanes per slot (a row each, the first form of this block) issued 4 x 230; measured 5-8 k -> ... cycles per level.
+      for (int pb = wave * 64; pb < n_slots; pb += T) {
+        const int p = pb + lane;
+        if (p < n_slots && s_meta[p].x != SLOT_HOLE) {
+          const float u = s_uvr[2 * p], v = s_uvr[2 * p + 1];
+          const PatchW pw = patch_weights(u, v);
+          uint32_t d[7][3]; int shf[7];
 #pragma unroll
-        for (int k = 0; k < PC; ++k) {
-          const int p = pb0 + k * (T / 4) + grp;
-          on[k] = p < n_slots && s_meta[p].x != SLOT_HOLE;
-          pws[k] = PatchW{ 0, 0, 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) { d[k][rr][0] = 0u; d[k][rr][1] = 0u; d[k][rr][2] = 0u; sh[k][rr] = 0; }
-          if (on[k]) {
-            pws[k] = patch_weights(s_uvr[2 * p], s_uvr[2 * p + 1]);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {   // image rows vi-3+row .. vi+row, columns ui-3 .. ui+3 (row-major slab: aligned dwords + v_alignbyte)
-              const int off = (pws[k].vi - 3 + row + rr) * pitch + (pws[k].ui - 3), a = off & ~3;
-              sh[k][rr] = off & 3;
-              d[k][rr][0] = *reinterpret_cast<const uint32_t*>(ref_img + a);
-              d[k][rr][1] = *reinterpret_cast<const uint32_t*>(ref_img + a + 4);
-              d[k][rr][2] = *reinterpret_cast<const uint32_t*>(ref_img + a + 8);
-            }
+          for (int k = 0; k < 7; ++k) {   // image rows vi-3 .. vi+3, columns ui-3 .. ui+3 (+1 byte of padding per row)
+            const int off = (pw.vi - 3 + k) * pitch + (pw.ui - 3), a = off & ~3;
+            shf[k] = off & 3;
+            d[k][0] = *reinterpret_cast<const uint32_t*>(ref_img + a);
+            d[k][1] = *reinterpret_cast<const uint32_t*>(ref_img + a + 4);
+            d[k][2] = *reinterpret_cast<const uint32_t*>(ref_img + a + 8);
           }
-        }
+          uint32_t lo[7], hi[7];
 #pragma unroll
-        for (int k = 0; k < PC; ++k) {
-          const int p = pb0 + k * (T / 4) + grp;
-          if (on[k]) {
-            float I[4][7];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-              unpack_row7(__builtin_amdgcn_alignbyte(d[k][rr][1], d[k][rr][0], (uint32_t)sh[k][rr]), __builtin_amdgcn_alignbyte(d[k][rr][2], d[k][rr][1], (uint32_t)sh[k][rr]), I[rr]);
-            float4 vr, vx, vy;
-            ref_row_direct(I, pws[k].wTL, pws[k].wTR, pws[k].wBL, pws[k].wBR, vr, vx, vy);
-            float4* const dst = reinterpret_cast<float4*>(b.cache_ref) + ((pbase + p) * 4 + row) * 3;
-            dst[0] = vr; dst[1] = vx; dst[2] = vy;
+          for (int k = 0; k < 7; ++k) {
+            lo[k] = __builtin_amdgcn_alignbyte(d[k][1], d[k][0], (uint32_t)shf[k]);
+            hi[k] = __builtin_amdgcn_alignbyte(d[k][2], d[k][1], (uint32_t)shf[k]);
           }
+          // the record's layout: q[k] = record rows 2k, 2k+1 (8 bytes each); q[3].zw = the two sub-pixel fractions
+          uint4 q[4];
+          q[0] = make_uint4(lo[0], hi[0], lo[1], hi[1]); q[1] = make_uint4(lo[2], hi[2], lo[3], hi[3]); q[2] = make_uint4(lo[4], hi[4], lo[5], hi[5]);
+          q[3] = make_uint4(lo[6], hi[6], __float_as_uint(u - floorf(u)), __float_as_uint(v - floorf(v)));
+          float4* const dst = reinterpret_cast<float4*>(b.cache_ref) + (pbase + p) * 12;
+          RecordRows rec;
+          rec.start(q);
+          float4 vr, vx, vy;
+          rec.template row<0>(vr, vx, vy); dst[0] = vr; dst[1] = vx; dst[2] = vy;
+          rec.template row<1>(vr, vx, vy); dst[3] = vr; dst[4] = vx; dst[5] = vy;
+          rec.template row<2>(vr, vx, vy); dst[6] = vr; dst[7] = vx; dst[8] = vy;
+          rec.template row<3>(vr, vx, vy); dst[9] = vr; dst[10] = vx; dst[11] = vy;
         }
       }
     } else {
@@ -1151,6 +1156,9 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
           for (int k = 0; k < 6; ++k) r->Jres[k] = s_tot[21 + k];
         }
       }
+#if defined(PLSVO_TIMING) && PLSVO_TIMING == 3
+      if (iter == 0) TICK_RAW(7); else TICK_RAW(6);   // the first iteration of the launch runs its code cold (instruction fetch): slot 7, the others slot 6
+#endif
       TICK(6);
       if (s_ctl[0]) break;
     }

@@ -48,6 +48,17 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
   return v;
 }
 
+// sum of an int over the 64 lanes of a wave; the total is valid in lane 63
+__device__ __forceinline__ int wave_sum_i32_to_lane63(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, DPP_QUAD_XOR1, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, DPP_QUAD_XOR2, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_HALF_MIRROR, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_MIRROR, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST15, 0xA, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST31, 0xC, 0xf, false);
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Reduce-scatter of 32 lane-private doubles over the 16 lanes of every DPP row (butterfly, fixed shape):
 // step s halves the number of values a lane carries and pairs it with the lane whose index differs in bit s,

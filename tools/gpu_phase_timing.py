@@ -21,7 +21,7 @@ L.plsvo_align_phase_ticks.restype = C.c_int
 L.plsvo_align_phase_ticks.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 if os.environ.get("SETUP") == "1":   # a -DPLSVO_TIMING=3 build (tools/build_variant.sh <suffix> "-DPLSVO_TIMING=3" timing): the level set-up split into its steps
     names = ["before the level (kernel start / previous level's tail)", "s_meta reset + barrier", "slot table (thread 0's features)", "barrier after the table",
-             "reference patches (thread 0's slots)", "pose matrix + barrier", "all iterations", "-"]
+             "reference patches (thread 0's slots)", "pose matrix + barrier", "iterations after the first", "FIRST iteration of the launch"]
 for threads in [os.environ.get("PLSVO_ALIGN_THREADS", "default")]:   # (the library reads the override once, at context creation)
     for level in (3, 2, 1):
         jobs = [P.align_job_from_stream(s, level, level, ref_slot=2 * i, cur_slot=2 * i + 1) for i, s in enumerate(streams)]
