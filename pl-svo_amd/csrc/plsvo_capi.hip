@@ -143,6 +143,18 @@ struct plsvo_ctx {
   size_t pinned_cap[2] = { 0, 0 };
   hipEvent_t pinned_done[2] = { nullptr, nullptr };
   int pinned_next = 0;
+  // the same for whole pyramids (plsvo_hip_upload_pyramid packs a frame's levels into one pinned image of its slot: ONE DMA, no wait)
+  void* pyr_pinned[2] = { nullptr, nullptr };
+  size_t pyr_pinned_cap[2] = { 0, 0 };
+  hipEvent_t pyr_pinned_done[2] = { nullptr, nullptr };
+  int pyr_pinned_next = 0;
+  // slots whose TILED mirror is stale: an uploaded pyramid is re-tiled only when a launch that reads the mirror (the one-wave-per-frame
+  // shape of the alignment) is about to use it -- a per-frame caller never pays the four tile launches
+  std::vector<uint8_t> tiled_stale;
+  int tiled_stale_count = 0;
+  // results of a fetch come back through a pinned buffer (device-to-PAGEABLE copies are staged and waited for one by one by the driver)
+  void* dl_pinned = nullptr;
+  size_t dl_pinned_cap = 0;
 
   // profiling
   bool profiling = false;
@@ -248,6 +260,8 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
                      &c->ch_d_ptkeep, &c->ch_d_segkeep, &c->ch_d_s32, &c->ch_d_s64, &c->ch_d_poses, &c->rec_d };
   for (DevBuf* b : bufs) b->release();
   for (int k = 0; k < 2; ++k) { if (c->pinned[k]) (void)hipHostFree(c->pinned[k]); if (c->pinned_done[k]) (void)hipEventDestroy(c->pinned_done[k]); }
+  for (int k = 0; k < 2; ++k) { if (c->pyr_pinned[k]) (void)hipHostFree(c->pyr_pinned[k]); if (c->pyr_pinned_done[k]) (void)hipEventDestroy(c->pyr_pinned_done[k]); }
+  if (c->dl_pinned) (void)hipHostFree(c->dl_pinned);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -310,6 +324,7 @@ extern "C" int plsvo_hip_config_pyramids(plsvo_ctx* c, int n_slots, int width, i
   d.base = c->pyr_slab.as<uint8_t>();
   d.tbase = c->pyr_tiled.as<uint8_t>();
   c->pyr = d;
+  c->tiled_stale.assign((size_t)n_slots, 0); c->tiled_stale_count = 0;
   c->a_staged = false;
   c->ch_staged = false;
   return PLSVO_OK;
@@ -331,20 +346,74 @@ static int retile(plsvo_ctx* c, int first_slot, int n, int n_levels) {
   return PLSVO_OK;
 }
 
+// the tiled mirror of every slot in [first, first + n) is current again (whoever calls this has just enqueued retile() for them)
+static void mark_tiled_fresh(plsvo_ctx* c, int first, int n) {
+  if (c->tiled_stale_count == 0) return;
+  for (int s = first; s < first + n && s < (int)c->tiled_stale.size(); ++s)
+    if (c->tiled_stale[(size_t)s]) { c->tiled_stale[(size_t)s] = 0; --c->tiled_stale_count; }
+}
+// re-tile the stale slots among `slots` (a launch that reads the mirror is about to be enqueued behind this)
+static int retile_stale(plsvo_ctx* c, const std::vector<int>& slots) {
+  if (c->tiled_stale_count == 0) return PLSVO_OK;
+  for (int sl : slots) {
+    if (sl < 0 || sl >= (int)c->tiled_stale.size() || !c->tiled_stale[(size_t)sl]) continue;
+    int rc = retile(c, sl, 1, c->pyr.n_levels); if (rc) return rc;
+    c->tiled_stale[(size_t)sl] = 0; --c->tiled_stale_count;
+    if (c->tiled_stale_count == 0) break;
+  }
+  return PLSVO_OK;
+}
+
 extern "C" int plsvo_hip_upload_pyramid(plsvo_ctx* c, int slot, int n_levels, const uint8_t* const* level_ptr, const int* width,
                                         const int* height, const int* stride_bytes) {
   CTX_CHECK(c);
   int rc = check_slot(c, slot); if (rc) return rc;
-  if (!level_ptr || !width || !height || !stride_bytes || n_levels > c->pyr.n_levels) return fail(c, PLSVO_E_INVALID, "upload_pyramid: bad arguments");
+  if (!level_ptr || !width || !height || !stride_bytes || n_levels <= 0 || n_levels > c->pyr.n_levels) return fail(c, PLSVO_E_INVALID, "upload_pyramid: bad arguments");
   HIP_TRY(c, hipSetDevice(c->device));
   for (int l = 0; l < n_levels; ++l) {
-    if (width[l] != c->pyr.w[l] || height[l] != c->pyr.h[l]) return fail(c, PLSVO_E_INVALID, "upload_pyramid: level size does not match the configured pyramid");
-    uint8_t* dst = c->pyr_slab.as<uint8_t>() + (size_t)slot * c->pyr.slot_bytes + c->pyr.off[l];
-    HIP_TRY(c, hipMemcpy2DAsync(dst, (size_t)width[l], level_ptr[l], (size_t)stride_bytes[l], (size_t)width[l], (size_t)height[l],
-                                hipMemcpyHostToDevice, c->stream));
+    if (!level_ptr[l] || width[l] != c->pyr.w[l] || height[l] != c->pyr.h[l] || stride_bytes[l] < width[l])
+      return fail(c, PLSVO_E_INVALID, "upload_pyramid: level size does not match the configured pyramid");
   }
-  rc = retile(c, slot, 1, n_levels); if (rc) return rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the host buffers may be released by the caller
+  uint8_t* const slot_dst = c->pyr_slab.as<uint8_t>() + (size_t)slot * c->pyr.slot_bytes;
+  // The levels are packed into a pinned image of the slot (rows tight, every level at its offset) and cross PCIe as ONE copy enqueued on
+  // the stream: the caller's buffers are free when the call returns, nothing is waited for, and whatever is launched next on the stream
+  // reads the new pyramid.  (Until round 4: one pageable 2-D copy per level -- each staged by the driver -- four tile launches and a stream
+  // synchronisation, ~45 us of a 0.4 ms SparseImgAlign::run.)  Two pinned images, each guarded by an event behind its last DMA.
+  const size_t image_bytes = (size_t)c->pyr.off[n_levels - 1] + (size_t)width[n_levels - 1] * (size_t)height[n_levels - 1];
+  const int k = c->pyr_pinned_next;
+  if (!c->pyr_pinned_done[k] && hipEventCreate(&c->pyr_pinned_done[k]) != hipSuccess) c->pyr_pinned_done[k] = nullptr;
+  bool packed = false;
+  if (c->pyr_pinned_done[k]) {
+    HIP_TRY(c, hipEventSynchronize(c->pyr_pinned_done[k]));   // the DMA that last read this image has landed (no-op when never recorded)
+    if (c->pyr_pinned_cap[k] < image_bytes) {
+      if (c->pyr_pinned[k]) (void)hipHostFree(c->pyr_pinned[k]);
+      c->pyr_pinned[k] = nullptr; c->pyr_pinned_cap[k] = 0;
+      if (hipHostMalloc(&c->pyr_pinned[k], (size_t)c->pyr.slot_bytes, hipHostMallocDefault) == hipSuccess) {
+        c->pyr_pinned_cap[k] = (size_t)c->pyr.slot_bytes;
+        memset(c->pyr_pinned[k], 0, c->pyr_pinned_cap[k]);   // (the slack between the levels travels with them)
+      }
+    }
+    if (c->pyr_pinned[k]) {
+      uint8_t* const img = static_cast<uint8_t*>(c->pyr_pinned[k]);
+      for (int l = 0; l < n_levels; ++l) {
+        uint8_t* d = img + c->pyr.off[l];
+        const size_t w = (size_t)width[l];
+        if ((size_t)stride_bytes[l] == w) memcpy(d, level_ptr[l], w * (size_t)height[l]);
+        else for (int y = 0; y < height[l]; ++y) memcpy(d + (size_t)y * w, level_ptr[l] + (size_t)y * (size_t)stride_bytes[l], w);
+      }
+      HIP_TRY(c, hipMemcpyAsync(slot_dst, img, image_bytes, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c, hipEventRecord(c->pyr_pinned_done[k], c->stream));
+      c->pyr_pinned_next = k ^ 1;
+      packed = true;
+    }
+  }
+  if (!packed) {   // no pinned memory: straight from the caller's buffers, which must stay untouched until the copies have landed
+    for (int l = 0; l < n_levels; ++l)
+      HIP_TRY(c, hipMemcpy2DAsync(slot_dst + c->pyr.off[l], (size_t)width[l], level_ptr[l], (size_t)stride_bytes[l], (size_t)width[l], (size_t)height[l],
+                                  hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  if (!c->tiled_stale[(size_t)slot]) { c->tiled_stale[(size_t)slot] = 1; ++c->tiled_stale_count; }
   return PLSVO_OK;
 }
 
@@ -356,6 +425,7 @@ static int build_levels(plsvo_ctx* c, int first_slot, int n, int rounding) {
                                  base + c->pyr.off[l], c->pyr.slot_bytes, n, rounding, c->stream));
     prof_end(c, PLSVO_K_HALFSAMPLE, &ep);
   }
+  mark_tiled_fresh(c, first_slot, n);
   return retile(c, first_slot, n, c->pyr.n_levels);
 }
 
@@ -401,6 +471,11 @@ extern "C" int plsvo_hip_copy_slots(plsvo_ctx* c, int dst_first, int src_first, 
                             (size_t)n * c->pyr.slot_bytes, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->pyr_tiled.as<uint8_t>() + (size_t)dst_first * c->pyr.tslot_bytes, c->pyr_tiled.as<uint8_t>() + (size_t)src_first * c->pyr.tslot_bytes,
                             (size_t)n * c->pyr.tslot_bytes, hipMemcpyDeviceToDevice, c->stream));
+  for (int k = 0; k < n; ++k) {   // a stale mirror stays stale in its copy (and a fresh one replaces a stale one)
+    const uint8_t st = c->tiled_stale[(size_t)(src_first + k)];
+    uint8_t& dt = c->tiled_stale[(size_t)(dst_first + k)];
+    if (st != dt) { c->tiled_stale_count += st ? 1 : -1; dt = st; }
+  }
   return PLSVO_OK;
 }
 
@@ -456,6 +531,28 @@ extern "C" int plsvo_align_slot_layout(const plsvo_align_in* in, int level, int3
   if (n_slots) *n_slots = (int32_t)used;
   if (long_lines) *long_lines = any_long;
   if (n_patches) *n_patches = n_real;
+  return PLSVO_OK;
+}
+
+// Up to three device ranges to the host with ONE wait: through the context's pinned download buffer when they fit (a per-frame caller's
+// results: a few hundred bytes of state + the flags), straight into the caller's (pageable) buffers otherwise.  On return h[k] points at
+// range k's bytes: inside the pinned buffer (valid until the next fetch) or at dst[k].
+static int download_ranges(plsvo_ctx* c, int n_ranges, const void* const* src, const size_t* bytes, void* const* dst, const uint8_t** h) {
+  size_t total = 0, off[3] = { 0, 0, 0 };
+  for (int k = 0; k < n_ranges; ++k) { off[k] = total; total += (bytes[k] + 63) & ~(size_t)63; }
+  bool pinned = total <= ((size_t)4 << 20);
+  if (pinned && c->dl_pinned_cap < total) {
+    if (c->dl_pinned) (void)hipHostFree(c->dl_pinned);
+    c->dl_pinned = nullptr; c->dl_pinned_cap = 0;
+    const size_t want = std::max(total * 2, (size_t)64 << 10);
+    if (hipHostMalloc(&c->dl_pinned, want, hipHostMallocDefault) == hipSuccess) c->dl_pinned_cap = want; else { c->dl_pinned = nullptr; pinned = false; }
+  }
+  for (int k = 0; k < n_ranges; ++k) {
+    void* to = pinned ? static_cast<void*>(static_cast<uint8_t*>(c->dl_pinned) + off[k]) : dst[k];
+    h[k] = static_cast<const uint8_t*>(to);
+    if (bytes[k]) HIP_TRY(c, hipMemcpyAsync(to, src[k], bytes[k], hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return PLSVO_OK;
 }
 
@@ -679,6 +776,12 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
   pick_align_config(c, c->a_n, cap, scap, max_pts, &threads, &lds, &chi_lds_pts);
   c->a_b.chi_lds_pts = chi_lds_pts;
   if (lds > c->lds_per_block) return fail(c, PLSVO_E_CAPACITY, "align_run: slot tables do not fit in LDS (too many features in one job)");
+  if (threads <= 64 && c->tiled_stale_count > 0) {   // the one-wave-per-frame shape reads the tiled mirror: bring the uploaded slots' tiles up to date first
+    std::vector<int> slots;
+    slots.reserve(2 * c->a_jobs.size());
+    for (const AlignJobDev& J : c->a_jobs) { slots.push_back(J.ref_slot); slots.push_back(J.cur_slot); }
+    const int rc_t = retile_stale(c, slots); if (rc_t) return rc_t;
+  }
   if (threads >= kQuadMinThreads) {   // latency shapes keep the reference patches as float rows: 192 B per slot (small batches only: <= 4 frames per CU)
     HIP_TRY(c, c->a_d_cref.ensure(c->a_patch_total * 192));
     c->a_b.cache_ref = c->a_d_cref.as<float>();
@@ -704,11 +807,16 @@ extern "C" int plsvo_align_fetch(plsvo_ctx* c, int n, plsvo_align_out* out) {
   if (!c->a_staged) return fail(c, PLSVO_E_STATE, "align_fetch: no staged batch");
   if (n != c->a_n || !out) return fail(c, PLSVO_E_INVALID, "align_fetch: n does not match the staged batch");
   HIP_TRY(c, hipSetDevice(c->device));
-  std::vector<AlignStateDev> st((size_t)n);
-  std::vector<uint8_t> alive((size_t)std::max(c->a_total_seg, 1));
-  HIP_TRY(c, hipMemcpyAsync(st.data(), c->a_d_state.p, (size_t)n * sizeof(AlignStateDev), hipMemcpyDeviceToHost, c->stream));
-  if (c->a_total_seg > 0) HIP_TRY(c, hipMemcpyAsync(alive.data(), c->a_d_alive.p, (size_t)c->a_total_seg, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::vector<AlignStateDev> st_v;
+  std::vector<uint8_t> alive_v;
+  const size_t rb[2] = { (size_t)n * sizeof(AlignStateDev), (size_t)std::max(c->a_total_seg, 0) };
+  if (rb[0] + rb[1] > ((size_t)4 << 20)) { st_v.resize((size_t)n); alive_v.resize((size_t)std::max(c->a_total_seg, 1)); }   // (large batches: the caller-side staging of old)
+  const void* const rs[2] = { c->a_d_state.p, c->a_d_alive.p };
+  void* const rd[2] = { st_v.data(), alive_v.data() };
+  const uint8_t* rh[2] = { nullptr, nullptr };
+  { const int rc_d = download_ranges(c, 2, rs, rb, rd, rh); if (rc_d) return rc_d; }
+  const AlignStateDev* const st = reinterpret_cast<const AlignStateDev*>(rh[0]);
+  const uint8_t* const alive = rh[1];
   int dev_err = 0;
   for (int j = 0; j < n; ++j) {
     const AlignStateDev& s = st[(size_t)j];
@@ -723,7 +831,7 @@ extern "C" int plsvo_align_fetch(plsvo_ctx* c, int n, plsvo_align_out* out) {
     for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) o.iters_per_level[l] = s.iters[l];
     o.status = s.stop ? 1 : 0;
     if (alive_out && c->a_jobs[(size_t)j].n_seg > 0)
-      memcpy(alive_out, alive.data() + c->a_jobs[(size_t)j].seg_off, (size_t)c->a_jobs[(size_t)j].n_seg);
+      memcpy(alive_out, alive + c->a_jobs[(size_t)j].seg_off, (size_t)c->a_jobs[(size_t)j].n_seg);
     if (s.error) dev_err = s.error;
   }
   if (dev_err) return fail(c, PLSVO_E_CAPACITY, "align: device-side capacity check failed (code " + std::to_string(dev_err) + ")");
@@ -934,12 +1042,16 @@ extern "C" int plsvo_poseopt_fetch(plsvo_ctx* c, int n, plsvo_poseopt_out* out) 
   if (!c->p_staged) return fail(c, PLSVO_E_STATE, "poseopt_fetch: no staged batch");
   if (n != c->p_n || !out) return fail(c, PLSVO_E_INVALID, "poseopt_fetch: n does not match the staged batch");
   HIP_TRY(c, hipSetDevice(c->device));
-  std::vector<PoseStateDev> st((size_t)n);
-  std::vector<uint8_t> pk((size_t)std::max(c->p_total_pt, 1)), sk((size_t)std::max(c->p_total_seg, 1));
-  HIP_TRY(c, hipMemcpyAsync(st.data(), c->p_d_state.p, (size_t)n * sizeof(PoseStateDev), hipMemcpyDeviceToHost, c->stream));
-  if (c->p_total_pt > 0) HIP_TRY(c, hipMemcpyAsync(pk.data(), c->p_d_ptkeep.p, (size_t)c->p_total_pt, hipMemcpyDeviceToHost, c->stream));
-  if (c->p_total_seg > 0) HIP_TRY(c, hipMemcpyAsync(sk.data(), c->p_d_segkeep.p, (size_t)c->p_total_seg, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::vector<PoseStateDev> st_v;
+  std::vector<uint8_t> pk_v, sk_v;
+  const size_t rb[3] = { (size_t)n * sizeof(PoseStateDev), (size_t)std::max(c->p_total_pt, 0), (size_t)std::max(c->p_total_seg, 0) };
+  if (rb[0] + rb[1] + rb[2] > ((size_t)4 << 20)) { st_v.resize((size_t)n); pk_v.resize((size_t)std::max(c->p_total_pt, 1)); sk_v.resize((size_t)std::max(c->p_total_seg, 1)); }
+  const void* const rs[3] = { c->p_d_state.p, c->p_d_ptkeep.p, c->p_d_segkeep.p };
+  void* const rd[3] = { st_v.data(), pk_v.data(), sk_v.data() };
+  const uint8_t* rh[3] = { nullptr, nullptr, nullptr };
+  { const int rc_d = download_ranges(c, 3, rs, rb, rd, rh); if (rc_d) return rc_d; }
+  const PoseStateDev* const st = reinterpret_cast<const PoseStateDev*>(rh[0]);
+  const uint8_t* const pk = rh[1]; const uint8_t* const sk = rh[2];
   for (int j = 0; j < n; ++j) {
     const PoseStateDev& s = st[(size_t)j];
     const PoseJobDev& J = c->p_jobs[(size_t)j];
@@ -952,8 +1064,8 @@ extern "C" int plsvo_poseopt_fetch(plsvo_ctx* c, int n, plsvo_poseopt_out* out) 
     o.estimated_scale = s.estimated_scale; o.error_init = s.error_init; o.error_final = s.error_final;
     o.num_obs_pt = s.num_obs_pt; o.num_obs_ls = s.num_obs_ls;
     o.iters = s.iters; o.iters_ref = s.iters_ref; o.status = s.status;
-    if (pko && J.n_pts > 0) memcpy(pko, pk.data() + J.pt_off, (size_t)J.n_pts);
-    if (sko && J.n_seg > 0) memcpy(sko, sk.data() + J.seg_off, (size_t)J.n_seg);
+    if (pko && J.n_pts > 0) memcpy(pko, pk + J.pt_off, (size_t)J.n_pts);
+    if (sko && J.n_seg > 0) memcpy(sko, sk + J.seg_off, (size_t)J.n_seg);
   }
   return PLSVO_OK;
 }
