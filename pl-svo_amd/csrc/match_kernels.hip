@@ -34,6 +34,7 @@ namespace plsvo_hip {
 
 __global__ void __launch_bounds__(MT) match_direct_kernel(const MatchBatchDev b) {
   __shared__ uint32_t s_patch[PB_ROWS * PB_WORDS * MT];   // patch_with_border_, word-major / lane-minor
+  __shared__ uint32_t s_src[SRC_ROWS * SRC_WORDS * MT];   // the keyframe-image window a warp reads, staged once (match_device.hpp::warp_affine_lds)
   const int lane = threadIdx.x;
   const int i = blockIdx.x * MT + lane;
   if (i >= b.n) return;
@@ -57,7 +58,7 @@ __global__ void __launch_bounds__(MT) match_direct_kernel(const MatchBatchDev b)
     warp_matrix_affine(cam, rpx0, rpx1, b.ref_f + 3 * i, depth_ref, T_cur_ref, level, A);
     search_level = best_search_level(A, b.n_pyr_levels - 1);
     const uint8_t* img_ref = b.pyr_base + (unsigned long long)b.frame_slot[rf] * b.slot_bytes + pyr_level_offset(b.width, b.height, level);
-    if (warp_affine_lds(A, img_ref, b.width >> level, b.height >> level, rpx0, rpx1, level, search_level, my)) {
+    if (warp_affine_lds(A, img_ref, b.width >> level, b.height >> level, rpx0, rpx1, level, search_level, my, s_src + lane)) {
       const int cols = b.width >> search_level, rows = b.height >> search_level;
       const uint8_t* cur_img = b.pyr_base + (unsigned long long)b.frame_slot[cf] * b.slot_bytes + pyr_level_offset(b.width, b.height, search_level);
       const double scale = (double)(1 << search_level);
