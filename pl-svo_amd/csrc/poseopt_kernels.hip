@@ -133,9 +133,21 @@ __device__ __forceinline__ double rcp_refined(double b) {
 }
 __device__ __forceinline__ double div_by_refined(double a, double b, double r) { const double q = a * r; return fma(fma(-b, q, a), r, q); }
 // x / z, y / z, 1 / z
+#ifndef PLSVO_PO_DIV_SHARE
+#define PLSVO_PO_DIV_SHARE 0   // measured on MI355X: the shared refined reciprocal (bit-identical quotients, exponent guards) is 11 % SLOWER than the compiler's divisions
+#endif
+#ifndef PLSVO_PO_FMA_ACC
+#define PLSVO_PO_FMA_ACC 1
+#endif
+#ifndef PLSVO_PO_RCP_MUL
+#define PLSVO_PO_RCP_MUL 0   // EXPERIMENT ONLY (not the reference's arithmetic): x / z, y / z as x * (1 / z), y * (1 / z)
+#endif
 __device__ __forceinline__ void div3_shared(double x, double y, double z, double& xq, double& yq, double& z_inv) {
+#if PLSVO_PO_RCP_MUL
+  z_inv = 1. / z; xq = x * z_inv; yq = y * z_inv; return;
+#endif
   const unsigned ex = exp_field(x), ey = exp_field(y), ez = exp_field(z);
-  if (exp_safe(min(ex, min(ey, ez)), max(ex, max(ey, ez)))) {
+  if (PLSVO_PO_DIV_SHARE && exp_safe(min(ex, min(ey, ez)), max(ex, max(ey, ez)))) {
     const double r = rcp_refined(z);
     xq = div_by_refined(x, z, r); yq = div_by_refined(y, z, r); z_inv = fma(fma(-z, r, 1.0), r, r);
   } else {
@@ -144,8 +156,11 @@ __device__ __forceinline__ void div3_shared(double x, double y, double z, double
 }
 // x / z, y / z
 __device__ __forceinline__ void div2_shared(double x, double y, double z, double& xq, double& yq) {
+#if PLSVO_PO_RCP_MUL
+  { const double zi = 1. / z; xq = x * zi; yq = y * zi; return; }
+#endif
   const unsigned ex = exp_field(x), ey = exp_field(y), ez = exp_field(z);
-  if (exp_safe(min(ex, min(ey, ez)), max(ex, max(ey, ez)))) {
+  if (PLSVO_PO_DIV_SHARE && exp_safe(min(ex, min(ey, ez)), max(ex, max(ey, ez)))) {
     const double r = rcp_refined(z);
     xq = div_by_refined(x, z, r); yq = div_by_refined(y, z, r);
   } else {
@@ -155,7 +170,7 @@ __device__ __forceinline__ void div2_shared(double x, double y, double z, double
 // a / b for a denominator that is the same for every feature of a pass (the MAD scales): r = rcp_refined(b), b_ok = b's exponent is in range
 __device__ __forceinline__ double div_const(double a, double b, double r, bool b_ok) {
   const unsigned ea = exp_field(a);
-  return (b_ok && exp_safe(ea, ea)) ? div_by_refined(a, b, r) : a / b;
+  return (PLSVO_PO_DIV_SHARE && b_ok && exp_safe(ea, ea)) ? div_by_refined(a, b, r) : a / b;
 }
 // Frame::jacobian_xyz2uv (include/plsvo/frame.h:138-160; plsvo_math.hpp::jacobian_xyz2uv) with its z_inv = 1. / z handed in
 __device__ __forceinline__ void jacobian_xyz2uv_zinv(double x, double y, double z_inv, double* J) {
@@ -228,6 +243,7 @@ __device__ __forceinline__ void popt_accumulate_feature(const PoseBatchDev& b, c
   // A += J^T J w, b -= J^T e w (:163-165): the two rows of J are weighted once (12 products) and every entry is two fused multiply-adds
   // -- 21 x 2 + 6 x 2 + 12 double instructions where (J_i J_j + J'_i J'_j) w, written out, issues 21 x 4 + 6 x 4; the sums differ from the
   // reference's in the last bits of each term only (A, b agree with the oracle to 1e-15)
+#if PLSVO_PO_FMA_ACC
   double wJ[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) wJ[k] = J[k] * weight;
@@ -238,6 +254,15 @@ __device__ __forceinline__ void popt_accumulate_feature(const PoseBatchDev& b, c
     for (int jj = i; jj < 6; ++jj) { acc[k] = fma(wJ[i], J[jj], fma(wJ[6 + i], J[6 + jj], acc[k])); ++k; }
 #pragma unroll
   for (int i = 0; i < 6; ++i) acc[21 + i] = fma(-wJ[i], e0, fma(-wJ[6 + i], e1, acc[21 + i]));
+#else
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int jj = i; jj < 6; ++jj) { acc[k] += (J[i] * J[jj] + J[6 + i] * J[6 + jj]) * weight; ++k; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) acc[21 + i] -= (J[i] * e0 + J[6 + i] * e1) * weight;
+#endif
   acc[27] += (e0 * e0 + e1 * e1) * weight;
   acc[28] += cnt_pt; acc[29] += cnt_ls;
 }
