@@ -333,7 +333,15 @@ template <int T>
 __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignBatchDev b, int cap, int scap, int level_hi, int level_lo, int do_init) {
   // longest-processing-time-first: the hardware hands out workgroups in blockIdx order, so the jobs with the most patches
   // start first and the launch tail is made of the cheapest frames
-  const int job_id = b.order ? b.order[blockIdx.x] : (int)blockIdx.x;
+  // Two workgroups per frame (b.pair, latency shapes only): blocks q and q + 8 of every group of 16 share frame (group, q) -- the hardware
+  // deals consecutive blocks to the eight XCDs in turn, so the pair shares an L2 (a speed bonus, never a correctness condition).
+  const bool pair = T >= kQuadMinThreads && b.pair != 0;
+  const int rank = pair ? (int)((blockIdx.x >> 3) & 1u) : 0;
+  const int wg_index = pair ? (int)((blockIdx.x >> 4) * 8u + (blockIdx.x & 7u)) : (int)blockIdx.x;
+  if (wg_index >= b.n_jobs) return;
+  const bool lead = rank == 0;                    // the workgroup that publishes the frame's state, pose and trace
+  const bool own_pts = !pair || rank == 0, own_segs = !pair || rank == 1;
+  const int job_id = b.order ? b.order[wg_index] : wg_index;
   const AlignJobDev job = b.jobs[job_id];
   AlignStateDev* st = b.state + job_id;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
 #endif
   const int lv_first = min(job.max_level, level_hi), lv_last = max(job.min_level, level_lo);
   const bool nothing = job.skip || lv_first < lv_last;
-  if (do_init) {
+  if (do_init && own_segs) {
     // solver reset() ([ext] vk::NLLSSolver::reset) and the working copy of the segment flags
     for (int s = tid; s < job.n_seg; s += T)
       b.seg_alive[job.seg_off + s] = b.seg_alive_in ? (b.seg_alive_in[job.seg_off + s] != 0) : 1;
@@ -373,6 +381,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
     if (do_init) {
 #pragma unroll
       for (int k = 0; k < 7; ++k) T_in[k] = b.T0[7 * job_id + k];
+      if (lead) {
 #pragma unroll
       for (int k = 0; k < 7; ++k) st->T[k] = T_in[k];
       st->chi2 = 1e10; st->n_meas = 0; st->stop = 0; st->log_count = 0; st->error = 0;
@@ -381,6 +390,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
       st->patch_levels = 0; st->patch_iters = 0; st->patch_iters_pt = 0; st->chi2_ties = 0; st->chi2_unarmed = 0;
       for (int k = 0; k < 8; ++k) st->phase_ticks[k] = 0;
       if (nothing && b.poses) for (int k = 0; k < 7; ++k) b.poses[7 * job_id + k] = T_in[k];
+      }
     } else if (!nothing) {   // per-level debug launches: the state crosses launches in HBM
 #pragma unroll
       for (int k = 0; k < 7; ++k) T_in[k] = st->T[k];
@@ -404,6 +414,10 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
   const size_t pbase = (size_t)job.patch_off;
   const int nfeat = job.n_pts + job.n_seg;
   double* const pxyz = b.patch_xyz + 3 * pbase;      // 3-D point of every slot (ref frame)
+  // two workgroups per frame: rank 0 works on the slots [0, line0) -- the points --, rank 1 on [line0, n_slots) -- the segments' samples
+  const int line0 = pair ? ((job.n_pts + 63) & ~63) : 0;
+  unsigned long long* const xb = pair ? b.xbuf + (size_t)job_id * 256 : nullptr;
+  unsigned xseq = b.xseq0;                            // (advanced identically by both workgroups: one per exchange)
 
   for (int level = lv_first; level >= lv_last; --level) {
     // (level geometry is recomputed instead of indexing the kernel-argument arrays with a run-time level,
@@ -421,9 +435,10 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
 #pragma unroll
     for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) if (l == level) { n_slots = job.n_slots[l]; long_lines = ((job.long_mask >> l) & 1) != 0; }
     if (n_slots > cap || n_slots > job.patch_cap) {  // host layout inconsistent with the launch: flag and bail out (uniform)
-      if (tid == 0) st->error = 1;
+      if (tid == 0 && lead) st->error = 1;
       return;
     }
+    const int slot_lo = (pair && rank == 1) ? min(line0, n_slots) : 0, slot_hi = (pair && rank == 0) ? min(line0, n_slots) : n_slots;
     block_sync<T>();  // previous level done with every LDS table
     TICKS(0);
 
@@ -435,7 +450,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
     // ---- slot table: every feature fills the slots the host layout gives it ----
     const double scale = 1.0 / (double)(1 << level);  // the reference's float scale is a power of two: exact
     int my_patches = 0;
-    for (int f = tid; f < nfeat; f += T) {
+    for (int f = (own_pts ? 0 : job.n_pts) + tid; f < (own_segs ? nfeat : job.n_pts); f += T) {
       if (f < job.n_pts) {
         // precomputeGaussNewtonParamsPoints :216-219: floor of the float position, 3 px border
         const int i = job.pt_off + f;
@@ -523,9 +538,9 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
       // the four rows -- the operations the throughput shapes repeat every iteration, bit-identical to the reference's precompute
       // (tests/test_refpatch_host.py) -- sharing every interpolated value between the rows that need it: 340 float instructions per slot
       // where four lanes per slot (a row each, the first form of this block) issued 4 x 230; measured 5-8 k -> ... cycles per level.
-      for (int pb = wave * 64; pb < n_slots; pb += T) {
+      for (int pb = slot_lo + wave * 64; pb < slot_hi; pb += T) {
         const int p = pb + lane;
-        if (p < n_slots && s_meta[p].x != SLOT_HOLE) {
+        if (p < slot_hi && s_meta[p].x != SLOT_HOLE) {
           const float u = s_uvr[2 * p], v = s_uvr[2 * p + 1];
           const PatchW pw = patch_weights(u, v);
           uint32_t d[7][3]; int shf[7];
@@ -612,7 +627,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
       for (int pass = (long_lines && !terms_only) ? 0 : 1; pass < 2; ++pass) {
         const bool write_abs = (!long_lines || pass == 0) && !terms_only;
         const bool accumulate = pass == 1 && !terms_only;
-        const int n_rounds_slots = terms_only ? min(n_slots, job.n_pts) : n_slots;   // a terms-only re-run visits the point slots only
+        const int n_rounds_slots = terms_only ? min(n_slots, job.n_pts) : (kQuad ? slot_hi : n_slots);   // a terms-only re-run visits the point slots only
 
         if constexpr (kQuad) {
         // ---- the pieces of the latency shape's pass ----
@@ -748,7 +763,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
           //  slot; a wave's unit took 12 k cycles, the two waves of a SIMD serialise on its issue port and the pass got SLOWER, 15.3 k ->
           //  16.8 k cycles per iteration incl. the wait for the partner wave.  profiles/r05_quad_pass_phase_ticks.log)
           const float4* const cache_f = reinterpret_cast<const float4*>(b.cache_ref);
-          for (int pb = wave * 64; pb < n_rounds_slots; pb += T) {
+          for (int pb = (terms_only ? 0 : slot_lo) + wave * 64; pb < n_rounds_slots; pb += T) {
             const int p = pb + lane;
             struct Rows3 { float4 r4, x4, y4; };
             auto load_row = [&](int r) -> Rows3 {          // patch row r of the slot's cached reference patch: does not depend on the pose
@@ -1061,7 +1076,16 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
       //    update decision
       if (wave == 0 && stage == last_stage) {
         // (after terms-only re-runs the totals of the iteration are read back from s_tot and the solve is simply done again)
-        const double tot = terms_only ? s_tot[lane & 31] : reduce_rows_finish<ROWS>(s_red);
+        double tot = terms_only ? s_tot[lane & 31] : reduce_rows_finish<ROWS>(s_red);
+        if constexpr (kQuad) {
+          if (pair) {   // two workgroups per frame: the partner's partial sums (value 31 carries its patch count of the level); both add in the
+            //             same order, so both hold the same totals bit for bit and take the same decisions from here on
+            if ((lane & 31) == 31) tot = (double)s_ctl[5];
+            const double theirs = pair_allgather32(xb, rank, xseq, tot);
+            ++xseq;   // (only wave 0 exchanges, and only its copy of the counter is ever read)
+            tot = rank == 0 ? tot + theirs : theirs + tot;
+          }
+        }
         if (lane < 32 && !terms_only) s_tot[lane] = tot;   // (0..26 the system, 27..30 chi2 / n_meas / work counters: a terms-only re-run reads them back)
         TICK(3);
         double x[6];
@@ -1090,14 +1114,26 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
         }
         if (tie) {   // wave-uniform
           if (b.chi_lds_pts > 0)
+            // (two workgroups per frame: rank 0 re-adds the points' terms, rank 1 the lines' -- each sum starts at +0, so each side's
+            //  output IS its partial sum)
             exact_chi2_pair_lds((const PLSVO_LDS float*)(s_win + (iter & 1) * b.chi_lds_pts * 16), (const PLSVO_LDS float*)(s_win + ((iter & 1) ^ 1) * b.chi_lds_pts * 16),
-                                job.n_pts, job.n_seg, iter, (const PLSVO_LDS int*)s_dead, (const PLSVO_LDS float*)s_lterm, scap, (PLSVO_LDS float*)s_lterm + 2 * scap);
+                                own_pts ? job.n_pts : 0, own_segs ? job.n_seg : 0, iter, (const PLSVO_LDS int*)s_dead, (const PLSVO_LDS float*)s_lterm, scap, (PLSVO_LDS float*)s_lterm + 2 * scap);
           else
             exact_chi2_pair((const PLSVO_GLOBAL float*)(b.chi_terms + (size_t)(iter & 1) * b.chi_plane + (size_t)job.pt_off * 16),
                             (const PLSVO_GLOBAL float*)(b.chi_terms + (size_t)((iter & 1) ^ 1) * b.chi_plane + (size_t)job.pt_off * 16),
                             job.n_pts, job.n_seg, iter, (const PLSVO_LDS int*)s_dead, (PLSVO_LDS float*)s_win, (const PLSVO_LDS float*)s_lterm, scap,
                             (PLSVO_LDS float*)s_lterm + 2 * scap);
-          const float FA = s_lterm[2 * scap], FB = s_lterm[2 * scap + 1];   // chi2 of this / of the previous iteration, before the division
+          float FA = s_lterm[2 * scap], FB = s_lterm[2 * scap + 1];   // chi2 of this / of the previous iteration, before the division
+          if constexpr (kQuad) {
+            if (pair) {   // chi2 = pt_chi2 + seg_chi2 (:171): the points' sums from rank 0, the lines' from rank 1
+              const double mine = (lane & 31) == 0 ? (double)FA : ((lane & 31) == 1 ? (double)FB : 0.0);
+              const double theirs = pair_allgather32(xb, rank, xseq, mine);
+              ++xseq;
+              const float TA = (float)readlane_f64(theirs, 0), TB = (float)readlane_f64(theirs, 1);
+              FA = rank == 0 ? __fadd_rn(FA, TA) : __fadd_rn(TA, FA);
+              FB = rank == 0 ? __fadd_rn(FB, TB) : __fadd_rn(TB, FB);
+            }
+          }
           new_chi2 = (double)(FA / (float)nm);
           old_chi2 = (double)(FB / (float)(unsigned long long)(s_pose[30] + 0.5));
         }
@@ -1132,7 +1168,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
           se3_store(model, s_pose + 12);
           quat_to_matrix(model.q, s_pose); s_pose[9] = model.t[0]; s_pose[10] = model.t[1]; s_pose[11] = model.t[2];
           s_ctl[1] = stop; s_ctl[0] = brk;
-          if (b.log) {
+          if (b.log && lead) {
             const int lc = st->log_count;
             if (lc < b.log_cap) {
               plsvo_align_iterlog* r = b.log + (size_t)job_id * b.log_cap + lc;
@@ -1148,7 +1184,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
       block_sync<T>();
       if (stage == 0) redo_mask = s_ctl[10];   // (0 unless wave 0 deferred its decision)
      }   // stages of the iteration
-      if (b.log && tid == 0) {  // H and Jres of the trace come from s_tot (written by lanes 0..26 above)
+      if (b.log && tid == 0 && lead) {  // H and Jres of the trace come from s_tot (written by lanes 0..26 above)
         const int lc = st->log_count - 1;
         if (lc >= 0 && lc < b.log_cap) {
           plsvo_align_iterlog* r = b.log + (size_t)job_id * b.log_cap + lc;
@@ -1164,14 +1200,14 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
     }
 
     if (tid == 0) {   // work counters stay in LDS until the end of the launch (a global read-modify-write here would stall every level)
-      st->iters[level] = s_ctl[2];
-      s_pose[28] += (double)s_ctl[5];
+      if (lead) st->iters[level] = s_ctl[2];
+      s_pose[28] += pair ? s_tot[31] : (double)s_ctl[5];   // (two workgroups per frame: value 31 of the exchanged totals = both patch counts)
       s_pose[29] += s_pose[27];
     }
   }  // levels
 
   block_sync<T>();
-  if (tid == 0) {
+  if (tid == 0 && lead) {
     for (int k = 0; k < 7; ++k) st->T[k] = s_pose[12 + k];
     if (b.poses) for (int k = 0; k < 7; ++k) b.poses[7 * job_id + k] = s_pose[12 + k];
     st->chi2 = s_pose[26];
@@ -1201,7 +1237,15 @@ template <int T>
 static hipError_t launch_fused_T(const AlignBatchDev& b, int cap, int scap, int level_hi, int level_lo, int do_init, size_t lds, hipStream_t stream) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(align_fused_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((align_fused_kernel<T>), dim3(b.n_jobs), dim3(T), lds, stream, b, cap, scap, level_hi, level_lo, do_init);
+  // one workgroup per frame, or (b.pair) two: blocks q and q + 8 of every group of 16
+  const unsigned grid = (T >= kQuadMinThreads && b.pair) ? (unsigned)((b.n_jobs + 7) / 8) * 16u : (unsigned)b.n_jobs;
+#ifdef PLSVO_WAVE_EMU
+  wave_emu::pair_stride() = (T >= kQuadMinThreads && b.pair) ? 8 : 0;   // the emulator runs the two workgroups of a frame on two OS threads
+#endif
+  hipLaunchKernelGGL((align_fused_kernel<T>), dim3(grid), dim3(T), lds, stream, b, cap, scap, level_hi, level_lo, do_init);
+#ifdef PLSVO_WAVE_EMU
+  wave_emu::pair_stride() = 0;
+#endif
   return hipGetLastError();
 }
 

@@ -108,6 +108,10 @@ struct plsvo_ctx {
   DevBuf a_d_state, a_d_alive;   // (inputs: a_d_blob)
   DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_chi, a_d_log, a_d_poses;
   size_t a_patch_total = 0;                 // patch slots of the staged batch (all jobs, all levels' maximum)
+  int a_seg_align = 32;                     // the staged layout's segment alignment (64: two workgroups per frame are possible)
+  DevBuf a_d_xbuf;                          // two workgroups per frame: their exchange granules (2 KB per frame, zeroed once)
+  unsigned int x_launch = 0;                // launches that used it (tags = launch << 10 | exchange: never repeated)
+  bool env_align_no_pair = false;
   AlignBatchDev a_b{};
 
   // pose-opt batch
@@ -243,6 +247,7 @@ static int create_ctx(int device_id, void* stream, bool use_given_stream, plsvo_
   if (const char* s = getenv("PLSVO_POSEOPT_THREADS")) { const int v = atoi(s); if (v == 16 || v == 64 || v == 256 || v == 512) c->env_poseopt_threads = v; }
   if (const char* s = getenv("PLSVO_ALIGN_PER_LEVEL")) c->env_align_per_level = atoi(s) != 0;
   c->env_align_no_lpt = getenv("PLSVO_ALIGN_NO_LPT") != nullptr;
+  c->env_align_no_pair = getenv("PLSVO_ALIGN_NO_PAIR") != nullptr;   // (A/B: one workgroup per frame also for small batches)
   c->env_host_timing = getenv("PLSVO_HOST_TIMING") != nullptr;
   *out = c;
   return PLSVO_OK;
@@ -254,6 +259,7 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+  c->a_d_xbuf.release();
   DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_tiled, &c->pyr_upload, &c->a_d_blob, &c->a_d_state, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv, &c->a_d_cref,
                      &c->a_d_chi, &c->a_d_log, &c->a_d_poses, &c->p_d_blob, &c->p_d_state, &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64,
                      &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out, &c->ch_d_blob, &c->ch_d_work, &c->ch_d_po, &c->ch_d_state,
@@ -502,11 +508,12 @@ static int upload(plsvo_ctx* c, DevBuf& buf, const std::vector<T>& v) {
 // from the next multiple of 32 in feature order, and a segment with N <= 32 samples never straddles a multiple of 32, so that
 // all its samples sit in one wave-round of the kernel.  Segments without a landmark on entry, or whose end points fail the
 // 3-pixel border test of the level (src/sparse_img_align.cpp:299-301), get no slots (code -1).  Host-only arithmetic.
-extern "C" int plsvo_align_slot_layout(const plsvo_align_in* in, int level, int32_t* seg_code, int32_t* n_slots, int32_t* long_lines,
-                                       long long* n_patches) {
+// seg_align: the segments' first slot is a multiple of it (32: a wave-round of the throughput shapes; 64: small batches, whose point and
+// segment slots may go to two workgroups -- a multiple of 32 as well, so every launch shape reads either layout)
+static int slot_layout(const plsvo_align_in* in, int level, int seg_align, int32_t* seg_code, int32_t* n_slots, int32_t* long_lines, long long* n_patches) {
   if (!in || level < 0 || level >= PLSVO_MAX_LEVELS || in->n_pts < 0 || in->n_seg < 0 || (in->n_seg > 0 && !seg_code)) return PLSVO_E_INVALID;
   const plsvo_align_in& a = *in;
-  long long cur = a.n_seg > 0 ? (((long long)a.n_pts + 31) & ~31LL) : (long long)a.n_pts;
+  long long cur = a.n_seg > 0 ? (((long long)a.n_pts + seg_align - 1) & ~(long long)(seg_align - 1)) : (long long)a.n_pts;
   long long used = a.n_pts, n_real = a.n_pts;
   int any_long = 0;
   const double scale = 1.0 / (double)(1 << level);
@@ -532,6 +539,10 @@ extern "C" int plsvo_align_slot_layout(const plsvo_align_in* in, int level, int3
   if (long_lines) *long_lines = any_long;
   if (n_patches) *n_patches = n_real;
   return PLSVO_OK;
+}
+extern "C" int plsvo_align_slot_layout(const plsvo_align_in* in, int level, int32_t* seg_code, int32_t* n_slots, int32_t* long_lines,
+                                       long long* n_patches) {
+  return slot_layout(in, level, 32, seg_code, n_slots, long_lines, n_patches);
 }
 
 // Up to three device ranges to the host with ONE wait: through the context's pinned download buffer when they fit (a per-frame caller's
@@ -601,6 +612,10 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   std::vector<double> T0((size_t)n * 7), ptpx, ptxyz, spx, epx, len, sp, sq;
   std::vector<uint8_t> alive;
   int gmax = -1, gmin = 99;
+  // small batches may run two workgroups per frame (points | segments: plsvo_align_run decides from the launch shape): their segments start
+  // at a multiple of 64 slots
+  const int cus_stage = c->cu_count > 0 ? c->cu_count : 256;
+  const int seg_align = (2 * n <= cus_stage) ? 64 : 32;
   int caps[PLSVO_MAX_LEVELS] = { 0 };
   std::vector<long long> work((size_t)n, 0);   // patches summed over the levels, per job: the launch-order key
   std::vector<int> seg_slot[PLSVO_MAX_LEVELS];   // per level, one entry per segment of the batch
@@ -641,7 +656,7 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
     std::vector<int> codes((size_t)std::max(a.n_seg, 1));
     for (int l = a.max_level; l >= a.min_level; --l) {
       int n_slots = 0, long_lines = 0; long long n_real = 0;
-      const int lrc = plsvo_align_slot_layout(&a, l, codes.data(), &n_slots, &long_lines, &n_real);
+      const int lrc = slot_layout(&a, l, seg_align, codes.data(), &n_slots, &long_lines, &n_real);
       if (lrc == PLSVO_E_CAPACITY) return fail(c, PLSVO_E_CAPACITY, "align_stage: a segment with more than 2047 samples or more than 2^20 patch slots in one job");
       if (lrc != PLSVO_OK) return fail(c, lrc, "align_stage: slot layout failed");
       seg_slot[(size_t)l].insert(seg_slot[(size_t)l].end(), codes.begin(), codes.begin() + a.n_seg);
@@ -706,12 +721,14 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   b.log = c->a_trace_cap > 0 ? c->a_d_log.as<plsvo_align_iterlog>() : nullptr;
   b.log_cap = c->a_trace_cap;
   b.n_jobs = n;
+  b.pair = 0; b.xseq0 = 0; b.xbuf = nullptr;   // (plsvo_align_run decides)
   b.order = reinterpret_cast<const int*>(base + o_order);
   c->a_jobs.swap(jobs);
   c->a_n = n; c->a_total_seg = (int)alive.size(); c->a_gmax = gmax; c->a_gmin = gmin;
   for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) c->a_cap[l] = caps[l];
   c->a_scap = 4;
   for (int j = 0; j < n; ++j) c->a_scap = std::max(c->a_scap, in[j].n_seg);
+  c->a_seg_align = seg_align;
   c->a_staged = true; c->a_run_seq = 0;
   return PLSVO_OK;
 }
@@ -781,6 +798,24 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
     slots.reserve(2 * c->a_jobs.size());
     for (const AlignJobDev& J : c->a_jobs) { slots.push_back(J.ref_slot); slots.push_back(J.cur_slot); }
     const int rc_t = retile_stale(c, slots); if (rc_t) return rc_t;
+  }
+  // TWO WORKGROUPS PER FRAME: a frame that has a CU to itself is bound by that CU's instruction issue (two 64-slot wave-rounds per SIMD per
+  // pass at 380 slots); with at most cu_count / 2 frames a second CU takes the segment slots, the two exchange 32 partial sums per
+  // iteration through L2 (~1 us) and both run the identical solver.  Needs the latency shape, the chi2 planes in LDS (no deferred
+  // decisions) and the layout staged for it; the per-level debug launches keep one workgroup.
+  const int cus_run = c->cu_count > 0 ? c->cu_count : 256;
+  const bool pair = threads >= kQuadMinThreads && chi_lds_pts > 0 && c->a_seg_align == 64 && 2 * c->a_n <= cus_run && !c->env_align_no_pair &&
+                    !c->env_align_per_level && have_levels;
+  c->a_b.pair = pair ? 1 : 0;
+  if (pair) {
+    const size_t xbytes = (size_t)c->a_n * 256 * sizeof(unsigned long long);
+    if (c->a_d_xbuf.cap < xbytes) {
+      HIP_TRY(c, c->a_d_xbuf.ensure(std::max(xbytes, (size_t)128 * 2048)));
+      HIP_TRY(c, hipMemsetAsync(c->a_d_xbuf.p, 0, c->a_d_xbuf.cap, c->stream));   // tag 0 is never used
+    }
+    c->a_b.xbuf = c->a_d_xbuf.as<unsigned long long>();
+    c->x_launch = (c->x_launch + 1u) & 0x3fffffu; if (c->x_launch == 0) c->x_launch = 1;
+    c->a_b.xseq0 = c->x_launch << 10;
   }
   if (threads >= kQuadMinThreads) {   // latency shapes keep the reference patches as float rows: 192 B per slot (small batches only: <= 4 frames per CU)
     HIP_TRY(c, c->a_d_cref.ensure(c->a_patch_total * 192));

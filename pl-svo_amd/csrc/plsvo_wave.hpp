@@ -317,6 +317,53 @@ __device__ __forceinline__ void wave_solve6_core(double m, double* x, int flavou
   for (int r = 0; r < 6; ++r) x[r] = readlane_f64(xi, 8 * r + 6);
 }
 
+// ------------------------------------------------------------------------------------------------
+// All-gather of 32 doubles between the TWO workgroups that share a frame (align_kernels.hip, latency shapes): called by one full wave of
+// each; lane l hands in value l & 31 (lanes 32..63 repeat lanes 0..31) and gets the PEER's value l & 31 back.
+// Transport: data-tagged 8-byte granules {tag << 32 | half of a double}, one per lane, each written by ONE agent-scope relaxed store
+// (global_store_dwordx2 ... sc1: write-through, visible to the other CU whichever XCD it sits on) and polled with agent-scope relaxed loads
+// (sc1: never served from this CU's L1) until the tag is the exchange's sequence number -- data and tag arrive together, so no fence,
+// no flag, no ordering between granules is needed (MI355X_MICROARCH.md, "handoff-1to1": 0.8-1.0 us on an idle chip).  Two buffers used in
+// turn (seq & 1): a workgroup can be at most one exchange ahead of its peer, so the granules of exchange n are intact until the peer has
+// read them.  `seq` must be non-zero, the same on both sides, and never repeat within the buffer's life (host: launch number << 10).
+// xb: the frame's 2 (parity) x 2 (rank) x 64 granules.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void granule_store(unsigned long long* p, unsigned long long v) {
+#ifdef PLSVO_WAVE_EMU
+  __atomic_store_n(p, v, __ATOMIC_RELEASE);
+#else
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ unsigned long long granule_load(const unsigned long long* p) {
+#ifdef PLSVO_WAVE_EMU
+  return __atomic_load_n(p, __ATOMIC_ACQUIRE);
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ double pair_allgather32(unsigned long long* xb, int rank, unsigned seq, double mine) {
+  const int lane = threadIdx.x & 63;
+  const double v = __shfl(mine, lane >> 1, 64);                                   // lane l ships half (l & 1) of value l >> 1
+  const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
+  unsigned long long* const own = xb + (((seq & 1u) * 2u + (unsigned)rank) * 64u + (unsigned)lane);
+  const unsigned long long* const peer = xb + (((seq & 1u) * 2u + (unsigned)(rank ^ 1)) * 64u + (unsigned)lane);
+  granule_store(own, ((unsigned long long)seq << 32) | (unsigned long long)half);
+  unsigned long long g;
+  for (;;) {
+    g = granule_load(peer);
+    if (!__any((unsigned)(g >> 32) != seq)) break;
+#ifdef PLSVO_WAVE_EMU
+    wave_emu_yield_thread();
+#else
+    __builtin_amdgcn_s_sleep(2);
+#endif
+  }
+  const int k = lane & 31;
+  const unsigned lo = (unsigned)__shfl((int)(unsigned)g, 2 * k, 64), hi = (unsigned)__shfl((int)(unsigned)g, 2 * k + 1, 64);
+  return __hiloint2double((int)hi, (int)lo);
+}
+
 __device__ __forceinline__ Quat quat_normalized_fast(const Quat& a) {
   const double inv = fast_rcp(fast_sqrt(a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w));
   Quat r = { a.x * inv, a.y * inv, a.z * inv, a.w * inv };

@@ -116,81 +116,10 @@ __device__ __forceinline__ float norm2_f32(float a, float b) {
 // 1.0 / (1 << level) (the reference's scale of a pyramid level, :119-120): a power of two, written into the exponent -- exact
 __device__ __forceinline__ double pow2_neg(int level) { return __hiloint2double((1023 - level) << 20, 0); }
 
-// ---- IEEE quotients that share their denominator ---------------------------------------------------------------------------------------
-// The reference divides x / z, y / z and 1 / z (world2cam + Frame::jacobian_xyz2uv) and error / scale one by one; for an IEEE double
-// division hipcc emits  r = rcp(b); two Newton steps on r;  q = a r;  q' = fma(fma(-b, q, a), r, q)  between v_div_scale / v_div_fmas /
-// v_div_fixup, which are the identity unless an operand's exponent could overflow an intermediate.  With every operand's exponent inside
-// [-256, 256] (checked on the high dwords: anything else -- zero, denormal, huge, Inf, NaN -- takes the plain `/`) the refined reciprocal is
-// formed ONCE per denominator and each further quotient costs three instructions instead of eleven: the very same fma sequence, hence
-// bit-identical quotients (the alignment's robust weight uses the same argument, robust_weight.hpp, checked exhaustively there).
-__device__ __forceinline__ unsigned exp_field(double v) { return (unsigned)__double2hiint(v) & 0x7ff00000u; }
-__device__ __forceinline__ bool exp_safe(unsigned lo, unsigned hi) { return lo >= ((1023u - 256u) << 20) && hi <= ((1023u + 256u) << 20); }
-__device__ __forceinline__ double rcp_refined(double b) {
-  double r = __builtin_amdgcn_rcp(b);
-  r = fma(fma(-b, r, 1.0), r, r);
-  r = fma(fma(-b, r, 1.0), r, r);
-  return r;
-}
-__device__ __forceinline__ double div_by_refined(double a, double b, double r) { const double q = a * r; return fma(fma(-b, q, a), r, q); }
-// x / z, y / z, 1 / z
-#ifndef PLSVO_PO_DIV_SHARE
-#define PLSVO_PO_DIV_SHARE 0   // measured on MI355X: the shared refined reciprocal (bit-identical quotients, exponent guards) is 11 % SLOWER than the compiler's divisions
-#endif
-#ifndef PLSVO_PO_FMA_ACC
-#define PLSVO_PO_FMA_ACC 1
-#endif
-#ifndef PLSVO_PO_RCP_MUL
-#define PLSVO_PO_RCP_MUL 0   // EXPERIMENT ONLY (not the reference's arithmetic): x / z, y / z as x * (1 / z), y * (1 / z)
-#endif
-__device__ __forceinline__ void div3_shared(double x, double y, double z, double& xq, double& yq, double& z_inv) {
-#if PLSVO_PO_RCP_MUL
-  z_inv = 1. / z; xq = x * z_inv; yq = y * z_inv; return;
-#endif
-  const unsigned ex = exp_field(x), ey = exp_field(y), ez = exp_field(z);
-  if (PLSVO_PO_DIV_SHARE && exp_safe(min(ex, min(ey, ez)), max(ex, max(ey, ez)))) {
-    const double r = rcp_refined(z);
-    xq = div_by_refined(x, z, r); yq = div_by_refined(y, z, r); z_inv = fma(fma(-z, r, 1.0), r, r);
-  } else {
-    xq = x / z; yq = y / z; z_inv = 1. / z;
-  }
-}
-// x / z, y / z
-__device__ __forceinline__ void div2_shared(double x, double y, double z, double& xq, double& yq) {
-#if PLSVO_PO_RCP_MUL
-  { const double zi = 1. / z; xq = x * zi; yq = y * zi; return; }
-#endif
-  const unsigned ex = exp_field(x), ey = exp_field(y), ez = exp_field(z);
-  if (PLSVO_PO_DIV_SHARE && exp_safe(min(ex, min(ey, ez)), max(ex, max(ey, ez)))) {
-    const double r = rcp_refined(z);
-    xq = div_by_refined(x, z, r); yq = div_by_refined(y, z, r);
-  } else {
-    xq = x / z; yq = y / z;
-  }
-}
-// a / b for a denominator that is the same for every feature of a pass (the MAD scales): r = rcp_refined(b), b_ok = b's exponent is in range
-__device__ __forceinline__ double div_const(double a, double b, double r, bool b_ok) {
-  const unsigned ea = exp_field(a);
-  return (PLSVO_PO_DIV_SHARE && b_ok && exp_safe(ea, ea)) ? div_by_refined(a, b, r) : a / b;
-}
-// Frame::jacobian_xyz2uv (include/plsvo/frame.h:138-160; plsvo_math.hpp::jacobian_xyz2uv) with its z_inv = 1. / z handed in
-__device__ __forceinline__ void jacobian_xyz2uv_zinv(double x, double y, double z_inv, double* J) {
-  const double z_inv_2 = z_inv * z_inv;
-  J[0] = -z_inv; J[1] = 0.0; J[2] = x * z_inv_2; J[3] = y * J[2]; J[4] = -(1.0 + x * J[2]); J[5] = y * z_inv;
-  J[6] = 0.0; J[7] = -z_inv; J[8] = y * z_inv_2; J[9] = 1.0 + y * J[8]; J[10] = -J[3]; J[11] = -x * z_inv;
-}
-
 // one feature of a Gauss-Newton iteration (src/pose_optimizer.cpp:107-166 / :473-533): residual, Jacobian, Tukey weight, accumulation
 // into acc (0..20 A upper row-major, 21..26 b, 27 chi2, 28 #points, 29 #segments)
-struct ScaleRcp { double r_pt, r_ls; bool ok_pt, ok_ls; };   // refined reciprocals of the two MAD scales of a pass (div_const)
-__device__ __forceinline__ ScaleRcp make_scale_rcp(double scale_pt, double scale_ls) {
-  ScaleRcp sc;
-  const unsigned ep = exp_field(scale_pt), el = exp_field(scale_ls);
-  sc.ok_pt = exp_safe(ep, ep); sc.ok_ls = exp_safe(el, el);
-  sc.r_pt = sc.ok_pt ? rcp_refined(scale_pt) : 0.0; sc.r_ls = sc.ok_ls ? rcp_refined(scale_ls) : 0.0;
-  return sc;
-}
 __device__ __forceinline__ void popt_accumulate_feature(const PoseBatchDev& b, const PoseJobDev& job, int f, const double (&P)[12], double scale_pt,
-                                                        double scale_ls, const ScaleRcp& sc, bool first_iter, double* init_vec, const double* obs, double* acc) {
+                                                        double scale_ls, bool first_iter, double* init_vec, const double* obs, double* acc) {
   const int np = job.n_pts;
   const double R0 = P[0], R1 = P[1], R2 = P[2], R3 = P[3], R4 = P[4], R5 = P[5], R6 = P[6], R7 = P[7], R8 = P[8], t0 = P[9], t1 = P[10], t2 = P[11];
   double J[12], e0, e1, weight, cnt_pt, cnt_ls;   // (the two counters are added at the common tail: `acc[28 + is_segment] += 1` would be a dynamically indexed private array, i.e. scratch)
@@ -199,17 +128,15 @@ __device__ __forceinline__ void popt_accumulate_feature(const PoseBatchDev& b, c
     if (!b.pt_keep[i]) return;
     const double x = b.pt_pos[3 * i], y = b.pt_pos[3 * i + 1], z = b.pt_pos[3 * i + 2];
     const double xyz[3] = { R0 * x + R1 * y + R2 * z + t0, R3 * x + R4 * y + R5 * z + t1, R6 * x + R7 * y + R8 * z + t2 };
-    double uq, vq, z_inv;
-    div3_shared(xyz[0], xyz[1], xyz[2], uq, vq, z_inv);
-    jacobian_xyz2uv_zinv(xyz[0], xyz[1], z_inv, J);
-    e0 = obs[2 * f] - uq;
-    e1 = obs[2 * f + 1] - vq;
+    jacobian_xyz2uv(xyz, J);
+    e0 = obs[2 * f] - xyz[0] / xyz[2];
+    e1 = obs[2 * f + 1] - xyz[1] / xyz[2];
     const double sic = pow2_neg(b.pt_level[i]);
     e0 *= sic; e1 *= sic;
     if (first_iter) init_vec[f] = e0 * e0 + e1 * e1;
 #pragma unroll
     for (int k = 0; k < 12; ++k) J[k] *= sic;
-    weight = (double)tukey_weight((float)div_const(sqrt(e0 * e0 + e1 * e1), scale_pt, sc.r_pt, sc.ok_pt));
+    weight = (double)tukey_weight((float)(sqrt(e0 * e0 + e1 * e1) / scale_pt));
     cnt_pt = 1.0; cnt_ls = 0.0;
   } else {
     const int s = job.seg_off + (f - np);
@@ -219,14 +146,11 @@ __device__ __forceinline__ void popt_accumulate_feature(const PoseBatchDev& b, c
     const double ex = b.seg_epos[3 * s], ey = b.seg_epos[3 * s + 1], ez = b.seg_epos[3 * s + 2];
     const double xs[3] = { R0 * sx + R1 * sy + R2 * sz + t0, R3 * sx + R4 * sy + R5 * sz + t1, R6 * sx + R7 * sy + R8 * sz + t2 };
     const double xe[3] = { R0 * ex + R1 * ey + R2 * ez + t0, R3 * ex + R4 * ey + R5 * ez + t1, R6 * ex + R7 * ey + R8 * ez + t2 };
-    double su, sv, s_zinv, eu, ev, e_zinv;
-    div3_shared(xs[0], xs[1], xs[2], su, sv, s_zinv);
-    div3_shared(xe[0], xe[1], xe[2], eu, ev, e_zinv);
-    jacobian_xyz2uv_zinv(xs[0], xs[1], s_zinv, Js);
-    jacobian_xyz2uv_zinv(xe[0], xe[1], e_zinv, Je);
+    jacobian_xyz2uv(xs, Js);
+    jacobian_xyz2uv(xe, Je);
     const double l0 = b.seg_line[3 * s], l1 = b.seg_line[3 * s + 1], l2 = b.seg_line[3 * s + 2];
-    const float ds = (float)(l0 * su + l1 * sv + l2 * 1.0);
-    const float de = (float)(l0 * eu + l1 * ev + l2 * 1.0);
+    const float ds = (float)(l0 * (xs[0] / xs[2]) + l1 * (xs[1] / xs[2]) + l2 * 1.0);
+    const float de = (float)(l0 * (xe[0] / xe[2]) + l1 * (xe[1] / xe[2]) + l2 * 1.0);
     const double sic = pow2_neg(b.seg_level[s]);
     e0 = (double)ds * sic; e1 = (double)de * sic;
     if (first_iter) init_vec[f] = e0 * e0 + e1 * e1;
@@ -237,13 +161,14 @@ __device__ __forceinline__ void popt_accumulate_feature(const PoseBatchDev& b, c
       J[c] = l0 * (Js[c] * ks) + l1 * (Js[6 + c] * ks);
       J[6 + c] = l0 * (Je[c] * ks) + l1 * (Je[6 + c] * ks);
     }
-    weight = (double)tukey_weight((float)div_const(en, scale_ls, sc.r_ls, sc.ok_ls));
+    weight = (double)tukey_weight((float)(en / scale_ls));
     cnt_pt = 0.0; cnt_ls = 1.0;
   }
   // A += J^T J w, b -= J^T e w (:163-165): the two rows of J are weighted once (12 products) and every entry is two fused multiply-adds
   // -- 21 x 2 + 6 x 2 + 12 double instructions where (J_i J_j + J'_i J'_j) w, written out, issues 21 x 4 + 6 x 4; the sums differ from the
-  // reference's in the last bits of each term only (A, b agree with the oracle to 1e-15)
-#if PLSVO_PO_FMA_ACC
+  // reference's in the last bits of each term only (A, b agree with the oracle to 1e-15).  Measured -2 % per launch; sharing a refined
+  // reciprocal between the quotients of one denominator (bit-identical, exponent-guarded) measured +11 % and is not in the tree
+  // (profiles/r05_poseopt_experiments.log).
   double wJ[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) wJ[k] = J[k] * weight;
@@ -254,15 +179,6 @@ __device__ __forceinline__ void popt_accumulate_feature(const PoseBatchDev& b, c
     for (int jj = i; jj < 6; ++jj) { acc[k] = fma(wJ[i], J[jj], fma(wJ[6 + i], J[6 + jj], acc[k])); ++k; }
 #pragma unroll
   for (int i = 0; i < 6; ++i) acc[21 + i] = fma(-wJ[i], e0, fma(-wJ[6 + i], e1, acc[21 + i]));
-#else
-  int k = 0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int jj = i; jj < 6; ++jj) { acc[k] += (J[i] * J[jj] + J[6 + i] * J[6 + jj]) * weight; ++k; }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) acc[21 + i] -= (J[i] * e0 + J[6 + i] * e1) * weight;
-#endif
   acc[27] += (e0 * e0 + e1 * e1) * weight;
   acc[28] += cnt_pt; acc[29] += cnt_ls;
 }
@@ -278,9 +194,7 @@ __device__ __forceinline__ float popt_scale_error(const PoseBatchDev& b, const P
     const double fz = b.pt_f[3 * i + 2];
     const double ox = b.pt_f[3 * i] / fz, oy = b.pt_f[3 * i + 1] / fz;
     obs[2 * f] = ox; obs[2 * f + 1] = oy;
-    double uq, vq;
-    div2_shared(xc, yc, zc, uq, vq);
-    double e0 = ox - uq, e1 = oy - vq;
+    double e0 = ox - xc / zc, e1 = oy - yc / zc;
     const double sic = pow2_neg(b.pt_level[i]);
     e0 *= sic; e1 *= sic;
     return (float)sqrt(e0 * e0 + e1 * e1);
@@ -291,11 +205,8 @@ __device__ __forceinline__ float popt_scale_error(const PoseBatchDev& b, const P
   const double xs0 = R0 * sx + R1 * sy + R2 * sz + t0, xs1 = R3 * sx + R4 * sy + R5 * sz + t1, xs2 = R6 * sx + R7 * sy + R8 * sz + t2;
   const double xe0 = R0 * ex + R1 * ey + R2 * ez + t0, xe1 = R3 * ex + R4 * ey + R5 * ez + t1, xe2 = R6 * ex + R7 * ey + R8 * ez + t2;
   const double l0 = b.seg_line[3 * s], l1 = b.seg_line[3 * s + 1], l2 = b.seg_line[3 * s + 2];
-  double su, sv, eu, ev;
-  div2_shared(xs0, xs1, xs2, su, sv);
-  div2_shared(xe0, xe1, xe2, eu, ev);
-  const float es = (float)(l0 * su + l1 * sv + l2 * 1.0);   // not scaled by the level (:84-87)
-  const float ee = (float)(l0 * eu + l1 * ev + l2 * 1.0);
+  const float es = (float)(l0 * (xs0 / xs2) + l1 * (xs1 / xs2) + l2 * 1.0);   // not scaled by the level (:84-87)
+  const float ee = (float)(l0 * (xe0 / xe2) + l1 * (xe1 / xe2) + l2 * 1.0);
   return norm2_f32(es, ee);
 }
 
@@ -311,9 +222,7 @@ __device__ __forceinline__ double popt_cull_feature(const PoseBatchDev& b, const
     const int i = job.pt_off + f;
     const double x = b.pt_pos[3 * i], y = b.pt_pos[3 * i + 1], z = b.pt_pos[3 * i + 2];
     const double xc = R0 * x + R1 * y + R2 * z + t0, yc = R3 * x + R4 * y + R5 * z + t1, zc = R6 * x + R7 * y + R8 * z + t2;
-    double uq, vq;
-    div2_shared(xc, yc, zc, uq, vq);
-    e0 = obs[2 * f] - uq; e1 = obs[2 * f + 1] - vq;
+    e0 = obs[2 * f] - xc / zc; e1 = obs[2 * f + 1] - yc / zc;
     const double sic = pow2_neg(b.pt_level[i]);
     e0 *= sic; e1 *= sic;
     if (sqrt(e0 * e0 + e1 * e1) > thr_pt) { b.pt_keep[i] = 0; deleted = 1; }
@@ -325,11 +234,8 @@ __device__ __forceinline__ double popt_cull_feature(const PoseBatchDev& b, const
     const double xe0 = R0 * ex + R1 * ey + R2 * ez + t0, xe1 = R3 * ex + R4 * ey + R5 * ez + t1, xe2 = R6 * ex + R7 * ey + R8 * ez + t2;
     const double l0 = b.seg_line[3 * s], l1 = b.seg_line[3 * s + 1], l2 = b.seg_line[3 * s + 2];
     const double sic = pow2_neg(b.seg_level[s]);
-    double su, sv, eu, ev;
-    div2_shared(xs0, xs1, xs2, su, sv);
-    div2_shared(xe0, xe1, xe2, eu, ev);
-    e0 = (l0 * su + l1 * sv + l2 * 1.0) * sic;     // doubles here, no float truncation (:229)
-    e1 = (l0 * eu + l1 * ev + l2 * 1.0) * sic;
+    e0 = (l0 * (xs0 / xs2) + l1 * (xs1 / xs2) + l2 * 1.0) * sic;     // doubles here, no float truncation (:229)
+    e1 = (l0 * (xe0 / xe2) + l1 * (xe1 / xe2) + l2 * 1.0) * sic;
     if (sqrt(e0 * e0 + e1 * e1) > thr_ls) { b.seg_keep[s] = 0; deleted = 2; }
   }
   return e0 * e0 + e1 * e1;
@@ -341,7 +247,6 @@ __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseS
                              double* init_vec, const double* obs, double* s_tot) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int np = job.n_pts, ns = job.n_seg, nf = np + ns;
-  const ScaleRcp sc = make_scale_rcp(scale_pt, scale_ls);
   for (int iter = 0; iter < n_iter; ++iter) {
     double acc[32];   // 0..20 A (upper, row-major), 21..26 b, 27 chi2, 28 #points, 29 #segments, 30..31 unused
 #pragma unroll
@@ -349,7 +254,7 @@ __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseS
     double P[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) P[k] = s_pose[k];
-    for (int f = tid; f < nf; f += PO_T) popt_accumulate_feature(b, job, f, P, scale_pt, scale_ls, sc, iter == 0, init_vec, obs, acc);
+    for (int f = tid; f < nf; f += PO_T) popt_accumulate_feature(b, job, f, P, scale_pt, scale_ls, iter == 0, init_vec, obs, acc);
     {
       double out2[2];
       row_reduce_scatter32(acc, out2);
@@ -708,7 +613,6 @@ __device__ __forceinline__ void rows_gn_loop(const PoseBatchDev& b, const PoseJo
                                              int n_iter, int phase, double scale_pt, double scale_ls, double* init_vec, const double* obs) {
   const int lane = threadIdx.x & 63, rl = lane & 15;
   const int nf = job.n_pts + job.n_seg;
-  const ScaleRcp sc = make_scale_rcp(scale_pt, scale_ls);
   bool running = row_on && n_iter > 0;
   for (int iter = 0; __any(running); ++iter) {
     double acc[32];
@@ -718,7 +622,7 @@ __device__ __forceinline__ void rows_gn_loop(const PoseBatchDev& b, const PoseJo
       double P[12];
 #pragma unroll
       for (int k = 0; k < 12; ++k) P[k] = L.pose[k];
-      for (int f = rl; f < nf; f += 16) popt_accumulate_feature(b, job, f, P, scale_pt, scale_ls, sc, iter == 0, init_vec, obs, acc);
+      for (int f = rl; f < nf; f += 16) popt_accumulate_feature(b, job, f, P, scale_pt, scale_ls, iter == 0, init_vec, obs, acc);
     }
     double out2[2];
     row_reduce_scatter32(acc, out2);     // every lane of the wave takes part (DPP); the row's totals are the frame's

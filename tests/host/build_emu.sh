@@ -21,5 +21,5 @@ for f in align_kernels poseopt_kernels pyramid_kernels structopt_kernels match_k
 done
 $CXX $FLAGS -c $R/tests/host/emu_runtime.cpp -o $OUT/emu_runtime.o &
 wait
-$CXX -shared -fPIC -o $OUT/libplsvo_hip_emu.so $OBJS $OUT/emu_runtime.o -ldl $EMU_LDFLAGS   # (EMU_LDFLAGS: e.g. -fsanitize=address, --coverage)
+$CXX -shared -fPIC -pthread -o $OUT/libplsvo_hip_emu.so $OBJS $OUT/emu_runtime.o -ldl $EMU_LDFLAGS   # (EMU_LDFLAGS: e.g. -fsanitize=address, --coverage)
 echo "built $OUT/libplsvo_hip_emu.so"

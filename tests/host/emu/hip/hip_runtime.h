@@ -5,7 +5,15 @@
 #pragma once
 #include <chrono>
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
 #include "../wave_emu.hpp"
+
+#define PLSVO_WAVE_EMU 1
+inline void wave_emu_yield_thread() { std::this_thread::yield(); }   // a workgroup polling its peer (two workgroups of a frame run on two OS threads)
 
 // ---- device language -----------------------------------------------------------------------------------------------------------
 #define __device__
@@ -20,7 +28,7 @@ struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned 
 struct WaveEmuTid { operator unsigned() const { return wave_emu::S().tid_base + (unsigned)wave_emu::fibre(); } };
 struct WaveEmuTid3 { WaveEmuTid x; unsigned y = 0, z = 0; };
 static const WaveEmuTid3 threadIdx = {};
-namespace wave_emu { inline dim3& block_idx() { static dim3 v; return v; } inline dim3& block_dim() { static dim3 v; return v; } inline dim3& grid_dim() { static dim3 v; return v; } }
+namespace wave_emu { inline dim3& block_idx() { static thread_local dim3 v; return v; } inline dim3& block_dim() { static dim3 v; return v; } inline dim3& grid_dim() { static dim3 v; return v; } }
 #define blockIdx (wave_emu::block_idx())
 #define blockDim (wave_emu::block_dim())
 #define gridDim (wave_emu::grid_dim())
@@ -152,15 +160,53 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = s
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
-// a launch: the workgroups run one after the other, each on its own set of fibres; dynamic LDS is re-poisoned for every workgroup
-namespace wave_emu { void poison_dynamic_lds(size_t bytes); constexpr size_t DYNAMIC_LDS_BYTES = 160 * 1024; }
+// a launch: the workgroups run one after the other, each on its own set of fibres; dynamic LDS is re-poisoned for every workgroup.
+// Workgroups that WAIT FOR EACH OTHER inside the kernel (the two workgroups of a frame, align_kernels.hip: blocks q and q + stride of
+// every group of 2 * stride, announced through wave_emu::pair_stride()) run concurrently: the second of a pair on a helper OS thread --
+// the emulator's state, blockIdx and LDS are per thread -- so that each finds its partner's granules arriving while it polls.
+namespace wave_emu {
+void poison_dynamic_lds(size_t bytes);
+constexpr size_t DYNAMIC_LDS_BYTES = 160 * 1024;
+inline int& pair_stride() { static int v = 0; return v; }
+struct PairWorker {
+  std::thread th; std::mutex m; std::condition_variable cv; std::function<void()> task; bool has = false, done = true, quit = false;
+  PairWorker() {
+    th = std::thread([this] {
+      for (;;) {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return has || quit; });
+        if (quit) return;
+        std::function<void()> t = std::move(task);
+        has = false;
+        l.unlock(); t(); l.lock();
+        done = true; cv.notify_all();
+      }
+    });
+  }
+  ~PairWorker() { { std::lock_guard<std::mutex> l(m); quit = true; } cv.notify_all(); th.join(); }
+  void start(std::function<void()> t) { std::lock_guard<std::mutex> l(m); task = std::move(t); has = true; done = false; cv.notify_all(); }
+  void wait() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return done; }); }
+};
+inline PairWorker& pair_worker() { static PairWorker w; return w; }
+}
 template <class K, class... A>
 inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t, A... args) {
   blockDim = block; gridDim = grid;
   const int T = (int)(block.x * block.y * block.z);
-  for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
+  auto one = [&](unsigned bx, unsigned by, unsigned bz) {
     blockIdx = dim3(bx, by, bz);
     if (lds) wave_emu::poison_dynamic_lds(lds);
     wave_emu::run_block(T, [&]() { kernel(args...); });
+  };
+  const unsigned ps = (unsigned)wave_emu::pair_stride();
+  if (ps > 0 && grid.y == 1 && grid.z == 1 && grid.x % (2 * ps) == 0) {
+    for (unsigned g = 0; g < grid.x; g += 2 * ps)
+      for (unsigned q = 0; q < ps; ++q) {
+        wave_emu::pair_worker().start([&, g, q] { one(g + q + ps, 0, 0); });
+        one(g + q, 0, 0);
+        wave_emu::pair_worker().wait();
+      }
+    return;
   }
+  for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) one(bx, by, bz);
 }

@@ -80,7 +80,7 @@ struct State {
   size_t main_stack_size = 0;
   State() : ctx(MAXT), stack(MAXT), done(MAXT), at_sync(MAXT), tag(MAXT), site_line(MAXT), site_file(MAXT, ""), seq(MAXT) { for (int k = 0; k < 2; ++k) { slot[k].resize(MAXT); slot_seq[k].resize(MAXT); } }
 };
-inline State& S() { static State s; return s; }
+inline State& S() { static thread_local State s; return s; }   // (one per OS thread: the two workgroups of a frame run on two threads)
 inline int fibre() { return S().cur; }
 inline int lane() { return S().cur & 63; }
 // AddressSanitizer builds (tests/host/build_emu.sh ... -fsanitize=address) tell the runtime about every stack switch
