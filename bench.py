@@ -106,7 +106,7 @@ def offline_traffic(B, config=2):
         per_stream = d.get("align_fused_kernel_bytes_per_stream")
         if per_stream is None:
             return None, None, None
-        src = f"offline rocprofv3 PMC passes, profiles/hbm_traffic.json ({d.get('measured_at', 'commit unknown')}), scaled from {d.get('batch')} streams"
+        src = f"offline rocprofv3 PMC passes, profiles/{os.path.basename(tfile)} ({d.get('measured_at', 'commit unknown')}), scaled from {d.get('batch')} streams"
         raw = d.get("align_fused_kernel_bytes_per_stream_uncorrected")
         return int(round(per_stream * B)), src, (int(round(raw * B)) if raw is not None else None)
     except (OSError, ValueError, TypeError):
@@ -564,6 +564,11 @@ def main():
                             "kernel_requested_GBps": round(rate(own_bytes), 1),
                             "traffic_over_requested": round(traffic / per_launch(own_bytes), 3) if traffic else None,
                             "traffic_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic and avg_ms > 0 else None,
+                            # the PHYSICAL fraction: memory-side bytes of the PMC passes / launch time / 8 TB/s (<= 1 by construction)
+                            "traffic_frac": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic and avg_ms > 0 else None,
+                            "frac_is": "a work rate in SURVEY 8(d)'s reference-layout bytes (the contract's definition), not a bandwidth: it can pass 1; "
+                                       "traffic_frac (counters) and formulation_min_frac (the bytes this formulation must move) are the bounded figures",
+                            "work_rate_survey_units_GBps": round(achieved, 1),
                             "patch_levels_per_step": int(patch_levels), "patch_iters_per_step": int(patch_iters), "point_patch_iters_per_step": int(pt_iters)}
             result = {
                 "metric": cfg["metric"],

@@ -120,7 +120,11 @@ def test_hip_resident_chain_equals_the_per_call_chain(P, ob, gpu_ctx, seqm):
     rd2 = seqm.run_sequence(seqm.HipChainBackend(gpu_ctx), seq2, mapping=True)
     for k, (a, b) in enumerate(zip(rd2, rc2)):
         ang, dist = P.synth.se3_log_angle_dist(a["T"], b["T"])
-        assert ang < 1e-9 and dist < 1e-9 and a.get("n_known") == b.get("n_known"), (k, ang, dist)
+        # (the two chains normalise the new landmarks' bearings in different places: inputs that differ in the last bit, which a last-bit tie
+        #  of the alignment's float chi2 comparison turns into ~1e-8 now and then -- the float-tie floor of INTEGRATION.md section 3, three
+        #  orders of magnitude inside the bar; which frame meets it depends on the kernel's summation order: round 5's two-workgroup shape
+        #  meets it at frame 6 of this sequence, 1.0e-8 rad / 5.1e-8)
+        assert ang < 1e-7 and dist < 1e-6 and a.get("n_known") == b.get("n_known"), (k, ang, dist)
 
 
 @pytest.mark.gpu
