@@ -733,11 +733,13 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   return PLSVO_OK;
 }
 
-// Launch configuration of the fused alignment kernel (measured on MI355X).  A frame pair is one workgroup;
-// how many threads it gets depends on how many frames there are to fill the chip with:
-//   large batches (throughput): 128 threads, several workgroups per CU hide each other's serial solve/update tails;
-//   small batches (latency):    512 threads, the whole CU works on one frame and a Gauss-Newton iteration is one or two rounds.
-// Environment overrides (experiments only, read once at plsvo_hip_create): PLSVO_ALIGN_THREADS, PLSVO_ALIGN_PER_LEVEL, PLSVO_ALIGN_LDS_PAD.
+// Launch configuration of the fused alignment kernel (measured on MI355X).  A frame pair is one workgroup (two for the
+// smallest batches, plsvo_align_run); how many threads it gets depends on how many frames there are to fill the chip with:
+//   >= 64 frames per CU (throughput): 64 threads -- one wave per frame, eight frames per CU hide each other's serial solve / update tails;
+//   > 4 / > 1 frames per CU:          128 / 256 threads;
+//   at most one frame per CU (latency): 512 threads, the whole CU works on one frame (its points; a second CU on its segments).
+// Environment overrides (experiments only, read once at plsvo_hip_create): PLSVO_ALIGN_THREADS, PLSVO_ALIGN_PER_LEVEL, PLSVO_ALIGN_LDS_PAD,
+// PLSVO_ALIGN_NO_PAIR.
 static void pick_align_config(const plsvo_ctx* c, int n_jobs, int cap, int scap, int max_pts, int* threads, size_t* lds, int* chi_lds_pts) {
   const int cus = c->cu_count > 0 ? c->cu_count : 256;
   int t = 64;                            // >= 64 frames per CU: one wave per frame, no workgroup barrier at all
@@ -1058,12 +1060,13 @@ extern "C" int plsvo_poseopt_run(plsvo_ctx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
   // Large batches: a 16-lane row per frame, four frames per wave (the serial solve + update of four frames share one instruction stream:
   // poseopt_kernels.hip) while a frame has a few hundred features -- measured on MI355X, 32768 frames: 200 + 80 features 1.86 ms against
-  // 2.03 ms for a wave per frame, 500 + 200 features 4.55 against 3.77 (a row then needs 44 dependent feature rounds per pass), so frames
-  // above ~450 features keep the wave-per-frame shape.  Too few frames to fill the chip: four waves per frame (the Gauss-Newton loop of
+  // 2.03 ms for a wave per frame, 500 + 200 features 4.55 against 3.77 (a row then needs 44 dependent feature rounds per pass).  The
+  // crossover, measured in round 5 (tools/poseopt_crossover.py, 16384 frames): 420 features 1.31 vs 1.47 ms, 550 features 1.72 vs 1.79,
+  // 620 features 1.91 vs 1.80, 700 features 2.19 vs 1.95 -- frames above 580 features keep the wave-per-frame shape.  Too few frames to fill the chip: four waves per frame (the Gauss-Newton loop of
   // one frame is then ~2x shorter).  PLSVO_POSEOPT_THREADS / PLSVO_OPT_POSEOPT_THREADS override (tests and measurements).
   const int cus = c->cu_count > 0 ? c->cu_count : 256;
   const long feats = (long)c->p_total_pt + (long)c->p_total_seg;
-  int threads = c->p_n <= 2 * cus ? 256 : (feats <= 450l * c->p_n ? 16 : 64);
+  int threads = c->p_n <= 2 * cus ? 256 : (feats <= 580l * c->p_n ? 16 : 64);
   if (c->env_poseopt_threads) threads = c->env_poseopt_threads;
   EventPair ep{}; prof_begin(c, PLSVO_K_POSEOPT, &ep);
   HIP_TRY(c, launch_pose_opt(c->p_b, c->p_d_poses.as<double>(), threads, c->stream));
@@ -1491,7 +1494,7 @@ extern "C" int plsvo_chain_run(plsvo_ctx* c) {
     HIP_TRY(c, launch_chain_select(c->ch_b, c->stream));
     prof_end(c, PLSVO_K_MATCH, &ep); }
   const int cus = c->cu_count > 0 ? c->cu_count : 256;
-  int threads = c->ch_n <= 2 * cus ? 256 : ((long)c->ch_b.n_cand <= 450l * c->ch_n ? 16 : 64);   // (selected features <= candidates; see plsvo_poseopt_run)
+  int threads = c->ch_n <= 2 * cus ? 256 : ((long)c->ch_b.n_cand <= 580l * c->ch_n ? 16 : 64);   // (selected features <= candidates; see plsvo_poseopt_run)
   if (c->env_poseopt_threads) threads = c->env_poseopt_threads;
   EventPair ep{}; prof_begin(c, PLSVO_K_POSEOPT, &ep);
   HIP_TRY(c, launch_pose_opt(c->ch_pose, c->ch_d_poses.as<double>(), threads, c->stream));
