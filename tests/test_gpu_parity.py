@@ -264,7 +264,9 @@ def _seed_sweep_body(P, ob, gpu_ctx, tag, seed0, n_seeds, W, H, npts, nseg, nlev
     print(json.dumps(out))
     assert not failures, failures
     assert unarmed == 0, unarmed      # every near tie was decided on the reference's float sums (missing terms are rebuilt first)
-    assert len(different) <= max(2, n_seeds // 25), different     # measured: 2 of 150 (config 2), 1 of 60 (config 3)
+    # measured on the MI355X, rounds 3-5: 3 / 2 of 150 (config 2, small-batch / one-wave shape), 1 of 60 and 0 of 40 (config 3); 1000 emulated
+    # seeds: 17-23.  The allowance does not grow with what a rewrite of the kernel happens to meet: 2 % of the seeds, at least 3
+    assert len(different) <= max(3, n_seeds // 50), different
 
 
 def test_device_trace_against_scipy(P, ob, gpu_ctx):
