@@ -28,6 +28,12 @@
 //     in two passes (residuals, workgroup barrier, expansion) -- same code, selected by a workgroup-uniform flag;
 //   * REDUCTION: 27 + 3 lane-private doubles -> butterfly reduce-scatter inside each 16-lane DPP row (30 exchanges
 //     instead of 4 x 30), rows and waves combined through LDS in fixed order: deterministic.
+//   * TWO FAMILIES OF LAUNCH SHAPES (template parameter T = threads per frame).  THROUGHPUT (64 / 128: thousands of frames in flight, eight
+//     workgroups per CU): the reference patch is a 64-byte record of image bytes rebuilt every iteration, pyramids read through their tiled
+//     mirror (64), 255-256 registers, two waves per SIMD.  LATENCY (256 / 512: a frame owns most of a CU; round 5): the reference patch as
+//     float rows, slot tables in LDS, a shorter solve, a trimmed level set-up, and -- with at most cu_count / 2 frames -- TWO WORKGROUPS PER
+//     FRAME: rank 0 the point slots, rank 1 the segments' samples, 32 partial sums exchanged per iteration as tagged granules through L2
+//     (plsvo_wave.hpp::pair_allgather32), the identical solver on both.
 //
 // Numerics: image interpolation and residuals in float with the reference's operation order and NO
 // fma contraction (__fmul_rn/__fadd_rn); geometry and all accumulators in double.
