@@ -207,6 +207,11 @@ int plsvo_align_copy_poses(plsvo_ctx* ctx, double* d_dst);
  *   patch_levels = sum over jobs and levels of patches precomputed (497 B each)
  *   patch_iters  = sum over jobs, levels and GN iterations of patches evaluated (485 B each) */
 int plsvo_align_work(plsvo_ctx* ctx, uint64_t* patch_levels, uint64_t* patch_iters);
+/* The order in which the NEXT plsvo_align_run of the resident batch starts its jobs (block w works on job order[w]): the stage call's
+   (most patches first) until the batch has run; after a run of a batch larger than the device's resident slots, the jobs sorted by the
+   patch-iterations that run measured, longest first (align_kernels.hip::align_reorder_kernel).  Scheduling only: a job's results do not
+   depend on its place in the launch.  Tests and measurements. */
+int plsvo_align_launch_order(plsvo_ctx* ctx, int n, int32_t* order);
 /* of patch_iters, the evaluations of POINT patches that also wrote their 64 B of per-pixel chi2 terms to HBM (see plsvo_align_chi2_ties) */
 int plsvo_align_work_points(plsvo_ctx* ctx, uint64_t* point_patch_iters);
 

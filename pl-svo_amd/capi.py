@@ -20,7 +20,7 @@ SYMBOLS = [
     "plsvo_hip_config_pyramids", "plsvo_hip_upload_pyramid", "plsvo_hip_build_pyramid", "plsvo_hip_build_pyramids_dev",
     "plsvo_hip_download_level", "plsvo_hip_copy_slots",
     "plsvo_sparse_align", "plsvo_sparse_align_batch", "plsvo_align_stage", "plsvo_align_run", "plsvo_align_fetch",
-    "plsvo_align_set_trace", "plsvo_align_fetch_trace", "plsvo_align_poses_dev", "plsvo_align_copy_poses", "plsvo_align_work", "plsvo_align_work_points", "plsvo_align_chi2_ties",
+    "plsvo_align_set_trace", "plsvo_align_fetch_trace", "plsvo_align_poses_dev", "plsvo_align_copy_poses", "plsvo_align_work", "plsvo_align_work_points", "plsvo_align_chi2_ties", "plsvo_align_launch_order",
     "plsvo_pose_optimize", "plsvo_pose_optimize_batch", "plsvo_poseopt_stage", "plsvo_poseopt_run", "plsvo_poseopt_fetch",
     "plsvo_poseopt_set_trace", "plsvo_poseopt_fetch_trace", "plsvo_poseopt_poses_dev", "plsvo_poseopt_copy_poses", "plsvo_poseopt_work",
     "plsvo_structure_optimize", "plsvo_match_direct", "plsvo_reproject", "plsvo_trajectory_record", "plsvo_update_seeds",
@@ -82,6 +82,7 @@ def lib():
         "plsvo_align_work": (C.c_int, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "plsvo_align_chi2_ties": (C.c_int, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "plsvo_align_work_points": (C.c_int, [ctxp, C.POINTER(C.c_uint64)]),
+        "plsvo_align_launch_order": (C.c_int, [ctxp, C.c_int, C.POINTER(C.c_int32)]),
         "plsvo_pose_optimize": (C.c_int, [ctxp, C.POINTER(abi.PoseOptIn), C.POINTER(abi.PoseOptOut)]),
         "plsvo_pose_optimize_batch": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.PoseOptIn), C.POINTER(abi.PoseOptOut)]),
         "plsvo_poseopt_stage": (C.c_int, [ctxp, C.c_int, C.POINTER(abi.PoseOptIn)]),
@@ -275,6 +276,12 @@ class Context:
         a = C.c_uint64(0)
         self._chk(self.L.plsvo_align_work_points(self.h, C.byref(a)))
         return a.value
+
+    def align_launch_order(self, n):
+        """plsvo_align_launch_order: the job each block of the next align_run of the resident batch works on"""
+        out = np.zeros(n, dtype=np.int32)
+        self._chk(self.L.plsvo_align_launch_order(self.h, n, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
 
     def align_chi2_ties(self):
         """(Gauss-Newton iterations, iterations decided on the exact float chi2 sums, near ties whose terms had not been kept) of the last align_run"""

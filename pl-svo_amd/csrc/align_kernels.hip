@@ -1255,6 +1255,49 @@ static hipError_t launch_fused_T(const AlignBatchDev& b, int cap, int scap, int 
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Launch order from MEASURED work.  The hardware hands out workgroups in blockIdx order as slots free up, so a launch of 32768 frames on
+// 2048 resident slots is a list schedule: in an arbitrary order its tail -- the last frames to start may be the longest -- costs ~5 % of
+// the launch (frames take 10 .. 30 Gauss-Newton iterations; simulated: makespan 292 against an ideal 277, 278 longest-first).  The host
+// can only sort by patch count (the stage call); what a frame really costs is known after it ran: this kernel sorts the jobs of a resident
+// batch by the patch-iterations of its LAST launch (state[j].iters x n_slots, counting sort over 1024 bins, longest first) into the order
+// the NEXT launch of the same batch uses.  A tracker's streams change slowly from frame to frame, a benchmark's not at all.  The results of a
+// job do not depend on where it sits in the launch (tests: batch == single, bit for bit), so this is scheduling only.  One workgroup.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void align_reorder_kernel(const AlignJobDev* jobs, const AlignStateDev* state, int n, int* order_out) {
+  __shared__ int s_hist[1024];
+  __shared__ int s_scan[1024];
+  const int tid = threadIdx.x;
+  auto bin_of = [&](int j) -> int {
+    long long work = 0;
+#pragma unroll
+    for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) work += (long long)state[j].iters[l] * (long long)jobs[j].n_slots[l];
+    const long long b_ = work >> 7;
+    return 1023 - (int)(b_ > 1023 ? 1023 : (b_ < 0 ? 0 : b_));     // descending: the most work first
+  };
+  s_hist[tid] = 0;
+  __syncthreads();
+  for (int j = tid; j < n; j += 1024) atomicAdd(&s_hist[bin_of(j)], 1);
+  __syncthreads();
+  // exclusive prefix sum over the 1024 bins (Hillis-Steele, ten steps)
+  int v = s_hist[tid];
+  s_scan[tid] = v;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int add = tid >= d ? s_scan[tid - d] : 0;
+    __syncthreads();
+    s_scan[tid] += add;
+    __syncthreads();
+  }
+  s_hist[tid] = s_scan[tid] - v;      // first position of the bin
+  __syncthreads();
+  for (int j = tid; j < n; j += 1024) order_out[atomicAdd(&s_hist[bin_of(j)], 1)] = j;
+}
+hipError_t launch_align_reorder(const AlignJobDev* jobs, const AlignStateDev* state, int n, int* order_out, hipStream_t stream) {
+  hipLaunchKernelGGL(align_reorder_kernel, dim3(1), dim3(1024), 0, stream, jobs, state, n, order_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int scap, int level_hi, int level_lo, int do_init, int threads, size_t lds,
                                hipStream_t stream) {
   switch (threads) {

@@ -22,6 +22,7 @@
 namespace plsvo_hip {
 // kernels (align_kernels.hip, poseopt_kernels.hip, pyramid_kernels.hip)
 size_t align_level_lds_bytes(int threads, int cap, int scap, int chi_lds_pts);
+hipError_t launch_align_reorder(const AlignJobDev* jobs, const AlignStateDev* state, int n, int* order_out, hipStream_t stream);
 hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int scap, int level_hi, int level_lo, int do_init, int threads, size_t lds,
                                hipStream_t stream);
 hipError_t launch_pose_opt(const PoseBatchDev& b, double* d_poses, int threads, hipStream_t stream);
@@ -109,6 +110,10 @@ struct plsvo_ctx {
   DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_chi, a_d_log, a_d_poses;
   size_t a_patch_total = 0;                 // patch slots of the staged batch (all jobs, all levels' maximum)
   int a_seg_align = 32;                     // the staged layout's segment alignment (64: two workgroups per frame are possible)
+  DevBuf a_d_order[2];                      // launch order of a RE-RUN resident batch: sorted on the device by the last launch's measured work
+  int a_order_next = 0;                     //   (align_kernels.hip::align_reorder_kernel); the buffer the next reorder writes
+  bool env_align_no_reorder = false;
+  int env_align_reorder_min = 0;            //   PLSVO_ALIGN_REORDER_MIN: smallest batch that is re-ordered (tests; default 16 frames per CU)
   DevBuf a_d_xbuf;                          // two workgroups per frame: their exchange granules (2 KB per frame, zeroed once)
   unsigned int x_launch = 0;                // launches that used it (tags = launch << 10 | exchange: never repeated)
   bool env_align_no_pair = false;
@@ -248,6 +253,8 @@ static int create_ctx(int device_id, void* stream, bool use_given_stream, plsvo_
   if (const char* s = getenv("PLSVO_ALIGN_PER_LEVEL")) c->env_align_per_level = atoi(s) != 0;
   c->env_align_no_lpt = getenv("PLSVO_ALIGN_NO_LPT") != nullptr;
   c->env_align_no_pair = getenv("PLSVO_ALIGN_NO_PAIR") != nullptr;   // (A/B: one workgroup per frame also for small batches)
+  c->env_align_no_reorder = getenv("PLSVO_ALIGN_NO_REORDER") != nullptr;   // (A/B: keep the stage call's patch-count order for every launch)
+  if (const char* s = getenv("PLSVO_ALIGN_REORDER_MIN")) c->env_align_reorder_min = atoi(s);
   c->env_host_timing = getenv("PLSVO_HOST_TIMING") != nullptr;
   *out = c;
   return PLSVO_OK;
@@ -259,7 +266,7 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-  c->a_d_xbuf.release();
+  c->a_d_xbuf.release(); c->a_d_order[0].release(); c->a_d_order[1].release();
   DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_tiled, &c->pyr_upload, &c->a_d_blob, &c->a_d_state, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv, &c->a_d_cref,
                      &c->a_d_chi, &c->a_d_log, &c->a_d_poses, &c->p_d_blob, &c->p_d_state, &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64,
                      &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out, &c->ch_d_blob, &c->ch_d_work, &c->ch_d_po, &c->ch_d_state,
@@ -828,6 +835,15 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
     EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
     HIP_TRY(c, launch_align_levels(c->a_b, cap, scap, have_levels ? c->a_gmax : 0, have_levels ? c->a_gmin : 0, 1, threads, lds, c->stream));
     prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
+    // a batch with more frames than resident slots: the NEXT launch of this staged batch starts its frames longest-first by what they cost in
+    // this one (one small kernel behind the launch; the order buffers alternate, the running launch's is never written)
+    if (have_levels && c->a_n > (c->env_align_reorder_min > 0 ? c->env_align_reorder_min - 1 : 16 * cus_run) && !c->env_align_no_reorder && !c->env_align_no_lpt) {
+      DevBuf& ob = c->a_d_order[c->a_order_next];
+      HIP_TRY(c, ob.ensure((size_t)c->a_n * sizeof(int)));
+      HIP_TRY(c, launch_align_reorder(c->a_b.jobs, c->a_b.state, c->a_n, ob.as<int>(), c->stream));
+      c->a_b.order = ob.as<int>();
+      c->a_order_next ^= 1;
+    }
   } else {
     for (int level = c->a_gmax; level >= c->a_gmin; --level) {   // debug: one launch per level, state carried in HBM
       EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
@@ -977,6 +993,17 @@ extern "C" int plsvo_align_work_points(plsvo_ctx* c, uint64_t* point_patch_iters
   uint64_t n = 0;
   for (auto& s : st) n += s.patch_iters_pt;
   if (point_patch_iters) *point_patch_iters = n;
+  return PLSVO_OK;
+}
+
+extern "C" int plsvo_align_launch_order(plsvo_ctx* c, int n, int32_t* order) {
+  CTX_CHECK(c);
+  if (!c->a_staged) return fail(c, PLSVO_E_STATE, "align_launch_order: no staged batch");
+  if (n != c->a_n || !order) return fail(c, PLSVO_E_INVALID, "align_launch_order: n does not match the staged batch");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!c->a_b.order) { for (int j = 0; j < n; ++j) order[j] = j; return PLSVO_OK; }
+  HIP_TRY(c, hipMemcpyAsync(order, c->a_b.order, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return PLSVO_OK;
 }
 

@@ -1042,6 +1042,48 @@ def test_two_workgroups_per_frame_shape(P, ob, gpu_ctx):
     assert work[0] == work256[0] > 0 and abs(work[1] - work256[1]) <= 0.02 * work[1], (work, work256)
 
 
+@pytest.mark.gpu
+def test_launch_order_follows_the_measured_work_of_the_last_run(P, ob):
+    """A resident batch larger than the device's resident slots starts its frames longest-first by what they cost in its LAST launch
+    (align_kernels.hip::align_reorder_kernel; the threshold is lowered to 4 frames for this test): the order is a permutation, sorted by
+    the patch-iterations the device counted, and -- scheduling only -- every frame's result equals the single-frame call's, run after run."""
+    import os
+    os.environ["PLSVO_ALIGN_REORDER_MIN"] = "4"
+    try:
+        ctx = P.capi.Context(0)
+    finally:
+        del os.environ["PLSVO_ALIGN_REORDER_MIN"]
+    try:
+        W, H, B = 320, 240, 9
+        streams = [P.synth.make_align_stream(300 + i, W, H, 60 + 15 * (i % 4), 20 - 4 * (i % 3), max_level=3, motion_scale=0.3 + 0.2 * (i % 5)) for i in range(B)]
+        imgs = P.synth.render_streams(streams).numpy()
+        ctx.config_pyramids(2 * B, W, H, 4)
+        for i in range(B):
+            ctx.build_pyramid(2 * i, imgs[i, 0], 0)
+            ctx.build_pyramid(2 * i + 1, imgs[i, 1], 0)
+        jobs = [P.align_job_from_stream(s, 3, 1, ref_slot=2 * i, cur_slot=2 * i + 1) for i, s in enumerate(streams)]
+        ctx.set_launch_shapes(align_threads=64)                     # (the throughput shape, as the batches this is for)
+        single = []
+        for j in jobs:
+            single.append(ctx.sparse_align(j))
+        ctx.align_stage(jobs)
+        order0 = ctx.align_launch_order(B)
+        assert sorted(order0.tolist()) == list(range(B))            # the stage call's order: a permutation (most patches first)
+        for rep in range(3):
+            ctx.align_run()
+            res = ctx.align_fetch()
+            order = ctx.align_launch_order(B)
+            assert sorted(order.tolist()) == list(range(B)), order
+            iters = np.array([sum(r.iters_per_level) for r in res])
+            assert iters[order[0]] >= iters[order[-1]]                # longest first (bins of 128 patch-iterations: not a strict sort)
+            for k in range(B):
+                assert np.array_equal(res[k].T, single[k].T) and res[k].n_meas == single[k].n_meas and res[k].iters_per_level == single[k].iters_per_level, (rep, k)
+        ctx.align_stage(jobs)                                        # staging again resets the order to the host's
+        assert np.array_equal(ctx.align_launch_order(B), order0)
+    finally:
+        ctx.close()
+
+
 def _device_bytes(host):
     """`host` (uint8 array) in memory the library's device pointers can address: HBM through torch on a GPU box; the array itself when
     the library is the host emulation build (tests/test_emu_parity.py), whose device memory is host memory.  -> (keep-alive, pointer, read-back)"""
