@@ -1219,6 +1219,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
     st->chi2 = s_pose[26];
     st->patch_levels += (unsigned long long)(s_pose[28] + 0.5);
     st->patch_iters += (unsigned long long)(s_pose[29] + 0.5);
+    if (b.work_key) b.work_key[job_id] = (int)fmin(s_pose[29] + 0.5, 2147483647.0);   // what this frame cost: the next launch's sort key
     st->patch_iters_pt += (unsigned long long)(s_pose[31] + 0.5);
     st->stop = s_ctl[1];
     st->chi2_ties += s_ctl[6];
@@ -1260,20 +1261,17 @@ static hipError_t launch_fused_T(const AlignBatchDev& b, int cap, int scap, int 
 // 2048 resident slots is a list schedule: in an arbitrary order its tail -- the last frames to start may be the longest -- costs ~5 % of
 // the launch (frames take 10 .. 30 Gauss-Newton iterations; simulated: makespan 292 against an ideal 277, 278 longest-first).  The host
 // can only sort by patch count (the stage call); what a frame really costs is known after it ran: this kernel sorts the jobs of a resident
-// batch by the patch-iterations of its LAST launch (state[j].iters x n_slots, counting sort over 1024 bins, longest first) into the order
+// batch by the patch-iterations of its LAST launch (written by every frame's workgroup as it ends; counting sort over 1024 bins, longest first) into the order
 // the NEXT launch of the same batch uses.  A tracker's streams change slowly from frame to frame, a benchmark's not at all.  The results of a
 // job do not depend on where it sits in the launch (tests: batch == single, bit for bit), so this is scheduling only.  One workgroup.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void align_reorder_kernel(const AlignJobDev* jobs, const AlignStateDev* state, int n, int* order_out) {
+__global__ __launch_bounds__(1024) void align_reorder_kernel(const int* work_key, int n, int* order_out) {
   __shared__ int s_hist[1024];
   __shared__ int s_scan[1024];
   const int tid = threadIdx.x;
   auto bin_of = [&](int j) -> int {
-    long long work = 0;
-#pragma unroll
-    for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) work += (long long)state[j].iters[l] * (long long)jobs[j].n_slots[l];
-    const long long b_ = work >> 7;
-    return 1023 - (int)(b_ > 1023 ? 1023 : (b_ < 0 ? 0 : b_));     // descending: the most work first
+    const int b_ = work_key[j] >> 7;                                   // bins of 128 patch-iterations (a config-2 frame: ~6000)
+    return 1023 - (b_ > 1023 ? 1023 : (b_ < 0 ? 0 : b_));              // descending: the most work first
   };
   s_hist[tid] = 0;
   __syncthreads();
@@ -1293,8 +1291,8 @@ __global__ __launch_bounds__(1024) void align_reorder_kernel(const AlignJobDev* 
   __syncthreads();
   for (int j = tid; j < n; j += 1024) order_out[atomicAdd(&s_hist[bin_of(j)], 1)] = j;
 }
-hipError_t launch_align_reorder(const AlignJobDev* jobs, const AlignStateDev* state, int n, int* order_out, hipStream_t stream) {
-  hipLaunchKernelGGL(align_reorder_kernel, dim3(1), dim3(1024), 0, stream, jobs, state, n, order_out);
+hipError_t launch_align_reorder(const int* work_key, int n, int* order_out, hipStream_t stream) {
+  hipLaunchKernelGGL(align_reorder_kernel, dim3(1), dim3(1024), 0, stream, work_key, n, order_out);
   return hipGetLastError();
 }
 

@@ -22,7 +22,7 @@
 namespace plsvo_hip {
 // kernels (align_kernels.hip, poseopt_kernels.hip, pyramid_kernels.hip)
 size_t align_level_lds_bytes(int threads, int cap, int scap, int chi_lds_pts);
-hipError_t launch_align_reorder(const AlignJobDev* jobs, const AlignStateDev* state, int n, int* order_out, hipStream_t stream);
+hipError_t launch_align_reorder(const int* work_key, int n, int* order_out, hipStream_t stream);
 hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int scap, int level_hi, int level_lo, int do_init, int threads, size_t lds,
                                hipStream_t stream);
 hipError_t launch_pose_opt(const PoseBatchDev& b, double* d_poses, int threads, hipStream_t stream);
@@ -110,6 +110,7 @@ struct plsvo_ctx {
   DevBuf a_d_pxyz, a_d_puv, a_d_cref, a_d_chi, a_d_log, a_d_poses;
   size_t a_patch_total = 0;                 // patch slots of the staged batch (all jobs, all levels' maximum)
   int a_seg_align = 32;                     // the staged layout's segment alignment (64: two workgroups per frame are possible)
+  DevBuf a_d_workkey;                       // per job: the patch-iterations its last launch evaluated
   DevBuf a_d_order[2];                      // launch order of a RE-RUN resident batch: sorted on the device by the last launch's measured work
   int a_order_next = 0;                     //   (align_kernels.hip::align_reorder_kernel); the buffer the next reorder writes
   bool env_align_no_reorder = false;
@@ -214,6 +215,7 @@ static void prof_collect(plsvo_ctx* c) {
 extern "C" const char* plsvo_hip_version(void) { return "plsvo_hip 0.1 (gfx950)"; }
 
 static int create_ctx(int device_id, void* stream, bool use_given_stream, plsvo_ctx** out);
+static bool env_flag(const char* name) { const char* s = getenv(name); return s && *s && strcmp(s, "0") != 0; }   // set and not "0"
 extern "C" int plsvo_hip_create(int device_id, void* stream, plsvo_ctx** out) { return create_ctx(device_id, stream, stream != nullptr, out); }
 extern "C" int plsvo_hip_create_on_stream(int device_id, void* stream, plsvo_ctx** out) { return create_ctx(device_id, stream, true, out); }
 
@@ -251,9 +253,9 @@ static int create_ctx(int device_id, void* stream, bool use_given_stream, plsvo_
   if (const char* s = getenv("PLSVO_ALIGN_LDS_PAD")) c->env_align_lds_pad = std::max(0, atoi(s));
   if (const char* s = getenv("PLSVO_POSEOPT_THREADS")) { const int v = atoi(s); if (v == 16 || v == 64 || v == 256 || v == 512) c->env_poseopt_threads = v; }
   if (const char* s = getenv("PLSVO_ALIGN_PER_LEVEL")) c->env_align_per_level = atoi(s) != 0;
-  c->env_align_no_lpt = getenv("PLSVO_ALIGN_NO_LPT") != nullptr;
-  c->env_align_no_pair = getenv("PLSVO_ALIGN_NO_PAIR") != nullptr;   // (A/B: one workgroup per frame also for small batches)
-  c->env_align_no_reorder = getenv("PLSVO_ALIGN_NO_REORDER") != nullptr;   // (A/B: keep the stage call's patch-count order for every launch)
+  c->env_align_no_lpt = env_flag("PLSVO_ALIGN_NO_LPT");
+  c->env_align_no_pair = env_flag("PLSVO_ALIGN_NO_PAIR");   // (A/B: one workgroup per frame also for small batches)
+  c->env_align_no_reorder = env_flag("PLSVO_ALIGN_NO_REORDER");   // (A/B: keep the stage call's patch-count order for every launch)
   if (const char* s = getenv("PLSVO_ALIGN_REORDER_MIN")) c->env_align_reorder_min = atoi(s);
   c->env_host_timing = getenv("PLSVO_HOST_TIMING") != nullptr;
   *out = c;
@@ -266,7 +268,7 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-  c->a_d_xbuf.release(); c->a_d_order[0].release(); c->a_d_order[1].release();
+  c->a_d_xbuf.release(); c->a_d_order[0].release(); c->a_d_order[1].release(); c->a_d_workkey.release();
   DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_tiled, &c->pyr_upload, &c->a_d_blob, &c->a_d_state, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv, &c->a_d_cref,
                      &c->a_d_chi, &c->a_d_log, &c->a_d_poses, &c->p_d_blob, &c->p_d_state, &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64,
                      &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out, &c->ch_d_blob, &c->ch_d_work, &c->ch_d_po, &c->ch_d_state,
@@ -728,7 +730,7 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   b.log = c->a_trace_cap > 0 ? c->a_d_log.as<plsvo_align_iterlog>() : nullptr;
   b.log_cap = c->a_trace_cap;
   b.n_jobs = n;
-  b.pair = 0; b.xseq0 = 0; b.xbuf = nullptr;   // (plsvo_align_run decides)
+  b.pair = 0; b.xseq0 = 0; b.xbuf = nullptr; b.work_key = nullptr;   // (plsvo_align_run decides)
   b.order = reinterpret_cast<const int*>(base + o_order);
   c->a_jobs.swap(jobs);
   c->a_n = n; c->a_total_seg = (int)alive.size(); c->a_gmax = gmax; c->a_gmin = gmin;
@@ -831,16 +833,23 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
     c->a_b.cache_ref = c->a_d_cref.as<float>();
   }
   const bool per_level = c->env_align_per_level;
+  const bool reorder = have_levels && !per_level && c->a_n > (c->env_align_reorder_min > 0 ? c->env_align_reorder_min - 1 : 16 * cus_run) &&
+                       !c->env_align_no_reorder && !c->env_align_no_lpt;
+  c->a_b.work_key = nullptr;
+  if (reorder) {
+    HIP_TRY(c, c->a_d_workkey.ensure((size_t)c->a_n * sizeof(int)));
+    c->a_b.work_key = c->a_d_workkey.as<int>();
+  }
   if (!per_level || !have_levels) {
     EventPair ep{}; prof_begin(c, PLSVO_K_ALIGN_LEVEL, &ep);
     HIP_TRY(c, launch_align_levels(c->a_b, cap, scap, have_levels ? c->a_gmax : 0, have_levels ? c->a_gmin : 0, 1, threads, lds, c->stream));
     prof_end(c, PLSVO_K_ALIGN_LEVEL, &ep);
     // a batch with more frames than resident slots: the NEXT launch of this staged batch starts its frames longest-first by what they cost in
     // this one (one small kernel behind the launch; the order buffers alternate, the running launch's is never written)
-    if (have_levels && c->a_n > (c->env_align_reorder_min > 0 ? c->env_align_reorder_min - 1 : 16 * cus_run) && !c->env_align_no_reorder && !c->env_align_no_lpt) {
+    if (reorder) {
       DevBuf& ob = c->a_d_order[c->a_order_next];
       HIP_TRY(c, ob.ensure((size_t)c->a_n * sizeof(int)));
-      HIP_TRY(c, launch_align_reorder(c->a_b.jobs, c->a_b.state, c->a_n, ob.as<int>(), c->stream));
+      HIP_TRY(c, launch_align_reorder(c->a_b.work_key, c->a_n, ob.as<int>(), c->stream));
       c->a_b.order = ob.as<int>();
       c->a_order_next ^= 1;
     }

@@ -130,6 +130,7 @@ struct AlignBatchDev {
   // TWO WORKGROUPS PER FRAME (latency shapes, at most cu_count / 2 frames): rank 0 owns the point slots, rank 1 the segment slots (the host
   // layout starts the segments at a multiple of 64); every iteration the two exchange their 32 partial sums through `xbuf` (64 tagged
   // 8-byte granules per rank and parity, plsvo_wave.hpp::pair_allgather32) and both run the solver on the identical totals.
+  int* work_key;               // 1 per job, or null: the patch-iterations the job's last launch evaluated (what the next launch's order is sorted by)
   int pair;                    // 0 = one workgroup per frame, 1 = two
   unsigned int xseq0;          // first sequence number of this launch's exchanges (launch number << 10: never repeats in the buffer's life)
   unsigned long long* xbuf;    // 2 (parity) x 2 (rank) x 64 granules per frame
