@@ -1265,12 +1265,12 @@ static hipError_t launch_fused_T(const AlignBatchDev& b, int cap, int scap, int 
 // the NEXT launch of the same batch uses.  A tracker's streams change slowly from frame to frame, a benchmark's not at all.  The results of a
 // job do not depend on where it sits in the launch (tests: batch == single, bit for bit), so this is scheduling only.  One workgroup.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void align_reorder_kernel(const int* work_key, int n, int* order_out) {
+__global__ __launch_bounds__(1024) void align_reorder_kernel(const int* work_key, int n, int* order_out, int shift) {
   __shared__ int s_hist[1024];
   __shared__ int s_scan[1024];
   const int tid = threadIdx.x;
   auto bin_of = [&](int j) -> int {
-    const int b_ = work_key[j] >> 7;                                   // bins of 128 patch-iterations (a config-2 frame: ~6000)
+    const int b_ = work_key[j] >> shift;                               // alignment: bins of 128 patch-iterations (a config-2 frame: ~6000)
     return 1023 - (b_ > 1023 ? 1023 : (b_ < 0 ? 0 : b_));              // descending: the most work first
   };
   s_hist[tid] = 0;
@@ -1291,8 +1291,8 @@ __global__ __launch_bounds__(1024) void align_reorder_kernel(const int* work_key
   __syncthreads();
   for (int j = tid; j < n; j += 1024) order_out[atomicAdd(&s_hist[bin_of(j)], 1)] = j;
 }
-hipError_t launch_align_reorder(const int* work_key, int n, int* order_out, hipStream_t stream) {
-  hipLaunchKernelGGL(align_reorder_kernel, dim3(1), dim3(1024), 0, stream, work_key, n, order_out);
+hipError_t launch_align_reorder(const int* work_key, int n, int* order_out, int shift, hipStream_t stream) {
+  hipLaunchKernelGGL(align_reorder_kernel, dim3(1), dim3(1024), 0, stream, work_key, n, order_out, shift);
   return hipGetLastError();
 }
 

@@ -22,7 +22,7 @@
 namespace plsvo_hip {
 // kernels (align_kernels.hip, poseopt_kernels.hip, pyramid_kernels.hip)
 size_t align_level_lds_bytes(int threads, int cap, int scap, int chi_lds_pts);
-hipError_t launch_align_reorder(const int* work_key, int n, int* order_out, hipStream_t stream);
+hipError_t launch_align_reorder(const int* work_key, int n, int* order_out, int shift, hipStream_t stream);   // (the pose optimiser's batches use it too)
 hipError_t launch_align_levels(const AlignBatchDev& b, int cap, int scap, int level_hi, int level_lo, int do_init, int threads, size_t lds,
                                hipStream_t stream);
 hipError_t launch_pose_opt(const PoseBatchDev& b, double* d_poses, int threads, hipStream_t stream);
@@ -129,6 +129,10 @@ struct plsvo_ctx {
   DevBuf p_d_state, p_d_ptkeep, p_d_segkeep;   // (inputs: p_d_blob)
   DevBuf p_d_s32, p_d_s64, p_d_log, p_d_poses;
   PoseBatchDev p_b{};
+  DevBuf p_d_workkey, p_d_order[2];         // as a_d_workkey / a_d_order: the launch order of a re-run staged batch, from its last launch's feature-iterations
+  int p_order_next = 0, p_key_shift = 0;
+  bool env_poseopt_no_reorder = false;
+  int env_poseopt_reorder_min = 0;          //   PLSVO_POSEOPT_REORDER_MIN (tests)
 
   // resident frame step (plsvo_chain_*): candidates, glue state, pose-optimiser input written on the device
   bool ch_staged = false;
@@ -257,6 +261,8 @@ static int create_ctx(int device_id, void* stream, bool use_given_stream, plsvo_
   c->env_align_no_pair = env_flag("PLSVO_ALIGN_NO_PAIR");   // (A/B: one workgroup per frame also for small batches)
   c->env_align_no_reorder = env_flag("PLSVO_ALIGN_NO_REORDER");   // (A/B: keep the stage call's patch-count order for every launch)
   if (const char* s = getenv("PLSVO_ALIGN_REORDER_MIN")) c->env_align_reorder_min = atoi(s);
+  c->env_poseopt_no_reorder = env_flag("PLSVO_POSEOPT_NO_REORDER");
+  if (const char* s = getenv("PLSVO_POSEOPT_REORDER_MIN")) c->env_poseopt_reorder_min = atoi(s);
   c->env_host_timing = getenv("PLSVO_HOST_TIMING") != nullptr;
   *out = c;
   return PLSVO_OK;
@@ -268,7 +274,7 @@ extern "C" void plsvo_hip_destroy(plsvo_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_collect(c);
   for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
-  c->a_d_xbuf.release(); c->a_d_order[0].release(); c->a_d_order[1].release(); c->a_d_workkey.release();
+  c->a_d_xbuf.release(); c->a_d_order[0].release(); c->a_d_order[1].release(); c->a_d_workkey.release(); c->p_d_workkey.release(); c->p_d_order[0].release(); c->p_d_order[1].release();
   DevBuf* bufs[] = { &c->pyr_slab, &c->pyr_tiled, &c->pyr_upload, &c->a_d_blob, &c->a_d_state, &c->a_d_alive, &c->a_d_pxyz, &c->a_d_puv, &c->a_d_cref,
                      &c->a_d_chi, &c->a_d_log, &c->a_d_poses, &c->p_d_blob, &c->p_d_state, &c->p_d_ptkeep, &c->p_d_segkeep, &c->p_d_s32, &c->p_d_s64,
                      &c->p_d_log, &c->p_d_poses, &c->s_d_in, &c->s_d_out, &c->ch_d_blob, &c->ch_d_work, &c->ch_d_po, &c->ch_d_state,
@@ -849,7 +855,7 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
     if (reorder) {
       DevBuf& ob = c->a_d_order[c->a_order_next];
       HIP_TRY(c, ob.ensure((size_t)c->a_n * sizeof(int)));
-      HIP_TRY(c, launch_align_reorder(c->a_b.work_key, c->a_n, ob.as<int>(), c->stream));
+      HIP_TRY(c, launch_align_reorder(c->a_b.work_key, c->a_n, ob.as<int>(), 7, c->stream));
       c->a_b.order = ob.as<int>();
       c->a_order_next ^= 1;
     }
@@ -1083,6 +1089,13 @@ extern "C" int plsvo_poseopt_stage(plsvo_ctx* c, int n, const plsvo_poseopt_in* 
   b.scratch_f32 = c->p_d_s32.as<float>(); b.scratch_f64 = c->p_d_s64.as<double>();
   b.log = c->p_trace_cap > 0 ? c->p_d_log.as<plsvo_poseopt_iterlog>() : nullptr;
   b.log_cap = c->p_trace_cap; b.n_jobs = n;
+  b.order = nullptr; b.work_key = nullptr;   // a new batch: no measured work yet (plsvo_poseopt_run)
+  {   // sort-key resolution: the most feature-iterations a frame of this batch can evaluate, in 1024 bins
+    long key_max = 1;
+    for (int j = 0; j < n; ++j) key_max = std::max(key_max, (long)(jobs[j].n_pts + jobs[j].n_seg) * (long)(std::max(jobs[j].n_iter, 0) + std::max(jobs[j].n_iter_ref, 0)));
+    c->p_key_shift = 0;
+    while ((key_max >> c->p_key_shift) > 1023) ++c->p_key_shift;
+  }
   c->p_jobs.swap(jobs);
   c->p_n = n; c->p_total_pt = (int)npt; c->p_total_seg = (int)nsg;
   c->p_staged = true; c->p_run_seq = 0;
@@ -1104,10 +1117,26 @@ extern "C" int plsvo_poseopt_run(plsvo_ctx* c) {
   const long feats = (long)c->p_total_pt + (long)c->p_total_seg;
   int threads = c->p_n <= 2 * cus ? 256 : (feats <= 580l * c->p_n ? 16 : 64);
   if (c->env_poseopt_threads) threads = c->env_poseopt_threads;
+  // batches of many waves per SIMD slot: this launch records what every frame cost, the next one takes them most-expensive first (see
+  // plsvo_align_run; for the rows kernel the sort also puts frames that stop together into the same wave)
+  const bool reorder = threads != 256 && !c->env_poseopt_no_reorder &&
+                       c->p_n > (c->env_poseopt_reorder_min > 0 ? c->env_poseopt_reorder_min - 1 : 16 * cus);
+  c->p_b.work_key = nullptr;
+  if (reorder) {
+    HIP_TRY(c, c->p_d_workkey.ensure((size_t)c->p_n * sizeof(int)));
+    c->p_b.work_key = c->p_d_workkey.as<int>();
+  } else c->p_b.order = nullptr;
   EventPair ep{}; prof_begin(c, PLSVO_K_POSEOPT, &ep);
   HIP_TRY(c, launch_pose_opt(c->p_b, c->p_d_poses.as<double>(), threads, c->stream));
   c->p_run_seq = ++c->run_seq;
   prof_end(c, PLSVO_K_POSEOPT, &ep);
+  if (reorder) {
+    DevBuf& ob = c->p_d_order[c->p_order_next];
+    HIP_TRY(c, ob.ensure((size_t)c->p_n * sizeof(int)));
+    HIP_TRY(c, launch_align_reorder(c->p_b.work_key, c->p_n, ob.as<int>(), c->p_key_shift, c->stream));
+    c->p_b.order = ob.as<int>();
+    c->p_order_next ^= 1;
+  }
   return PLSVO_OK;
 }
 

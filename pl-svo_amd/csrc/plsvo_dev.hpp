@@ -171,6 +171,8 @@ struct PoseBatchDev {
   plsvo_poseopt_iterlog* log;
   int log_cap;
   int n_jobs;
+  const int* order;            // launch slot -> job, or null (identity): a RE-RUN of a staged batch takes its frames sorted by work_key, most first
+  int* work_key;               // 1 per job, or null: the feature-iterations the job's last launch evaluated
 };
 
 struct StructBatchDev {

@@ -310,10 +310,11 @@ __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseS
 
 template <int PO_T>
 __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* poses) {
-  const int job_id = blockIdx.x;
+  const int job_id = b.order ? b.order[blockIdx.x] : (int)blockIdx.x;
   const PoseJobDev job = b.jobs[job_id];
   PoseStateDev* st = b.state + job_id;
   const int tid = threadIdx.x;
+  if (tid == 0 && b.work_key) b.work_key[job_id] = 0;
   const int np = job.n_pts, ns = job.n_seg, nf = np + ns;
 
   __shared__ __align__(16) double s_red[32 * (PO_T / 16)];
@@ -441,6 +442,7 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* 
     st->num_obs_ls = (unsigned long long)(ns - n_del_ls);
     st->iters = s_ctl[1]; st->iters_ref = s_ctl[2];
     st->pt_iters = (unsigned long long)(s_pose[27] + 0.5); st->seg_iters = (unsigned long long)(s_pose[28] + 0.5);
+    if (b.work_key) b.work_key[job_id] = (int)fmin(s_pose[27] + s_pose[28] + 0.5, 2147483647.0);   // what this frame cost: the next launch's sort key
 #ifdef PLSVO_TIMING
     { const unsigned long long t__ = __builtin_amdgcn_s_memtime(); s_time[4] += t__ - s_tlast; }
     for (int k = 0; k < 8; ++k) st->phase_ticks[k] = s_time[k];
@@ -671,7 +673,10 @@ __global__ __launch_bounds__(64) void pose_opt_rows_kernel(PoseBatchDev b, doubl
   const int lane = threadIdx.x & 63, row = lane >> 4, rl = lane & 15;
   const int job_raw = blockIdx.x * 4 + row;
   const bool row_valid = job_raw < b.n_jobs;
-  const int job_id = row_valid ? job_raw : b.n_jobs - 1;
+  // a re-run staged batch comes sorted by the feature-iterations of its last launch (plsvo_capi.hip::plsvo_poseopt_run): the four frames of a
+  // wave run in lock step until the LAST of them stops, and the iteration counts are bimodal (4-6, or all 10) -- in an arbitrary order three
+  // waves of four hold a ten-iteration frame and run ten; sorted, the rows of a wave stop together
+  const int job_id = row_valid ? (b.order ? b.order[job_raw] : job_raw) : b.n_jobs - 1;
   const PoseJobDev job = b.jobs[job_id];
   PoseStateDev* st = b.state + job_id;
   PoseRowLds& L = s_rows[row];
@@ -694,6 +699,7 @@ __global__ __launch_bounds__(64) void pose_opt_rows_kernel(PoseBatchDev b, doubl
     for (int k = 0; k < 7; ++k) st->T[k] = job.T0[k];
     for (int k = 0; k < 8; ++k) st->phase_ticks[k] = 0;
     if (nf == 0) { st->status = 1; if (poses) for (int k = 0; k < 7; ++k) poses[7 * job_id + k] = job.T0[k]; }   // errors.empty() :88-89
+    if (b.work_key) b.work_key[job_id] = 0;
   }
   const bool row_on = row_valid && nf > 0;
   if (row_on) {
@@ -772,6 +778,7 @@ __global__ __launch_bounds__(64) void pose_opt_rows_kernel(PoseBatchDev b, doubl
     st->num_obs_ls = (unsigned long long)(ns - n_del_ls);
     st->iters = L.ctl[1]; st->iters_ref = L.ctl[2];
     st->pt_iters = (unsigned long long)(L.pose[27] + 0.5); st->seg_iters = (unsigned long long)(L.pose[28] + 0.5);
+    if (b.work_key) b.work_key[job_id] = (int)fmin(L.pose[27] + L.pose[28] + 0.5, 2147483647.0);
   }
 }
 

@@ -1084,6 +1084,41 @@ def test_launch_order_follows_the_measured_work_of_the_last_run(P, ob):
         ctx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [16, 64])
+def test_poseopt_launch_order_of_a_rerun_batch_changes_no_result(P, ob, threads):
+    """A staged pose-optimiser batch that is run again takes its frames sorted by the feature-iterations each evaluated in the last launch
+    (the four frames of a `pose_opt_rows_kernel` wave run until the last of them stops; threshold lowered to 4 frames here): scheduling
+    only -- every run's results equal the single-frame calls', which equal the oracle's."""
+    import os
+    os.environ["PLSVO_POSEOPT_REORDER_MIN"] = "4"
+    try:
+        ctx = P.capi.Context(0)
+    finally:
+        del os.environ["PLSVO_POSEOPT_REORDER_MIN"]
+    try:
+        ctx.set_launch_shapes(poseopt_threads=threads)
+        B = 11                                                       # (not a multiple of four: the last wave has idle rows)
+        frames = [P.synth.make_poseopt_frame(700 + i, 40 + 13 * (i % 5), 10 + 7 * (i % 3), 640, 480) for i in range(B)]
+        jobs = [P.poseopt_job_from_frame(f, n_iter_ref=(3 if i % 4 == 1 else -1)) for i, f in enumerate(frames)]
+        single = [ctx.pose_optimize(j) for j in jobs]
+        assert len({r.iters for r in single}) > 1                    # the batch does mix iteration counts
+        for k, j in enumerate(jobs):
+            o, _ = ob.pose_optimize(j)
+            assert single[k].iters == o.iters and np.array_equal(single[k].pt_keep, o.pt_keep) and np.allclose(single[k].T, o.T, rtol=0, atol=1e-9), k
+        ctx.poseopt_stage(jobs)
+        for rep in range(3):
+            ctx.poseopt_run()
+            res = ctx.poseopt_fetch()
+            for k in range(B):
+                a, b = res[k], single[k]
+                assert np.array_equal(a.T, b.T) and np.array_equal(a.cov, b.cov) and a.iters == b.iters and a.iters_ref == b.iters_ref, (rep, k)
+                assert a.error_init == b.error_init and a.error_final == b.error_final and a.num_obs_pt == b.num_obs_pt and a.num_obs_ls == b.num_obs_ls, (rep, k)
+                assert np.array_equal(a.pt_keep, b.pt_keep) and np.array_equal(a.seg_keep, b.seg_keep), (rep, k)
+    finally:
+        ctx.close()
+
+
 def _device_bytes(host):
     """`host` (uint8 array) in memory the library's device pointers can address: HBM through torch on a GPU box; the array itself when
     the library is the host emulation build (tests/test_emu_parity.py), whose device memory is host memory.  -> (keep-alive, pointer, read-back)"""
