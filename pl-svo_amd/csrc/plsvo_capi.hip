@@ -839,7 +839,7 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
     c->a_b.cache_ref = c->a_d_cref.as<float>();
   }
   const bool per_level = c->env_align_per_level;
-  const bool reorder = have_levels && !per_level && c->a_n > (c->env_align_reorder_min > 0 ? c->env_align_reorder_min - 1 : 16 * cus_run) &&
+  const bool reorder = have_levels && !per_level && c->a_n > (c->env_align_reorder_min > 0 ? c->env_align_reorder_min - 1 : cus_run * 512 / threads) &&   // more frames than resident workgroups (eight waves per CU)
                        !c->env_align_no_reorder && !c->env_align_no_lpt;
   c->a_b.work_key = nullptr;
   if (reorder) {
@@ -1117,10 +1117,10 @@ extern "C" int plsvo_poseopt_run(plsvo_ctx* c) {
   const long feats = (long)c->p_total_pt + (long)c->p_total_seg;
   int threads = c->p_n <= 2 * cus ? 256 : (feats <= 580l * c->p_n ? 16 : 64);
   if (c->env_poseopt_threads) threads = c->env_poseopt_threads;
-  // batches of many waves per SIMD slot: this launch records what every frame cost, the next one takes them most-expensive first (see
+  // batches larger than the resident waves: this launch records what every frame cost, the next one takes them most-expensive first (see
   // plsvo_align_run; for the rows kernel the sort also puts frames that stop together into the same wave)
   const bool reorder = threads != 256 && !c->env_poseopt_no_reorder &&
-                       c->p_n > (c->env_poseopt_reorder_min > 0 ? c->env_poseopt_reorder_min - 1 : 16 * cus);
+                       c->p_n > (c->env_poseopt_reorder_min > 0 ? c->env_poseopt_reorder_min - 1 : (threads == 16 ? 4 : 8) * cus);   // (rows: the grouping pays before the launch has a tail)
   c->p_b.work_key = nullptr;
   if (reorder) {
     HIP_TRY(c, c->p_d_workkey.ensure((size_t)c->p_n * sizeof(int)));

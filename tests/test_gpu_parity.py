@@ -1043,7 +1043,8 @@ def test_two_workgroups_per_frame_shape(P, ob, gpu_ctx):
 
 
 @pytest.mark.gpu
-def test_launch_order_follows_the_measured_work_of_the_last_run(P, ob):
+@pytest.mark.parametrize("threads", [64, 128, 256])
+def test_launch_order_follows_the_measured_work_of_the_last_run(P, ob, threads):
     """A resident batch larger than the device's resident slots starts its frames longest-first by what they cost in its LAST launch
     (align_kernels.hip::align_reorder_kernel; the threshold is lowered to 4 frames for this test): the order is a permutation, sorted by
     the patch-iterations the device counted, and -- scheduling only -- every frame's result equals the single-frame call's, run after run."""
@@ -1062,7 +1063,7 @@ def test_launch_order_follows_the_measured_work_of_the_last_run(P, ob):
             ctx.build_pyramid(2 * i, imgs[i, 0], 0)
             ctx.build_pyramid(2 * i + 1, imgs[i, 1], 0)
         jobs = [P.align_job_from_stream(s, 3, 1, ref_slot=2 * i, cur_slot=2 * i + 1) for i, s in enumerate(streams)]
-        ctx.set_launch_shapes(align_threads=64)                     # (the throughput shape, as the batches this is for)
+        ctx.set_launch_shapes(align_threads=threads)                # (every shape a batch larger than its resident workgroups can run in)
         single = []
         for j in jobs:
             single.append(ctx.sparse_align(j))
