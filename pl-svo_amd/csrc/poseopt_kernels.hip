@@ -21,6 +21,20 @@
 #include "plsvo_math.hpp"
 #include "plsvo_wave.hpp"
 
+// Waves per SIMD.  The wave-per-frame shape (64 threads) is capped at 168 VGPRs = THREE waves per SIMD: its feature loops stay spill-free
+// (the 58 spilled registers are touched ~20 times per Gauss-Newton iteration, around the solve) and the f64 division chains of a third
+// wave fill latency the other two leave: 500 + 200 features x 32768 frames 3.26 -> 3.19 ms.  The row shape LOSES 9 % at three waves
+// (1.40 -> 1.53 ms at 200 + 80: four frames' serial code per wave meets the spills) and both lose 2x at four; measured on one MI355X box,
+// profiles/r05_poseopt_experiments.log.  -DPLSVO_POSEOPT_WAVES=n / -DPLSVO_POSEOPT_ROWS_WAVES=n rebuild the experiment.
+#ifndef PLSVO_POSEOPT_WAVES
+#define PLSVO_POSEOPT_WAVES 3
+#endif
+#define PLSVO_PO_OCC(T) __attribute__((amdgpu_waves_per_eu((T) == 64 ? PLSVO_POSEOPT_WAVES : 1, (T) == 64 ? PLSVO_POSEOPT_WAVES : 8)))
+#ifdef PLSVO_POSEOPT_ROWS_WAVES
+#define PLSVO_PO_ROWS_OCC __attribute__((amdgpu_waves_per_eu(PLSVO_POSEOPT_ROWS_WAVES, PLSVO_POSEOPT_ROWS_WAVES)))
+#else
+#define PLSVO_PO_ROWS_OCC
+#endif
 namespace plsvo_hip {
 
 // optional per-phase timing (compile with -DPLSVO_TIMING): thread 0 accumulates s_memtime deltas
@@ -309,7 +323,7 @@ __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseS
 }
 
 template <int PO_T>
-__global__ __launch_bounds__(PO_T) void pose_opt_kernel(PoseBatchDev b, double* poses) {
+__global__ __launch_bounds__(PO_T) PLSVO_PO_OCC(PO_T) void pose_opt_kernel(PoseBatchDev b, double* poses) {
   const int job_id = b.order ? b.order[blockIdx.x] : (int)blockIdx.x;
   const PoseJobDev job = b.jobs[job_id];
   PoseStateDev* st = b.state + job_id;
@@ -668,7 +682,7 @@ __device__ __forceinline__ void rows_gn_loop(const PoseBatchDev& b, const PoseJo
   }
 }
 
-__global__ __launch_bounds__(64) void pose_opt_rows_kernel(PoseBatchDev b, double* poses) {
+__global__ __launch_bounds__(64) PLSVO_PO_ROWS_OCC void pose_opt_rows_kernel(PoseBatchDev b, double* poses) {
   __shared__ __align__(16) PoseRowLds s_rows[4];
   const int lane = threadIdx.x & 63, row = lane >> 4, rl = lane & 15;
   const int job_raw = blockIdx.x * 4 + row;
