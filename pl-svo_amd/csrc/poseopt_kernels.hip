@@ -29,8 +29,12 @@
 #ifndef PLSVO_POSEOPT_WAVES
 #define PLSVO_POSEOPT_WAVES 3
 #endif
+#ifdef PLSVO_WAVE_EMU   // (the host emulation build, tests/host/: kernels are plain functions there)
+#define PLSVO_PO_OCC(T)
+#else
 #define PLSVO_PO_OCC(T) __attribute__((amdgpu_waves_per_eu((T) == 64 ? PLSVO_POSEOPT_WAVES : 1, (T) == 64 ? PLSVO_POSEOPT_WAVES : 8)))
-#ifdef PLSVO_POSEOPT_ROWS_WAVES
+#endif
+#if defined(PLSVO_POSEOPT_ROWS_WAVES) && !defined(PLSVO_WAVE_EMU)
 #define PLSVO_PO_ROWS_OCC __attribute__((amdgpu_waves_per_eu(PLSVO_POSEOPT_ROWS_WAVES, PLSVO_POSEOPT_ROWS_WAVES)))
 #else
 #define PLSVO_PO_ROWS_OCC

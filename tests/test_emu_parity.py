@@ -68,6 +68,38 @@ def test_cpp_adapter_on_the_emulated_library(emu_lib):
     assert "4 passed" in out.stdout, out.stdout[-500:]
 
 
+def test_launch_order_sort_is_a_descending_permutation_at_every_size(emu_lib):
+    """`align_reorder_kernel` (the counting sort behind the launch-order refresh of a re-run staged batch, alignment and pose optimiser)
+    called directly on the emulated device: a duplicate or a missing job in its output would be a race or a stale result, and the parity
+    tests only reach batches of a dozen frames.  Sizes on both sides of its 1024 threads and bins; keys equal, random, beyond the bins
+    (clamped to the first) and negative (an unwritten key: clamped to the last).  Run in a sub-process: the library is a second HIP runtime."""
+    code = r'''
+import ctypes as C, sys
+import numpy as np
+L = C.CDLL(sys.argv[1])
+f = getattr(L, "_ZN9plsvo_hip20launch_align_reorderEPKiiPiiPv")
+f.restype = C.c_int
+f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+rng = np.random.default_rng(5)
+for n in (1, 2, 63, 1023, 1024, 1025, 4097, 40000):
+    for kind in ("equal", "random", "wide", "negative"):
+        for shift in (0, 7):
+            if kind == "equal": key = np.full(n, 777, np.int32)
+            elif kind == "random": key = rng.integers(0, 1024 << shift, n).astype(np.int32)
+            elif kind == "wide": key = rng.integers(0, 2**31 - 1, n).astype(np.int32)
+            else: key = rng.integers(-5000, 5000, n).astype(np.int32)
+            order = np.full(n, -1, np.int32)
+            rc = f(key.ctypes.data, n, order.ctypes.data, shift, None)
+            assert rc == 0, rc
+            assert np.array_equal(np.sort(order), np.arange(n)), (n, kind, shift)
+            b = np.clip(key.astype(np.int64) >> shift, 0, 1023)[order]
+            assert np.all(b[:-1] >= b[1:]), (n, kind, shift)
+print("ok")
+'''
+    out = subprocess.run([sys.executable, "-c", code, emu_lib], env=emu_env(emu_lib), capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-1500:] + out.stderr[-3000:]
+
+
 @pytest.mark.parametrize("argv", [["--batch", "8", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.4"],
                                   ["--config", "5", "--batch", "6", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.4"],
                                   ["--config", "4", "--batch", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]], ids=["config2", "config5", "config4-shards"])
