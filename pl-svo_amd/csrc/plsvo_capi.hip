@@ -754,7 +754,8 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
 //   > 4 / > 1 frames per CU:          128 / 256 threads;
 //   at most one frame per CU (latency): 512 threads, the whole CU works on one frame (its points; a second CU on its segments).
 // Environment overrides (experiments only, read once at plsvo_hip_create): PLSVO_ALIGN_THREADS, PLSVO_ALIGN_PER_LEVEL, PLSVO_ALIGN_LDS_PAD,
-// PLSVO_ALIGN_NO_PAIR.
+// PLSVO_ALIGN_NO_PAIR, PLSVO_ALIGN_NO_REORDER / PLSVO_POSEOPT_NO_REORDER (launch order of a re-run staged batch), PLSVO_ALIGN_REORDER_MIN /
+// PLSVO_POSEOPT_REORDER_MIN (its threshold, tests).  A switch set to "0" is off.
 static void pick_align_config(const plsvo_ctx* c, int n_jobs, int cap, int scap, int max_pts, int* threads, size_t* lds, int* chi_lds_pts) {
   const int cus = c->cu_count > 0 ? c->cu_count : 256;
   int t = 64;                            // >= 64 frames per CU: one wave per frame, no workgroup barrier at all
