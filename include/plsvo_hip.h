@@ -73,6 +73,12 @@ void plsvo_hip_destroy(plsvo_ctx* ctx);
  * (alignment), 16 / 64 / 256 / 512 (pose optimiser; 16 = a 16-lane row per frame, four frames per wave: the large-batch shape).  For tests and measurements: every shape computes the same thing. */
 #define PLSVO_OPT_ALIGN_THREADS 2
 #define PLSVO_OPT_POSEOPT_THREADS 3
+/* Launch order of a RE-RUN staged batch (plsvo_align_run / plsvo_poseopt_run called again without a new stage call): 1 (default) =
+ * the frames start longest-first by the work the PREVIOUS launch of the batch measured (a counting sort on the device behind every
+ * launch), 0 = every launch keeps the stage call's order (the alignment's: most patches first).  Scheduling only -- no result depends
+ * on it.  The environment switches PLSVO_ALIGN_NO_REORDER / PLSVO_POSEOPT_NO_REORDER set the initial value to 0. */
+#define PLSVO_OPT_ALIGN_REORDER 4
+#define PLSVO_OPT_POSEOPT_REORDER 5
 int plsvo_hip_set_option(plsvo_ctx* ctx, int option, int value);
 const char* plsvo_hip_last_error(const plsvo_ctx* ctx);   /* ctx may be NULL: last create error */
 void* plsvo_hip_stream(plsvo_ctx* ctx);                   /* the hipStream_t all work is enqueued on */
@@ -87,7 +93,12 @@ int plsvo_hip_synchronize(plsvo_ctx* ctx);
  * rows stored tightly (stride == width of the level).  Re-configuring frees the old slab. */
 int plsvo_hip_config_pyramids(plsvo_ctx* ctx, int n_slots, int width, int height, int n_levels);
 
-/* Upload an existing host pyramid (what the reference keeps in Frame::img_pyr_) into a slot. */
+/* Upload an existing host pyramid (what the reference keeps in Frame::img_pyr_) into a slot.
+ * The call returns WITHOUT a stream synchronisation: the levels are packed into a pinned image of the slot and cross PCIe as one
+ * copy enqueued on the context's stream -- the caller's buffers are free on return, and whatever is launched on the stream afterwards
+ * reads the new pyramid (a caller that reads the slot from ANOTHER stream orders it with plsvo_hip_synchronize).  The slot's tiled
+ * mirror (read by the one-wave-per-frame shape of the alignment only) is refreshed LAZILY: the slot is marked stale here and re-tiled
+ * by the first launch that reads the mirror; plsvo_hip_build_pyramid / _build_pyramids_dev / _copy_slots refresh it eagerly. */
 int plsvo_hip_upload_pyramid(plsvo_ctx* ctx, int slot, int n_levels,
                              const uint8_t* const* level_ptr, const int* width, const int* height,
                              const int* stride_bytes);

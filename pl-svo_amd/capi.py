@@ -152,6 +152,14 @@ class Context:
         if poseopt_threads is not None:
             self._chk(self.L.plsvo_hip_set_option(self.h, 3, int(poseopt_threads)))
 
+    def set_launch_order_refresh(self, align=None, poseopt=None):
+        """launch order of a RE-RUN staged batch: True (default) = longest-first by the previous launch's measured work, False = the stage
+        call's order for every launch (PLSVO_OPT_ALIGN_REORDER / PLSVO_OPT_POSEOPT_REORDER); scheduling only"""
+        if align is not None:
+            self._chk(self.L.plsvo_hip_set_option(self.h, 4, 1 if align else 0))
+        if poseopt is not None:
+            self._chk(self.L.plsvo_hip_set_option(self.h, 5, 1 if poseopt else 0))
+
     def close(self):
         if getattr(self, "h", None):
             self.L.plsvo_hip_destroy(self.h)

@@ -396,6 +396,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
       st->patch_levels = 0; st->patch_iters = 0; st->patch_iters_pt = 0; st->chi2_ties = 0; st->chi2_unarmed = 0;
       for (int k = 0; k < 8; ++k) st->phase_ticks[k] = 0;
       if (nothing && b.poses) for (int k = 0; k < 7; ++k) b.poses[7 * job_id + k] = T_in[k];
+      if (nothing && b.work_key) b.work_key[job_id] = 0;   // a job without work sorts last in the next launch's order
       }
     } else if (!nothing) {   // per-level debug launches: the state crosses launches in HBM
 #pragma unroll
@@ -424,6 +425,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
   const int line0 = pair ? ((job.n_pts + 63) & ~63) : 0;
   unsigned long long* const xb = pair ? b.xbuf + (size_t)job_id * 256 : nullptr;
   unsigned xseq = b.xseq0;                            // (advanced identically by both workgroups: one per exchange)
+  bool x_lost = false;                                // wave 0: an exchange gave up waiting for the partner (pair_allgather32's bounded poll): the frame ends with error 2
 
   for (int level = lv_first; level >= lv_last; --level) {
     // (level geometry is recomputed instead of indexing the kernel-argument arrays with a run-time level,
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
 #pragma unroll
     for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) if (l == level) { n_slots = job.n_slots[l]; long_lines = ((job.long_mask >> l) & 1) != 0; }
     if (n_slots > cap || n_slots > job.patch_cap) {  // host layout inconsistent with the launch: flag and bail out (uniform)
-      if (tid == 0 && lead) st->error = 1;
+      if (tid == 0 && lead) { st->error = 1; if (b.work_key) b.work_key[job_id] = 0; }
       return;
     }
     const int slot_lo = (pair && rank == 1) ? min(line0, n_slots) : 0, slot_hi = (pair && rank == 0) ? min(line0, n_slots) : n_slots;
@@ -1087,7 +1089,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
           if (pair) {   // two workgroups per frame: the partner's partial sums (value 31 carries its patch count of the level); both add in the
             //             same order, so both hold the same totals bit for bit and take the same decisions from here on
             if ((lane & 31) == 31) tot = (double)s_ctl[5];
-            const double theirs = pair_allgather32(xb, rank, xseq, tot);
+            const double theirs = pair_allgather32(xb, rank, xseq, tot, x_lost);
             ++xseq;   // (only wave 0 exchanges, and only its copy of the counter is ever read)
             tot = rank == 0 ? tot + theirs : theirs + tot;
           }
@@ -1133,7 +1135,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
           if constexpr (kQuad) {
             if (pair) {   // chi2 = pt_chi2 + seg_chi2 (:171): the points' sums from rank 0, the lines' from rank 1
               const double mine = (lane & 31) == 0 ? (double)FA : ((lane & 31) == 1 ? (double)FB : 0.0);
-              const double theirs = pair_allgather32(xb, rank, xseq, mine);
+              const double theirs = pair_allgather32(xb, rank, xseq, mine, x_lost);
               ++xseq;
               const float TA = (float)readlane_f64(theirs, 0), TB = (float)readlane_f64(theirs, 1);
               FA = rank == 0 ? __fadd_rn(FA, TA) : __fadd_rn(TA, FA);
@@ -1144,6 +1146,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
           old_chi2 = (double)(FB / (float)(unsigned long long)(s_pose[30] + 0.5));
         }
         TICK(7);
+        if (x_lost && lane == 0) s_ctl[3] = 2;   // the partner workgroup never answered: flag the frame, stop iterating (both sides time out alike)
         if (lane == 0 && !defer) {
           s_ctl[10] = 0;
           s_pose[27] += ev_d;
@@ -1153,7 +1156,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
           if (tie) s_ctl[6] += 1;
           if (near && !have_terms) s_ctl[9] += 1;   // decided on the rounded-once sums after all
           int stop = s_ctl[1];
-          if (isnan(x[0])) stop = 1;                                           // :700
+          if (isnan(x[0]) || x_lost) stop = 1;                                 // :700
           SE3d model = se3_load(s_pose + 12);
           int accepted, brk = 0;
           if ((iter > 0 && new_chi2 > old_chi2) || stop) {
@@ -1222,6 +1225,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
     if (b.work_key) b.work_key[job_id] = (int)fmin(s_pose[29] + 0.5, 2147483647.0);   // what this frame cost: the next launch's sort key
     st->patch_iters_pt += (unsigned long long)(s_pose[31] + 0.5);
     st->stop = s_ctl[1];
+    if (s_ctl[3]) st->error = s_ctl[3];
     st->chi2_ties += s_ctl[6];
     st->chi2_unarmed += s_ctl[9];
     st->n_meas = (unsigned long long)(s_tot[28] + 0.5);

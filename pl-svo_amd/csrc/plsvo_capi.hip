@@ -114,6 +114,8 @@ struct plsvo_ctx {
   DevBuf a_d_order[2];                      // launch order of a RE-RUN resident batch: sorted on the device by the last launch's measured work
   int a_order_next = 0;                     //   (align_kernels.hip::align_reorder_kernel); the buffer the next reorder writes
   bool env_align_no_reorder = false;
+  const int* a_stage_order = nullptr;          // the staged batch's own order (most patches first), inside a_d_blob
+  bool a_one_shot = false, p_one_shot = false;   // set around the run of a one-shot batch call: its launch order is never consumed
   int env_align_reorder_min = 0;            //   PLSVO_ALIGN_REORDER_MIN: smallest batch that is re-ordered (tests; default 16 frames per CU)
   DevBuf a_d_xbuf;                          // two workgroups per frame: their exchange granules (2 KB per frame, zeroed once)
   unsigned int x_launch = 0;                // launches that used it (tags = launch << 10 | exchange: never repeated)
@@ -305,6 +307,16 @@ extern "C" int plsvo_hip_set_option(plsvo_ctx* c, int option, int value) {
     c->env_poseopt_threads = value;
     return PLSVO_OK;
   }
+  if (option == PLSVO_OPT_ALIGN_REORDER || option == PLSVO_OPT_POSEOPT_REORDER) {
+    if (value != 0 && value != 1) return fail(c, PLSVO_E_INVALID, "set_option: the launch-order refresh is 0 (keep the stage order) or 1 (refresh from the last launch's measured work)");
+    if (option == PLSVO_OPT_ALIGN_REORDER) {
+      c->env_align_no_reorder = value == 0;
+      if (value == 0 && c->a_staged && c->a_d_blob.p) c->a_b.order = c->a_stage_order;   // back to the stage call's order
+    } else {
+      c->env_poseopt_no_reorder = value == 0;
+    }
+    return PLSVO_OK;
+  }
   return fail(c, PLSVO_E_INVALID, "set_option: unknown option");
 }
 
@@ -446,8 +458,16 @@ static int build_levels(plsvo_ctx* c, int first_slot, int n, int rounding) {
                                  base + c->pyr.off[l], c->pyr.slot_bytes, n, rounding, c->stream));
     prof_end(c, PLSVO_K_HALFSAMPLE, &ep);
   }
+  // (the slots count as fresh only once their tile launches are enqueued: a failed launch leaves them stale and the next launch that
+  //  reads the mirror tries again -- ADVICE r05)
+  const int rc_t = retile(c, first_slot, n, c->pyr.n_levels);
+  if (rc_t) {
+    for (int s = first_slot; s < first_slot + n && s < (int)c->tiled_stale.size(); ++s)
+      if (!c->tiled_stale[(size_t)s]) { c->tiled_stale[(size_t)s] = 1; ++c->tiled_stale_count; }
+    return rc_t;
+  }
   mark_tiled_fresh(c, first_slot, n);
-  return retile(c, first_slot, n, c->pyr.n_levels);
+  return PLSVO_OK;
 }
 
 extern "C" int plsvo_hip_build_pyramid(plsvo_ctx* c, int slot, const uint8_t* level0, int stride_bytes, int rounding) {
@@ -562,8 +582,10 @@ extern "C" int plsvo_align_slot_layout(const plsvo_align_in* in, int level, int3
 
 // Up to three device ranges to the host with ONE wait: through the context's pinned download buffer when they fit (a per-frame caller's
 // results: a few hundred bytes of state + the flags), straight into the caller's (pageable) buffers otherwise.  On return h[k] points at
-// range k's bytes: inside the pinned buffer (valid until the next fetch) or at dst[k].
-static int download_ranges(plsvo_ctx* c, int n_ranges, const void* const* src, const size_t* bytes, void* const* dst, const uint8_t** h) {
+// range k's bytes: inside the pinned buffer (valid until the next fetch) or inside `fallback`.
+// (`fallback` is sized HERE whenever the pinned path is not taken -- too large, or no pinned memory to be had -- so the decision and the
+//  storage can never disagree: ADVICE r05)
+static int download_ranges(plsvo_ctx* c, int n_ranges, const void* const* src, const size_t* bytes, std::vector<uint8_t>& fallback, const uint8_t** h) {
   size_t total = 0, off[3] = { 0, 0, 0 };
   for (int k = 0; k < n_ranges; ++k) { off[k] = total; total += (bytes[k] + 63) & ~(size_t)63; }
   bool pinned = total <= ((size_t)4 << 20);
@@ -573,8 +595,10 @@ static int download_ranges(plsvo_ctx* c, int n_ranges, const void* const* src, c
     const size_t want = std::max(total * 2, (size_t)64 << 10);
     if (hipHostMalloc(&c->dl_pinned, want, hipHostMallocDefault) == hipSuccess) c->dl_pinned_cap = want; else { c->dl_pinned = nullptr; pinned = false; }
   }
+  if (!pinned) fallback.resize(std::max(total, (size_t)64));
+  uint8_t* const base = pinned ? static_cast<uint8_t*>(c->dl_pinned) : fallback.data();
   for (int k = 0; k < n_ranges; ++k) {
-    void* to = pinned ? static_cast<void*>(static_cast<uint8_t*>(c->dl_pinned) + off[k]) : dst[k];
+    void* to = static_cast<void*>(base + off[k]);
     h[k] = static_cast<const uint8_t*>(to);
     if (bytes[k]) HIP_TRY(c, hipMemcpyAsync(to, src[k], bytes[k], hipMemcpyDeviceToHost, c->stream));
   }
@@ -738,6 +762,7 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
   b.n_jobs = n;
   b.pair = 0; b.xseq0 = 0; b.xbuf = nullptr; b.work_key = nullptr;   // (plsvo_align_run decides)
   b.order = reinterpret_cast<const int*>(base + o_order);
+  c->a_stage_order = b.order;
   c->a_jobs.swap(jobs);
   c->a_n = n; c->a_total_seg = (int)alive.size(); c->a_gmax = gmax; c->a_gmin = gmin;
   for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) c->a_cap[l] = caps[l];
@@ -822,8 +847,13 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
   // iteration through L2 (~1 us) and both run the identical solver.  Needs the latency shape, the chi2 planes in LDS (no deferred
   // decisions) and the layout staged for it; the per-level debug launches keep one workgroup.
   const int cus_run = c->cu_count > 0 ? c->cu_count : 256;
+  // (exchange tags are launch << 10 | exchange, at most two exchanges per Gauss-Newton iteration -- the totals and a near tie's float sums:
+  //  a launch that could need more than 1023 of them keeps one workgroup per frame, so a tag never runs into the next launch's range)
+  int max_iter = 0;
+  for (const AlignJobDev& J : c->a_jobs) max_iter = std::max(max_iter, J.n_iter);
+  const long long max_exchanges = have_levels ? (long long)(c->a_gmax - c->a_gmin + 1) * (long long)max_iter * 2 : 0;
   const bool pair = threads >= kQuadMinThreads && chi_lds_pts > 0 && c->a_seg_align == 64 && 2 * c->a_n <= cus_run && !c->env_align_no_pair &&
-                    !c->env_align_per_level && have_levels;
+                    !c->env_align_per_level && have_levels && max_exchanges < 1024;
   c->a_b.pair = pair ? 1 : 0;
   if (pair) {
     const size_t xbytes = (size_t)c->a_n * 256 * sizeof(unsigned long long);
@@ -832,7 +862,11 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
       HIP_TRY(c, hipMemsetAsync(c->a_d_xbuf.p, 0, c->a_d_xbuf.cap, c->stream));   // tag 0 is never used
     }
     c->a_b.xbuf = c->a_d_xbuf.as<unsigned long long>();
-    c->x_launch = (c->x_launch + 1u) & 0x3fffffu; if (c->x_launch == 0) c->x_launch = 1;
+    c->x_launch = (c->x_launch + 1u) & 0x3fffffu;
+    if (c->x_launch == 0) {   // the 22-bit launch counter wrapped: old tags could repeat -- zero the granules again (stream-ordered behind the last launch)
+      HIP_TRY(c, hipMemsetAsync(c->a_d_xbuf.p, 0, c->a_d_xbuf.cap, c->stream));
+      c->x_launch = 1;
+    }
     c->a_b.xseq0 = c->x_launch << 10;
   }
   if (threads >= kQuadMinThreads) {   // latency shapes keep the reference patches as float rows: 192 B per slot (small batches only: <= 4 frames per CU)
@@ -840,11 +874,15 @@ extern "C" int plsvo_align_run(plsvo_ctx* c) {
     c->a_b.cache_ref = c->a_d_cref.as<float>();
   }
   const bool per_level = c->env_align_per_level;
+  // (a one-shot call -- plsvo_sparse_align_batch -- never re-runs its batch: no key, no sort)
   const bool reorder = have_levels && !per_level && c->a_n > (c->env_align_reorder_min > 0 ? c->env_align_reorder_min - 1 : cus_run * 512 / threads) &&   // more frames than resident workgroups (eight waves per CU)
-                       !c->env_align_no_reorder && !c->env_align_no_lpt;
+                       !c->env_align_no_reorder && !c->env_align_no_lpt && !c->a_one_shot;
   c->a_b.work_key = nullptr;
   if (reorder) {
-    HIP_TRY(c, c->a_d_workkey.ensure((size_t)c->a_n * sizeof(int)));
+    if (c->a_d_workkey.cap < (size_t)c->a_n * sizeof(int)) {   // a fresh key buffer starts at zero work: jobs that leave the kernel early never write theirs
+      HIP_TRY(c, c->a_d_workkey.ensure((size_t)c->a_n * sizeof(int)));
+      HIP_TRY(c, hipMemsetAsync(c->a_d_workkey.p, 0, c->a_d_workkey.cap, c->stream));
+    }
     c->a_b.work_key = c->a_d_workkey.as<int>();
   }
   if (!per_level || !have_levels) {
@@ -876,14 +914,11 @@ extern "C" int plsvo_align_fetch(plsvo_ctx* c, int n, plsvo_align_out* out) {
   if (!c->a_staged) return fail(c, PLSVO_E_STATE, "align_fetch: no staged batch");
   if (n != c->a_n || !out) return fail(c, PLSVO_E_INVALID, "align_fetch: n does not match the staged batch");
   HIP_TRY(c, hipSetDevice(c->device));
-  std::vector<AlignStateDev> st_v;
-  std::vector<uint8_t> alive_v;
+  std::vector<uint8_t> big;   // (large batches, or no pinned memory: download_ranges sizes it)
   const size_t rb[2] = { (size_t)n * sizeof(AlignStateDev), (size_t)std::max(c->a_total_seg, 0) };
-  if (rb[0] + rb[1] > ((size_t)4 << 20)) { st_v.resize((size_t)n); alive_v.resize((size_t)std::max(c->a_total_seg, 1)); }   // (large batches: the caller-side staging of old)
   const void* const rs[2] = { c->a_d_state.p, c->a_d_alive.p };
-  void* const rd[2] = { st_v.data(), alive_v.data() };
   const uint8_t* rh[2] = { nullptr, nullptr };
-  { const int rc_d = download_ranges(c, 2, rs, rb, rd, rh); if (rc_d) return rc_d; }
+  { const int rc_d = download_ranges(c, 2, rs, rb, big, rh); if (rc_d) return rc_d; }
   const AlignStateDev* const st = reinterpret_cast<const AlignStateDev*>(rh[0]);
   const uint8_t* const alive = rh[1];
   int dev_err = 0;
@@ -912,7 +947,10 @@ extern "C" int plsvo_sparse_align_batch(plsvo_ctx* c, int n, const plsvo_align_i
   const auto t0 = std::chrono::steady_clock::now();
   int rc = plsvo_align_stage(c, n, in); if (rc) return rc;
   const auto t1 = std::chrono::steady_clock::now();
-  rc = plsvo_align_run(c); if (rc) return rc;
+  c->a_one_shot = true;
+  rc = plsvo_align_run(c);
+  c->a_one_shot = false;
+  if (rc) return rc;
   const auto t2 = std::chrono::steady_clock::now();
   rc = plsvo_align_fetch(c, n, out);
   if (host_timing) {
@@ -1120,11 +1158,14 @@ extern "C" int plsvo_poseopt_run(plsvo_ctx* c) {
   if (c->env_poseopt_threads) threads = c->env_poseopt_threads;
   // batches larger than the resident waves: this launch records what every frame cost, the next one takes them most-expensive first (see
   // plsvo_align_run; for the rows kernel the sort also puts frames that stop together into the same wave)
-  const bool reorder = threads != 256 && !c->env_poseopt_no_reorder &&
+  const bool reorder = threads != 256 && !c->env_poseopt_no_reorder && !c->p_one_shot &&
                        c->p_n > (c->env_poseopt_reorder_min > 0 ? c->env_poseopt_reorder_min - 1 : (threads == 16 ? 4 : 8) * cus);   // (rows: the grouping pays before the launch has a tail)
   c->p_b.work_key = nullptr;
   if (reorder) {
-    HIP_TRY(c, c->p_d_workkey.ensure((size_t)c->p_n * sizeof(int)));
+    if (c->p_d_workkey.cap < (size_t)c->p_n * sizeof(int)) {
+      HIP_TRY(c, c->p_d_workkey.ensure((size_t)c->p_n * sizeof(int)));
+      HIP_TRY(c, hipMemsetAsync(c->p_d_workkey.p, 0, c->p_d_workkey.cap, c->stream));
+    }
     c->p_b.work_key = c->p_d_workkey.as<int>();
   } else c->p_b.order = nullptr;
   EventPair ep{}; prof_begin(c, PLSVO_K_POSEOPT, &ep);
@@ -1146,14 +1187,11 @@ extern "C" int plsvo_poseopt_fetch(plsvo_ctx* c, int n, plsvo_poseopt_out* out) 
   if (!c->p_staged) return fail(c, PLSVO_E_STATE, "poseopt_fetch: no staged batch");
   if (n != c->p_n || !out) return fail(c, PLSVO_E_INVALID, "poseopt_fetch: n does not match the staged batch");
   HIP_TRY(c, hipSetDevice(c->device));
-  std::vector<PoseStateDev> st_v;
-  std::vector<uint8_t> pk_v, sk_v;
+  std::vector<uint8_t> big;   // (large batches, or no pinned memory: download_ranges sizes it)
   const size_t rb[3] = { (size_t)n * sizeof(PoseStateDev), (size_t)std::max(c->p_total_pt, 0), (size_t)std::max(c->p_total_seg, 0) };
-  if (rb[0] + rb[1] + rb[2] > ((size_t)4 << 20)) { st_v.resize((size_t)n); pk_v.resize((size_t)std::max(c->p_total_pt, 1)); sk_v.resize((size_t)std::max(c->p_total_seg, 1)); }
   const void* const rs[3] = { c->p_d_state.p, c->p_d_ptkeep.p, c->p_d_segkeep.p };
-  void* const rd[3] = { st_v.data(), pk_v.data(), sk_v.data() };
   const uint8_t* rh[3] = { nullptr, nullptr, nullptr };
-  { const int rc_d = download_ranges(c, 3, rs, rb, rd, rh); if (rc_d) return rc_d; }
+  { const int rc_d = download_ranges(c, 3, rs, rb, big, rh); if (rc_d) return rc_d; }
   const PoseStateDev* const st = reinterpret_cast<const PoseStateDev*>(rh[0]);
   const uint8_t* const pk = rh[1]; const uint8_t* const sk = rh[2];
   for (int j = 0; j < n; ++j) {
@@ -1176,7 +1214,10 @@ extern "C" int plsvo_poseopt_fetch(plsvo_ctx* c, int n, plsvo_poseopt_out* out) 
 
 extern "C" int plsvo_pose_optimize_batch(plsvo_ctx* c, int n, const plsvo_poseopt_in* in, plsvo_poseopt_out* out) {
   int rc = plsvo_poseopt_stage(c, n, in); if (rc) return rc;
-  rc = plsvo_poseopt_run(c); if (rc) return rc;
+  c->p_one_shot = true;
+  rc = plsvo_poseopt_run(c);
+  c->p_one_shot = false;
+  if (rc) return rc;
   return plsvo_poseopt_fetch(c, n, out);
 }
 extern "C" int plsvo_pose_optimize(plsvo_ctx* c, const plsvo_poseopt_in* in, plsvo_poseopt_out* out) {

@@ -342,7 +342,10 @@ __device__ __forceinline__ unsigned long long granule_load(const unsigned long l
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
-__device__ __forceinline__ double pair_allgather32(unsigned long long* xb, int rank, unsigned seq, double mine) {
+// The poll is BOUNDED (kPairPollMax rounds of a load + s_sleep, ~1 s): a partner that never publishes -- tags out of step, a workgroup
+// that was never scheduled -- sets `lost` instead of hanging the GPU; the caller flags the frame (AlignStateDev::error = 2) and stops.
+constexpr unsigned kPairPollMax = 1u << 20;
+__device__ __forceinline__ double pair_allgather32(unsigned long long* xb, int rank, unsigned seq, double mine, bool& lost) {
   const int lane = threadIdx.x & 63;
   const double v = __shfl(mine, lane >> 1, 64);                                   // lane l ships half (l & 1) of value l >> 1
   const unsigned half = (lane & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v);
@@ -350,9 +353,10 @@ __device__ __forceinline__ double pair_allgather32(unsigned long long* xb, int r
   const unsigned long long* const peer = xb + (((seq & 1u) * 2u + (unsigned)(rank ^ 1)) * 64u + (unsigned)lane);
   granule_store(own, ((unsigned long long)seq << 32) | (unsigned long long)half);
   unsigned long long g;
-  for (;;) {
+  for (unsigned polls = 0;; ++polls) {
     g = granule_load(peer);
     if (!__any((unsigned)(g >> 32) != seq)) break;
+    if (polls >= kPairPollMax || lost) { lost = true; break; }   // (once lost, later exchanges of the launch do not wait again)
 #ifdef PLSVO_WAVE_EMU
     wave_emu_yield_thread();
 #else

@@ -43,6 +43,11 @@ class HipBackend:
     def sparse_align(self, job):
         return self.ctx.sparse_align(job)
 
+    def align_ties(self):
+        """Gauss-Newton iterations of the LAST alignment whose accept / roll-back decision was taken on the exact float chi2 sums (a frame
+        that met none cannot have left its path on a last-bit tie)"""
+        return int(self.ctx.align_chi2_ties()[1])
+
     def reproject(self, job):
         return self.ctx.reproject(job)
 
@@ -191,6 +196,7 @@ def run_sequence(backend, seq, max_level=3, min_level=1, n_pyr_levels=3, reproj_
             pj = abi.PoseOptJob(T_k, abs(cam[0]), reproj_thresh, 10, _bearing(cam, px_new[pt_i]), P3[pt_i], level[pt_i], line,
                                 seq["seg_spos"][seg_i], seq["seg_epos"][seg_i], level[n_pts + seg_i])
             pr = backend.pose_optimize(pj)
+        n_ties = backend.align_ties() if hasattr(backend, "align_ties") else None
         T_k = pr.T.copy()
         pt_keep, seg_keep = pr.pt_keep.astype(bool), pr.seg_keep.astype(bool)
         prev = dict(pt_idx=pt_i[pt_keep], pt_px=px_new[pt_i[pt_keep]], seg_idx=seg_i[seg_keep],
@@ -198,6 +204,8 @@ def run_sequence(backend, seq, max_level=3, min_level=1, n_pyr_levels=3, reproj_
         T_prev = T_k
         rec = dict(T=T_k.copy(), cov=pr.cov.copy(), n_align=ar.n_tracked, n_matched_pt=int(pt_ok.sum()), n_matched_seg=int(seg_ok.sum()),
                    n_kept_pt=int(pt_keep.sum()), n_kept_seg=int(seg_keep.sum()))
+        if n_ties is not None:
+            rec["align_ties"] = n_ties
         if mapping:
             poses_est.append(T_k.copy())
             kept = pt_i[pt_keep]

@@ -197,8 +197,9 @@ def make_align_stream(seed, W=640, H=480, n_pts=200, n_seg=80, max_level=3, moti
     return st
 
 
-def render_streams(streams, device="cpu", noise_sigma=2.0, chunk=64):
-    """Render the (ref, cur) level-0 images of a list of AlignStream -> uint8 tensor [B, 2, H, W] on `device`."""
+def render_streams(streams, device="cpu", noise_sigma=2.0, chunk=64, which=(0, 1)):
+    """Render the (ref, cur) level-0 images of a list of AlignStream -> uint8 tensor [B, 2, H, W] on `device`
+    (`which` = (1,): only the cur images are rendered, [:, 0] is left unwritten)."""
     B = len(streams)
     W, H = streams[0].W, streams[0].H
     dev = torch.device(device)
@@ -208,6 +209,7 @@ def render_streams(streams, device="cpu", noise_sigma=2.0, chunk=64):
     v = torch.arange(H, dtype=torch.float64, device=dev)
     rays = torch.stack([((u - cx) / fx)[None, :].expand(H, W), ((v - cy) / fy)[:, None].expand(H, W),
                         torch.ones((H, W), dtype=torch.float64, device=dev)], dim=-1)  # [H,W,3]
+    which_list = tuple(which)
     for c0 in range(0, B, chunk):
         sub = streams[c0:c0 + chunk]
         b = len(sub)
@@ -219,7 +221,7 @@ def render_streams(streams, device="cpu", noise_sigma=2.0, chunk=64):
         tex = t64([s.tex for s in sub])          # [b,K,4]
         tnorm = t64([np.array(s.tex_norm) for s in sub])
         gen = torch.Generator(device=dev)
-        for which in (0, 1):
+        for which in which_list:
             if which == 0:
                 o = torch.zeros((b, 3), dtype=torch.float64, device=dev)
                 dirs = rays[None].expand(b, H, W, 3)
@@ -244,6 +246,35 @@ def render_streams(streams, device="cpu", noise_sigma=2.0, chunk=64):
                 gen.manual_seed(int(sub[0].seed) * 2 + which + 977)
                 img = img + noise_sigma * torch.randn(img.shape, dtype=torch.float64, device=dev, generator=gen)
             out[c0:c0 + b, which] = img.round().clamp(0, 255).to(torch.uint8)
+    return out
+
+
+def stream_motion(st, k, motion_scale=0.5):
+    """cur_from_ref of the k-th image of a MOVING sequence over stream `st`'s scene: drawn like make_align_stream draws T_true (the same
+    range, the same scale) but independently for every k -- successive images of a stream share the scene, the features and the initial
+    pose, nothing else (bench.py's moving-inputs leg: the harshest case for anything learned from the previous launch)."""
+    rng = np.random.default_rng((int(st.seed) * 1000003 + 7919 * (int(k) + 1)) & 0x7fffffff)
+    d0 = st.plane_d / st.plane_n[2]
+    xi = np.concatenate([rng.uniform(-0.03, 0.03, 3) * d0, rng.uniform(-0.01, 0.01, 3)]) * motion_scale
+    return se3_exp(xi)
+
+
+def render_views(streams, poses, device="cpu", noise_sigma=2.0, chunk=64, noise_tag=0):
+    """One level-0 image per stream, seen from `poses[i]` (cur_from_ref; None = the reference view) -> uint8 tensor [B, H, W] on
+    `device`.  Same scene model and arithmetic as render_streams (which renders the pair ref / T_true)."""
+    import copy
+    out = None
+    for c0 in range(0, len(streams), chunk):
+        sub = []
+        for s_, T in zip(streams[c0:c0 + chunk], poses[c0:c0 + chunk]):
+            v = copy.copy(s_)
+            v.T_true = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]) if T is None else np.asarray(T, dtype=np.float64)
+            v.seed = int(s_.seed) + 104729 * (int(noise_tag) + 1)      # its own noise realisation
+            sub.append(v)
+        img = render_streams(sub, device=device, noise_sigma=noise_sigma, chunk=chunk, which=(1,))[:, 1]
+        if out is None:
+            out = torch.empty((len(streams),) + tuple(img.shape[1:]), dtype=torch.uint8, device=img.device)
+        out[c0:c0 + len(sub)] = img
     return out
 
 

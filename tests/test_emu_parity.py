@@ -122,6 +122,12 @@ def test_bench_script_dry_run(emu_lib, argv):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["algorithmic_bytes_per_launch"] > 0 and r["launches"] >= 1
+    if "--config" not in argv:   # the alignment's roofline is a bandwidth: bounded by the peak; SURVEY 8(d)'s work rate sits under its own name
+        assert 0 < r["frac"] <= 1.0 and r["work_rate_survey_units_GBps"] > 0 and r["basis"].startswith(("pmc_traffic", "formulation_min"))
+        lo = d["launch_order"]
+        assert lo["policy"] in ("refresh", "staged") and lo["value_other_policy"] > 0
+        mv = lo["moving_inputs"]
+        assert "error" not in mv and mv["align_launch_ms"]["staged_order"] > 0 and len(mv["align_launch_ms_per_image"]["ideal_same_image"]) == 2, mv
     if argv[0] == "--batch":     # the default workload also carries the small-batch leg
         assert d["latency"]["B1"]["frames_per_s"] > 0 and d["latency"]["B8"]["frames_per_s"] > 0, d.get("latency")
         # ... and the host-fed and resident-frame-step legs (guarded by try/except in the script: an error would only show up here)

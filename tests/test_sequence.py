@@ -118,13 +118,16 @@ def test_hip_resident_chain_equals_the_per_call_chain(P, ob, gpu_ctx, seqm):
     seq2 = seqm.make_sequence(6, n_frames=12, W=320, H=240, n_pts=100, n_seg=20, step_scale=1.0)
     rc2 = seqm.run_sequence(seqm.HipBackend(gpu_ctx), seq2, mapping=True)
     rd2 = seqm.run_sequence(seqm.HipChainBackend(gpu_ctx), seq2, mapping=True)
+    tie_seen = False
     for k, (a, b) in enumerate(zip(rd2, rc2)):
         ang, dist = P.synth.se3_log_angle_dist(a["T"], b["T"])
-        # (the two chains normalise the new landmarks' bearings in different places: inputs that differ in the last bit, which a last-bit tie
-        #  of the alignment's float chi2 comparison turns into ~1e-8 now and then -- the float-tie floor of INTEGRATION.md section 3, three
-        #  orders of magnitude inside the bar; which frame meets it depends on the kernel's summation order: round 5's two-workgroup shape
-        #  meets it at frame 6 of this sequence, 1.0e-8 rad / 5.1e-8)
-        assert ang < 1e-7 and dist < 1e-6 and a.get("n_known") == b.get("n_known"), (k, ang, dist)
+        # The two chains normalise the new landmarks' bearings in different places: inputs that differ in the last bit.  Frame for frame the
+        # bar is 1e-9 -- UNTIL one of the two chains reports an alignment iteration decided on a float chi2 tie (plsvo_align_chi2_ties):
+        # there a last-bit input difference can flip the decision (the float-tie floor of INTEGRATION.md section 3, ~1e-8), and since the
+        # pose of frame k starts frame k + 1, every later frame inherits it.  Only those frames get the wider bar.
+        tie_seen = tie_seen or a.get("align_ties", 0) > 0 or b.get("align_ties", 0) > 0
+        tol_a, tol_d = (1e-7, 1e-6) if tie_seen else (1e-9, 1e-9)
+        assert ang < tol_a and dist < tol_d and a.get("n_known") == b.get("n_known"), (k, ang, dist, tie_seen)
 
 
 @pytest.mark.gpu

@@ -16,7 +16,10 @@ coalesced stream on gfx950 and calls other access widths and WRITE_SIZE uncalibr
 Three figures are written per kernel: uncorrected (FETCH + WRITE), upper bound (2 x FETCH + WRITE: every fetch wide) and the
 estimate bench.py reports, c_fetch x FETCH + c_write x WRITE with c_fetch = w_wide x c_wide + (1 - w_wide) x 1, where w_wide is the
 wide share of the kernel's own requests (64 + 24 B of dense loads against 40 B of gathered dwords per patch-iteration; rounds 1-3: 192 + 24 against 48)."""
-import csv, json, sys
+import csv, json, os, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha     # hash of the sources align_fused_kernel is built from: bench.py uses the traffic only while it matches
 
 
 def per_launch(path, counter, kernel_substr):
@@ -30,7 +33,7 @@ def per_launch(path, counter, kernel_substr):
 
 fetch_csv, write_csv, batch, out, cmd, commit = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
 res = {"note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) on `{cmd}`, MI355X. Counters are in KiB.",
-       "batch": batch, "measured_at": commit}
+       "batch": batch, "measured_at": commit, "kernel_source_sha": kernel_source_sha()}
 c_wide, c_gather, c_write, calib = 2.0, 1.0, 1.0, None
 if len(sys.argv) > 9:
     cf, cw, cj = sys.argv[7], sys.argv[8], json.load(open(sys.argv[9]))
