@@ -143,7 +143,10 @@ def offline_traffic(B, config=2):
 # previous launch is learned from bit-identical inputs; whether it survives inputs that CHANGE is what the moving-inputs leg
 # (moving_leg below, profiles/r06_launch_order_moving_inputs.log) measures.  The policy here is set from that measurement and is the
 # same at every --gpus N; the line reports the figure of the other policy beside `value`.
-LAUNCH_ORDER_REFRESH = True
+# Measured (MI355X, 8192 streams x 8 images, profiles/r06_launch_order_moving_inputs.log): with independently drawn motions the refreshed
+# order keeps 18 % of the gain the same-image order has (4.13 ms staged, 4.04 refreshed, 3.61 ideal) -- less than half, so the timed steps
+# run in the STAGE CALL'S order; the repeat-input figure is reported beside `value` (launch_order.value_other_policy).
+LAUNCH_ORDER_REFRESH = False
 
 
 _DRY = False   # set by main() for the CPU dry run on the emulated library (tests/test_emu_parity.py): a handful of steps instead of hundreds
@@ -299,17 +302,20 @@ def host_fed_leg(P, torch, dev, stream, streams, cfg, n_streams=1024, steps=12):
         ctx.close()
 
 
-def moving_leg(P, torch, dev, stream, streams, cfg, n_streams=8192, n_images=8):
+def moving_leg(P, torch, dev, stream, streams, cfg, n_streams=8192, n_images=8, models=("independent", "smooth")):
     """Does a launch order learned from the PREVIOUS launch survive inputs that change?  (Never `value`.)
 
     The timed steps of this benchmark re-run one staged batch, so align_reorder_kernel sorts every launch by the work the previous
     launch measured on bit-identical inputs.  Here every launch sees a NEW current image: n streams, each with its reference frame and
-    n_images current images rendered at independently drawn motions (synth.stream_motion: same scene, same features, same initial pose,
-    nothing else in common -- the harshest case; a real camera's successive motions are correlated).  Before every launch the next image's
-    pyramid is copied into the streams' current-frame slots on the device (plsvo_hip_copy_slots), then plsvo_align_run; the launch
-    shape is the headline's (one wave per frame).  Three launch orders, hipEvent time of the alignment launch per image:
+    n_images current images (same scene, same features, same initial pose) rendered at
+      "independent"  independently drawn motions (synth.stream_motion): the harshest case -- only what the scene and the feature
+                     set decide about a frame's cost carries over from one image to the next; THIS model decides the policy;
+      "smooth"       motions within ~15 % of one per-stream motion: a camera on a smooth path.
+    Before every launch the next image's pyramid is copied into the streams' current-frame slots on the device
+    (plsvo_hip_copy_slots), then plsvo_align_run; the launch shape is the headline's (one wave per frame).  Three launch orders,
+    hipEvent time of the alignment launch per image:
       staged    PLSVO_OPT_ALIGN_REORDER = 0: the stage call's order (most patches first) for every launch
-      refresh   the default: longest-first by the work of the previous launch -- which ran on a DIFFERENT image
+      refresh   the library's default: longest-first by the work of the previous launch -- which ran on a DIFFERENT image
       ideal     the same image launched a second time: the order comes from its own work (what a repeat-input benchmark step sees)
     gain_kept = (staged - refresh) / (staged - ideal)."""
     capi, synth, abi = P.capi, P.synth, P.abi
@@ -320,21 +326,15 @@ def moving_leg(P, torch, dev, stream, streams, cfg, n_streams=8192, n_images=8):
     try:
         ctx.set_launch_shapes(align_threads=64)
         ctx.config_pyramids((2 + K) * n, W, H, cfg["pyr"])      # ref frames [0, n), working current frames [n, 2n), image k at [(2 + k) n, (3 + k) n)
-        motions = [[synth.stream_motion(s_, k) for s_ in sub] for k in range(K)]
         chunk = 256
         for c0 in range(0, n, chunk):
             part = sub[c0:c0 + chunk]
             img = synth.render_views(part, [None] * len(part), device=dev)
             ctx.build_pyramids_dev(c0, len(part), img.data_ptr(), W, W * H, 0)
-            for k in range(K):
-                ctx.synchronize()
-                img = synth.render_views(part, motions[k][c0:c0 + chunk], device=dev, noise_tag=k + 1)
-                ctx.build_pyramids_dev((2 + k) * n + c0, len(part), img.data_ptr(), W, W * H, 0)
             ctx.synchronize()
             del img
         jobs = [P.align_job_from_stream(s_, cfg["maxl"], cfg["minl"], ref_slot=i, cur_slot=n + i) for i, s_ in enumerate(sub)]
         ctx.align_stage(jobs)
-        ctx.set_profiling(True)
 
         def timed_run():
             ctx.reset_profiling()
@@ -356,24 +356,36 @@ def moving_leg(P, torch, dev, stream, streams, cfg, n_streams=8192, n_images=8):
                     second.append(timed_run())
             return first, second
 
-        sweep(True, False)                      # warm-up of everything (code, order buffers)
-        staged, _ = sweep(False, False)
-        refresh, ideal = sweep(True, True)
-        ctx.set_profiling(False)
-        res = ctx.align_fetch()                 # the last launch ran on image K - 1
-        errs = np.array([synth.se3_log_angle_dist(r.T, T) for r, T in zip(res[:64], motions[K - 1][:64])])
-        ms_s, ms_r, ms_i = float(np.mean(staged)), float(np.mean(refresh)), float(np.mean(ideal))
-        kept = (ms_s - ms_r) / (ms_s - ms_i) if ms_s - ms_i > 1e-9 else None
-        return {"streams": n, "images_per_stream": K, "launch_shape_threads": 64,
-                "align_launch_ms": {"staged_order": round(ms_s, 4), "refresh_from_previous_image": round(ms_r, 4), "ideal_same_image": round(ms_i, 4)},
-                "align_launch_ms_per_image": {"staged_order": [round(x, 4) for x in staged], "refresh_from_previous_image": [round(x, 4) for x in refresh],
-                                              "ideal_same_image": [round(x, 4) for x in ideal]},
-                "gain_ideal_pct": round(100.0 * (ms_s - ms_i) / ms_s, 2), "gain_refresh_pct": round(100.0 * (ms_s - ms_r) / ms_s, 2),
-                "gain_kept": round(kept, 3) if kept is not None else None,
-                "median_rot_err_vs_truth_rad": float(np.median(errs[:, 0])),
-                "what": "every launch aligns a NEW current image (independently drawn motion per image, same features and initial pose): hipEvent time "
-                        "of the alignment launch in the stage call's order, in the order refreshed from the previous launch (another image), "
-                        "and re-launched on the same image (order from its own work); NOT the headline value"}
+        out = {"streams": n, "images_per_stream": K, "launch_shape_threads": 64,
+               "what": "every launch aligns a NEW current image (same features and initial pose): hipEvent time of the alignment launch in the stage call's "
+                       "order, in the order refreshed from the previous launch (another image), and re-launched on the same image (order from its own "
+                       "work); `independent`: motions drawn independently per image (decides the policy), `smooth`: within ~15 % of one motion per stream; "
+                       "NOT the headline value"}
+        for model in models:
+            motions = [[synth.stream_motion(s_, k, model=model) for s_ in sub] for k in range(K)]
+            for c0 in range(0, n, chunk):
+                part = sub[c0:c0 + chunk]
+                for k in range(K):
+                    img = synth.render_views(part, motions[k][c0:c0 + chunk], device=dev, noise_tag=k + 1)
+                    ctx.build_pyramids_dev((2 + k) * n + c0, len(part), img.data_ptr(), W, W * H, 0)
+                    ctx.synchronize()
+                    del img
+            ctx.set_profiling(True)
+            sweep(True, False)                      # warm-up of everything (code, order buffers)
+            staged, _ = sweep(False, False)
+            refresh, ideal = sweep(True, True)
+            ctx.set_profiling(False)
+            res = ctx.align_fetch()                 # the last launch ran on image K - 1
+            errs = np.array([synth.se3_log_angle_dist(r.T, T) for r, T in zip(res[:64], motions[K - 1][:64])])
+            ms_s, ms_r, ms_i = float(np.mean(staged)), float(np.mean(refresh)), float(np.mean(ideal))
+            kept = (ms_s - ms_r) / (ms_s - ms_i) if ms_s - ms_i > 1e-9 else None
+            out[model] = {"align_launch_ms": {"staged_order": round(ms_s, 4), "refresh_from_previous_image": round(ms_r, 4), "ideal_same_image": round(ms_i, 4)},
+                          "align_launch_ms_per_image": {"staged_order": [round(x, 4) for x in staged], "refresh_from_previous_image": [round(x, 4) for x in refresh],
+                                                        "ideal_same_image": [round(x, 4) for x in ideal]},
+                          "gain_ideal_pct": round(100.0 * (ms_s - ms_i) / ms_s, 2), "gain_refresh_pct": round(100.0 * (ms_s - ms_r) / ms_s, 2),
+                          "gain_kept": round(kept, 3) if kept is not None else None,
+                          "median_rot_err_vs_truth_rad": float(np.median(errs[:, 0]))}
+        return out
     finally:
         ctx.close()
 

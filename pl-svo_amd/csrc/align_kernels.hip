@@ -910,7 +910,10 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
         };
         // (Projecting round r+1 and requesting its window BEFORE round r's arithmetic -- a second SlotA and a SlotB in flight -- was
         //  measured slower on MI355X, 15.1 -> 16.4 ms and 13.9 -> 15.5 ms with the byte records: the registers it takes cost more than
-        //  the latency it hides.  profiles/r04d_byte_records_gather_ahead_ab.log)
+        //  the latency it hides.  profiles/r04d_byte_records_gather_ahead_ab.log.  Round 6 built the same schedule with NO register parked:
+        //  everything a round prefetches staged in LDS by LDS-DMA (global_load_lds: the next round's windows as 10 dword pieces, its record
+        //  as 4 x 16 B, the 3-D points of the round after) -- parity-green and 10.5 % SLOWER, 13.93 -> 15.41 ms: seventeen DMA pieces per
+        //  round cost more to issue than the latency they hide.  tools/patches/r06_lds_dma_prefetch.patch, profiles/r06_lds_dma_prefetch_ab.log)
         SlotA a_nxt = stage_a(0);
         SlotC c_nxt = stage_c(0, a_nxt.cand);
         for (int pb = 0; pb < n_rounds_slots; pb += T) {

@@ -249,14 +249,23 @@ def render_streams(streams, device="cpu", noise_sigma=2.0, chunk=64, which=(0, 1
     return out
 
 
-def stream_motion(st, k, motion_scale=0.5):
-    """cur_from_ref of the k-th image of a MOVING sequence over stream `st`'s scene: drawn like make_align_stream draws T_true (the same
-    range, the same scale) but independently for every k -- successive images of a stream share the scene, the features and the initial
-    pose, nothing else (bench.py's moving-inputs leg: the harshest case for anything learned from the previous launch)."""
-    rng = np.random.default_rng((int(st.seed) * 1000003 + 7919 * (int(k) + 1)) & 0x7fffffff)
+def stream_motion(st, k, motion_scale=0.5, model="independent"):
+    """cur_from_ref of the k-th image of a MOVING sequence over stream `st`'s scene (bench.py's moving-inputs leg).
+    "independent": drawn like make_align_stream draws T_true (the same range, the same scale) but independently for every k --
+                   successive images of a stream share the scene, the features and the initial pose, nothing else: the harshest case
+                   for anything learned from the previous launch;
+    "smooth":      a camera on a smooth path -- one motion per stream (drawn as above), every image's motion within ~15 % of it
+                   (per-image factor 1 + 0.15 N(0,1) on the whole twist, plus 5 % of its size in a random direction): what
+                   successive inter-frame motions of a hand-held or vehicle camera look like."""
     d0 = st.plane_d / st.plane_n[2]
-    xi = np.concatenate([rng.uniform(-0.03, 0.03, 3) * d0, rng.uniform(-0.01, 0.01, 3)]) * motion_scale
-    return se3_exp(xi)
+    draw = lambda rng: np.concatenate([rng.uniform(-0.03, 0.03, 3) * d0, rng.uniform(-0.01, 0.01, 3)]) * motion_scale
+    if model == "independent":
+        return se3_exp(draw(np.random.default_rng((int(st.seed) * 1000003 + 7919 * (int(k) + 1)) & 0x7fffffff)))
+    base = draw(np.random.default_rng((int(st.seed) * 1000003 + 15485863) & 0x7fffffff))
+    rng = np.random.default_rng((int(st.seed) * 1000003 + 32452843 * (int(k) + 1)) & 0x7fffffff)
+    jitter = rng.normal(0.0, 1.0, 6)
+    size = np.concatenate([np.full(3, np.linalg.norm(base[:3])), np.full(3, np.linalg.norm(base[3:]))])
+    return se3_exp(base * (1.0 + 0.15 * rng.normal()) + 0.05 * size * jitter / np.sqrt(3.0))
 
 
 def render_views(streams, poses, device="cpu", noise_sigma=2.0, chunk=64, noise_tag=0):

@@ -127,7 +127,9 @@ def test_bench_script_dry_run(emu_lib, argv):
         lo = d["launch_order"]
         assert lo["policy"] in ("refresh", "staged") and lo["value_other_policy"] > 0
         mv = lo["moving_inputs"]
-        assert "error" not in mv and mv["align_launch_ms"]["staged_order"] > 0 and len(mv["align_launch_ms_per_image"]["ideal_same_image"]) == 2, mv
+        assert "error" not in mv, mv
+        for model in ("independent", "smooth"):
+            assert mv[model]["align_launch_ms"]["staged_order"] > 0 and len(mv[model]["align_launch_ms_per_image"]["ideal_same_image"]) == 2, mv
     if argv[0] == "--batch":     # the default workload also carries the small-batch leg
         assert d["latency"]["B1"]["frames_per_s"] > 0 and d["latency"]["B8"]["frames_per_s"] > 0, d.get("latency")
         # ... and the host-fed and resident-frame-step legs (guarded by try/except in the script: an error would only show up here)

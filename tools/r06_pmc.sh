@@ -15,8 +15,9 @@ for CFG in $CFGS; do
   CMD="python $R/bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-latency"
   for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_$C
-    /usr/bin/time -f "pmc pass config $CFG $C: %e s" timeout 900 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "align_fused|pose_opt" -d /tmp/pmc_$C -- $CMD > $O/pmc_c${CFG}_$C.log 2>&1
-    tail -1 $O/pmc_c${CFG}_$C.log
+    T0=$SECONDS
+    timeout 900 rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "align_fused|pose_opt" -d /tmp/pmc_$C -- $CMD > $O/pmc_c${CFG}_$C.log 2>&1
+    echo "pmc pass config $CFG $C: $((SECONDS - T0)) s"
     DB=$(find /tmp/pmc_$C -name "*results.db" | paste -sd, -)
     python $R/tools/rocpd_summary.py --counters "$DB" $O/pmc_c${CFG}_$C.csv "--kernel-include-regex align_fused -- python bench.py --config $CFG --steps 3 --warmup 1 --no-cpu-baseline --no-latency (MI355X, $B streams)"
   done
