@@ -122,6 +122,9 @@ constexpr float kChiBand = 1.5f;
 __host__ __device__ inline size_t align_chi_window_offset(int threads, int cap, int scap) {
   size_t o = sizeof(double) * 32 * (threads / 16) + sizeof(double) * 64 + sizeof(int) * 32;
   o += (size_t)cap * (sizeof(int2) + sizeof(float)) + (size_t)scap * sizeof(int) + ((size_t)2 * scap + 2) * sizeof(float);
+#ifdef PLSVO_EXP_PF
+  if (threads < 256) o += (size_t)cap * sizeof(int);   // s_prev: every slot's window position of the previous iteration
+#endif
   return (o + 15) & ~(size_t)15;
 }
 // the latency shapes' slot tables follow the window / the planes
@@ -363,6 +366,9 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
   float* s_abs = reinterpret_cast<float*>(s_meta + cap);                 // cap: sum |res| of the slot's 16 pixels, -1 = sample not in the image
   int* s_dead = reinterpret_cast<int*>(s_abs + cap);                     // scap: per segment, 0 = alive, k + 1 = culled at iteration k of this level
   float* s_lterm = reinterpret_cast<float*>(s_dead + scap);              // 2 * scap + 2: exact chi2 term of every line, two iterations; the two sums
+#ifdef PLSVO_EXP_PF
+  int* s_prev = reinterpret_cast<int*>(s_lterm + 2 * scap + 2);          // cap (throughput shapes): x0 | y0 << 16 of the slot's window at the previous iteration, -1 = none
+#endif
   float* s_win = reinterpret_cast<float*>(smem + align_chi_window_offset(T, cap, scap));   // 1024: two 32-slot windows of chi_terms, or the two planes themselves (chi_lds_pts)
   constexpr bool kQuad = T >= kQuadMinThreads;
   double* const s_xyz = reinterpret_cast<double*>(kQuad ? smem + align_quad_offset(T, cap, scap, b.chi_lds_pts) : smem);   // latency shapes: cap x 3, every slot's 3-D point (ref frame)
@@ -452,6 +458,9 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
 
     if (tid == 0) { s_ctl[0] = 0; s_ctl[2] = 0; s_ctl[5] = 0; s_ctl[7] = 0; s_ctl[8] = 0; s_pose[27] = 0.0; }
     for (int p = tid; p < n_slots; p += T) s_meta[p] = make_int2(SLOT_HOLE, 0);
+#ifdef PLSVO_EXP_PF
+    if constexpr (!kQuad) { for (int p = tid; p < n_slots; p += T) s_prev[p] = -1; }
+#endif
     block_sync<T>();
     TICKS(1);
 
@@ -845,6 +854,9 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
         // before round r's arithmetic.  (Rounds 1-3 of this build gave a slot to a lane PAIR: per-slot work -- projection, Jacobian,
         // line weights, half of the expansion -- was issued twice per slot, a wave-round covered 32 slots and a frame kept 64 slots
         // in flight per SIMD at two waves of 249 VGPRs; a lane per slot issues that work once and keeps 128 slots in flight.)
+#ifdef PLSVO_EXP_PF
+        int pb_cur = 0;
+#endif
         struct SlotA { int2 meta; bool cand; double X, Y, Z; };
         auto stage_a = [&](int pb_) -> SlotA {
           SlotA f;
@@ -889,6 +901,9 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
           if (g.live) {
             const int ui = (int)floorf(g.u), vi = (int)floorf(g.v);
             const int x0 = ui - 2, y0 = vi - 2;
+#ifdef PLSVO_EXP_PF
+            if constexpr (kTiled) s_prev[pb_cur + tid] = x0 | (y0 << 16);
+#endif
             if constexpr (kTiled) {
               const int ca = tiled_col_offset(x0 & ~3), cb = tiled_col_offset((x0 & ~3) + 4);
 #pragma unroll
@@ -916,12 +931,37 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
         //  round cost more to issue than the latency they hide.  tools/patches/r06_lds_dma_prefetch.patch, profiles/r06_lds_dma_prefetch_ab.log)
         SlotA a_nxt = stage_a(0);
         SlotC c_nxt = stage_c(0, a_nxt.cand);
+#ifdef PLSVO_EXP_PF
+        uint32_t pf_sink = 0u;               // destination of the prefetch loads: never read, kept allocated across the rounds (a late return must not land in a register that has been handed to something else)
+#endif
         for (int pb = 0; pb < n_rounds_slots; pb += T) {
           const int p = pb + tid;
           const SlotA sa = a_nxt;
           const SlotC sc = c_nxt;
+#ifdef PLSVO_EXP_PF
+          pb_cur = pb;
+#endif
           const SlotB sb = stage_b(sa);
           a_nxt = stage_a(pb + T);           // (slots beyond the table come back as holes: no loads)
+#ifdef PLSVO_EXP_PF
+          // L2 PREFETCH of the NEXT round's windows, from where they were at the PREVIOUS iteration (a Gauss-Newton step moves a window by
+          // a pixel or less): the lines holding two opposite corners of the old window are asked for now, a round before their real
+          // use, into a register nobody reads -- no projection, no parked data, one LDS word per slot.
+          if constexpr (kTiled) {
+            const int pn = pb + T + tid;
+            int pv = -1;
+            if (pn < n_rounds_slots) pv = s_prev[pn];
+            if (pv >= 0) {
+              const int x0 = pv & 0xffff, y0 = pv >> 16;
+              const int o00 = tiled_row_offset(pitch, y0) + tiled_col_offset(x0 & ~3);
+              const int o11 = tiled_row_offset(pitch, y0 + 4) + tiled_col_offset((x0 & ~3) + 4);
+#ifndef PLSVO_WAVE_EMU
+              asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(o00), "s"(cur_img));
+              asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(o11), "s"(cur_img));
+#endif
+            }
+          }
+#endif
           const bool next_cand = a_nxt.cand;
           const int2 meta = sa.meta;
           const bool hole = meta.x == SLOT_HOLE;
@@ -995,9 +1035,15 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
               }
             };
             float ra[5], rb[5];
+#ifdef PLSVO_EXP_HOIST
+            RecordRows rec;
+            rec.start(sc.q);                          // (reference-patch rows 0, 1 from the record -- registers only -- BEFORE the first use of the window just asked for)
+            unpack5(wlo[0], whi[0], wsh[0], ra);
+#else
             unpack5(wlo[0], whi[0], wsh[0], ra);
             RecordRows rec;
             rec.start(sc.q);
+#endif
             auto patch_row = [&](auto RI) {
               constexpr int r = decltype(RI)::value;
               float* const top = (r & 1) ? rb : ra;

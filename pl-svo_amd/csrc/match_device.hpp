@@ -101,8 +101,10 @@ __device__ __forceinline__ int best_search_level(const double* A, int max_level)
   return search_level;
 }
 
-// the source window of a warp staged in LDS (match_direct_kernel): SRC_ROWS rows of SRC_WORDS dwords per lane, word-major / lane-minor
-constexpr int SRC_ROWS = 14;
+// the source window of a warp staged in LDS (match_direct_kernel): SRC_ROWS rows of SRC_WORDS dwords per lane, word-major / lane-minor, filled
+// once per GROUP of SRC_GROUP rows of the 10x10 patch
+constexpr int SRC_GROUP = 2;
+constexpr int SRC_ROWS = 6;
 constexpr int SRC_WORDS = 5;
 #define SRCW(src, row, w) (src)[((row) * SRC_WORDS + (w)) * MT]
 
@@ -111,10 +113,15 @@ constexpr int SRC_WORDS = 5;
 //
 // `src` (optional): SRC_ROWS x SRC_WORDS dwords of LDS per lane.  The reference reads four single bytes of the keyframe image per warped
 // pixel (vk::interpolateMat_8u: 400 scattered byte reads per candidate, every one a line the CU's 32 KB L1 has long evicted when 64 lanes
-// warp 64 different patches -- the kernel waits on them, it does not compute).  The warp is affine, so the pixels it touches lie inside the
-// box of its four corners: when that box is at most SRC_ROWS x 4 SRC_WORDS - 1 bytes (every warp that does not zoom by more than ~1.6: the
-// rule, not the exception) its rows are fetched ONCE as aligned dwords -- 14 wide requests instead of 200 two-byte ones -- parked in LDS
-// lane-interleaved, and the same float expressions read their four taps from there.  Same values, same order: bit-identical results.
+// warp 64 different patches -- the kernel waits on them, it does not compute).  The warp is affine, so the pixels a block of patch rows
+// touches lie inside the box of the block's four corners (each corner expression is monotone in both grid coordinates, rounding
+// included): the patch is warped in groups of SRC_GROUP rows, and when a group's box is at most SRC_ROWS x 4 SRC_WORDS - 1 bytes (every
+// warp that neither zooms by more than ~1.6 nor turns by more than ~20 degrees: the rule, not the exception) its rows are fetched ONCE as
+// aligned dwords, parked in LDS lane-interleaved, and the same float expressions read their four taps from there; a group whose box is
+// larger reads its taps from the image.  Same values, same order: bit-identical results.
+// (Round 5 staged the box of the WHOLE patch, 14 rows: 280 B of LDS per lane capped the kernel at six one-wave workgroups per CU, and a
+//  candidate is a chain of dependent float additions -- the reference's sequential sums -- that wants many waves per SIMD, not few.  Five
+//  groups of <= 6 rows re-read ~40 % more image rows from L1 / L2 and take 120 B per lane: ten workgroups per CU.)
 __device__ __forceinline__ bool warp_affine_lds(const double* A, const uint8_t* img_ref, int rcols, int rrows, double rpx0, double rpx1,
                                                 int level, int search_level, uint32_t* my, uint32_t* src = nullptr) {
   const double det = A[0] * A[3] - A[2] * A[1];
@@ -124,73 +131,75 @@ __device__ __forceinline__ bool warp_affine_lds(const double* A, const uint8_t* 
   if (a00 != a00) return false;
   const float rx = (float)rpx0 / (float)(1 << level), ry = (float)rpx1 / (float)(1 << level);
   const float fscale = (float)(1 << search_level);
-  bool staged = false;
-  int cbase = 0, rmin = 0;
-  if (src) {
-    // the four corners of the 10x10 grid, with the very expressions of the pixel loop (each is monotone in ppx and in ppy, rounding
-    // included, so every pixel of the grid lies inside the corners' box)
-    float lo0 = 3.0e38f, hi0 = -3.0e38f, lo1 = 3.0e38f, hi1 = -3.0e38f;
-    bool inside = true;
+  const uint8_t* const src_b = reinterpret_cast<const uint8_t*>(src);
+  static_assert(PB_ROWS % SRC_GROUP == 0, "the patch rows are warped in whole groups");
+  for (int y0 = 0; y0 < PB_ROWS; y0 += SRC_GROUP) {
+    bool staged = false;
+    int cbase = 0, rmin = 0;
+    if (src) {
+      // the four corners of the group's 10 x SRC_GROUP grid, with the very expressions of the pixel loop
+      float lo0 = 3.0e38f, hi0 = -3.0e38f, lo1 = 3.0e38f, hi1 = -3.0e38f;
+      bool inside = true;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float ppx = (float)((k & 1) ? 4 : -5), ppy = (float)((k & 2) ? 4 : -5);
-      ppx *= fscale; ppy *= fscale;
-      const float px0 = (a00 * ppx + a01 * ppy) + rx;
-      const float px1 = (a10 * ppx + a11 * ppy) + ry;
-      inside = inside && !(px0 < 0 || px1 < 0 || px0 >= rcols - 1 || px1 >= rrows - 1) && px0 == px0 && px1 == px1;
-      lo0 = fminf(lo0, px0); hi0 = fmaxf(hi0, px0); lo1 = fminf(lo1, px1); hi1 = fmaxf(hi1, px1);
-    }
-    if (inside) {
-      const int cmin = (int)floorf(lo0), cmax = (int)floorf(hi0) + 1, rmax = (int)floorf(hi1) + 1;
-      rmin = (int)floorf(lo1);
-      cbase = cmin & ~3;
-      staged = (cmax - cbase) <= 4 * SRC_WORDS - 1 && (rmax - rmin) <= SRC_ROWS - 1;
-      if (staged) {
-        const int n_rows = rmax - rmin + 1;
+      for (int k = 0; k < 4; ++k) {
+        float ppx = (float)((k & 1) ? 4 : -5), ppy = (float)(((k & 2) ? y0 + SRC_GROUP - 1 : y0) - 5);
+        ppx *= fscale; ppy *= fscale;
+        const float px0 = (a00 * ppx + a01 * ppy) + rx;
+        const float px1 = (a10 * ppx + a11 * ppy) + ry;
+        inside = inside && !(px0 < 0 || px1 < 0 || px0 >= rcols - 1 || px1 >= rrows - 1) && px0 == px0 && px1 == px1;
+        lo0 = fminf(lo0, px0); hi0 = fmaxf(hi0, px0); lo1 = fminf(lo1, px1); hi1 = fmaxf(hi1, px1);
+      }
+      if (inside) {
+        const int cmin = (int)floorf(lo0), cmax = (int)floorf(hi0) + 1, rmax = (int)floorf(hi1) + 1;
+        rmin = (int)floorf(lo1);
+        cbase = cmin & ~3;
+        staged = (cmax - cbase) <= 4 * SRC_WORDS - 1 && (rmax - rmin) <= SRC_ROWS - 1;
+        if (staged) {
+          const int n_rows = rmax - rmin + 1;
 #pragma unroll 2
-        for (int r = 0; r < SRC_ROWS; ++r) {
-          if (r < n_rows) {   // (rows rmin .. rmax <= rrows - 1: inside the level; the dword reads run <= 27 bytes past a row's end: the level's slack)
-            const long off = (long)(rmin + r) * rcols + cbase;
-            const uint32_t* p = reinterpret_cast<const uint32_t*>(img_ref + (off & ~3l));
-            const uint32_t sh = (uint32_t)(off & 3);
-            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4], d5 = p[5];
-            SRCW(src, r, 0) = __builtin_amdgcn_alignbyte(d1, d0, sh); SRCW(src, r, 1) = __builtin_amdgcn_alignbyte(d2, d1, sh);
-            SRCW(src, r, 2) = __builtin_amdgcn_alignbyte(d3, d2, sh); SRCW(src, r, 3) = __builtin_amdgcn_alignbyte(d4, d3, sh);
-            SRCW(src, r, 4) = __builtin_amdgcn_alignbyte(d5, d4, sh);
+          for (int r = 0; r < SRC_ROWS; ++r) {
+            if (r < n_rows) {   // (rows rmin .. rmax <= rrows - 1: inside the level; the dword reads run <= 27 bytes past a row's end: the level's slack)
+              const long off = (long)(rmin + r) * rcols + cbase;
+              const uint32_t* p = reinterpret_cast<const uint32_t*>(img_ref + (off & ~3l));
+              const uint32_t sh = (uint32_t)(off & 3);
+              const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4], d5 = p[5];
+              SRCW(src, r, 0) = __builtin_amdgcn_alignbyte(d1, d0, sh); SRCW(src, r, 1) = __builtin_amdgcn_alignbyte(d2, d1, sh);
+              SRCW(src, r, 2) = __builtin_amdgcn_alignbyte(d3, d2, sh); SRCW(src, r, 3) = __builtin_amdgcn_alignbyte(d4, d3, sh);
+              SRCW(src, r, 4) = __builtin_amdgcn_alignbyte(d5, d4, sh);
+            }
           }
         }
       }
     }
-  }
-  const uint8_t* const src_b = reinterpret_cast<const uint8_t*>(src);
-  auto tap = [&](int lr, int lc) -> float {   // byte (row rmin + lr, column cbase + lc) of the staged window
-    return (float)src_b[((lr * SRC_WORDS + (lc >> 2)) * MT) * 4 + (lc & 3)];
-  };
-  for (int y = 0; y < PB_ROWS; ++y) {
-    uint32_t w[PB_WORDS] = { 0u, 0u, 0u };
+    auto tap = [&](int lr, int lc) -> float {   // byte (row rmin + lr, column cbase + lc) of the staged window
+      return (float)src_b[((lr * SRC_WORDS + (lc >> 2)) * MT) * 4 + (lc & 3)];
+    };
+    for (int y = y0; y < y0 + SRC_GROUP; ++y) {
+      uint32_t w[PB_WORDS] = { 0u, 0u, 0u };
 #pragma unroll
-    for (int x = 0; x < PB_STEP; ++x) {
-      float ppx = (float)(x - 5), ppy = (float)(y - 5);
-      ppx *= fscale; ppy *= fscale;
-      const float px0 = (a00 * ppx + a01 * ppy) + rx;
-      const float px1 = (a10 * ppx + a11 * ppy) + ry;
-      uint32_t val = 0u;
-      if (staged) {
-        // [ext] vk::interpolateMat_8u, its four taps read from the staged window (every pixel is inside the image: the corners are)
-        const int xi = (int)floorf(px0), yi = (int)floorf(px1);
-        const float subpix_x = px0 - xi, subpix_y = px1 - yi;
-        const float w00 = (1.0f - subpix_x) * (1.0f - subpix_y);
-        const float w01 = (1.0f - subpix_x) * subpix_y;
-        const float w10 = subpix_x * (1.0f - subpix_y);
-        const float w11 = 1.0f - w00 - w01 - w10;
-        const int lr = yi - rmin, lc = xi - cbase;
-        val = (uint32_t)(uint8_t)(w00 * tap(lr, lc) + w01 * tap(lr + 1, lc) + w10 * tap(lr, lc + 1) + w11 * tap(lr + 1, lc + 1));
-      } else if (!(px0 < 0 || px1 < 0 || px0 >= rcols - 1 || px1 >= rrows - 1)) {
-        val = (uint32_t)(uint8_t)interpolate_mat_8u(img_ref, rcols, px0, px1);
+      for (int x = 0; x < PB_STEP; ++x) {
+        float ppx = (float)(x - 5), ppy = (float)(y - 5);
+        ppx *= fscale; ppy *= fscale;
+        const float px0 = (a00 * ppx + a01 * ppy) + rx;
+        const float px1 = (a10 * ppx + a11 * ppy) + ry;
+        uint32_t val = 0u;
+        if (staged) {
+          // [ext] vk::interpolateMat_8u, its four taps read from the staged window (every pixel is inside the image: the corners are)
+          const int xi = (int)floorf(px0), yi = (int)floorf(px1);
+          const float subpix_x = px0 - xi, subpix_y = px1 - yi;
+          const float w00 = (1.0f - subpix_x) * (1.0f - subpix_y);
+          const float w01 = (1.0f - subpix_x) * subpix_y;
+          const float w10 = subpix_x * (1.0f - subpix_y);
+          const float w11 = 1.0f - w00 - w01 - w10;
+          const int lr = yi - rmin, lc = xi - cbase;
+          val = (uint32_t)(uint8_t)(w00 * tap(lr, lc) + w01 * tap(lr + 1, lc) + w10 * tap(lr, lc + 1) + w11 * tap(lr + 1, lc + 1));
+        } else if (!(px0 < 0 || px1 < 0 || px0 >= rcols - 1 || px1 >= rrows - 1)) {
+          val = (uint32_t)(uint8_t)interpolate_mat_8u(img_ref, rcols, px0, px1);
+        }
+        w[x >> 2] |= val << (8 * (x & 3));
       }
-      w[x >> 2] |= val << (8 * (x & 3));
+      PBW(my, y, 0) = w[0]; PBW(my, y, 1) = w[1]; PBW(my, y, 2) = w[2];
     }
-    PBW(my, y, 0) = w[0]; PBW(my, y, 1) = w[1]; PBW(my, y, 2) = w[2];
   }
   return true;   // every lane reads back only its own words: no barrier needed
 }
