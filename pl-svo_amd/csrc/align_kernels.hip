@@ -73,12 +73,22 @@ template <bool TILED>
 __device__ __forceinline__ uint2 load_row8_raw(const uint8_t* img, int pitch, int x, int y) {
   uint32_t d0, d1, d2, sh;
   if constexpr (TILED) {
+#ifdef PLSVO_STRIP_MIRROR
+    // column-strip mirror (`pitch` = level width): the eight column dwords of the band holding row y, byte y & 3 of each
+    const uint32_t* const cw = reinterpret_cast<const uint32_t*>(img + strip_offset(pitch, x, y & ~3));
+    const uint32_t bsh = 8u * (uint32_t)(y & 3);
+    uint32_t lo = 0u, hi = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { lo |= ((cw[k] >> bsh) & 0xffu) << (8 * k); hi |= ((cw[4 + k] >> bsh) & 0xffu) << (8 * k); }
+    return make_uint2(lo, hi);
+#else
     const int a = x & ~3;
     sh = (uint32_t)(x & 3);
     const int row = tiled_row_offset(pitch, y);
     d0 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a)));
     d1 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a + 4)));
     d2 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a + 8)));
+#endif
   } else {
     const int off = y * pitch + x, a = off & ~3;
     sh = (uint32_t)(off & 3);
@@ -122,9 +132,6 @@ constexpr float kChiBand = 1.5f;
 __host__ __device__ inline size_t align_chi_window_offset(int threads, int cap, int scap) {
   size_t o = sizeof(double) * 32 * (threads / 16) + sizeof(double) * 64 + sizeof(int) * 32;
   o += (size_t)cap * (sizeof(int2) + sizeof(float)) + (size_t)scap * sizeof(int) + ((size_t)2 * scap + 2) * sizeof(float);
-#ifdef PLSVO_EXP_PF
-  if (threads < 256) o += (size_t)cap * sizeof(int);   // s_prev: every slot's window position of the previous iteration
-#endif
   return (o + 15) & ~(size_t)15;
 }
 // the latency shapes' slot tables follow the window / the planes
@@ -366,9 +373,6 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
   float* s_abs = reinterpret_cast<float*>(s_meta + cap);                 // cap: sum |res| of the slot's 16 pixels, -1 = sample not in the image
   int* s_dead = reinterpret_cast<int*>(s_abs + cap);                     // scap: per segment, 0 = alive, k + 1 = culled at iteration k of this level
   float* s_lterm = reinterpret_cast<float*>(s_dead + scap);              // 2 * scap + 2: exact chi2 term of every line, two iterations; the two sums
-#ifdef PLSVO_EXP_PF
-  int* s_prev = reinterpret_cast<int*>(s_lterm + 2 * scap + 2);          // cap (throughput shapes): x0 | y0 << 16 of the slot's window at the previous iteration, -1 = none
-#endif
   float* s_win = reinterpret_cast<float*>(smem + align_chi_window_offset(T, cap, scap));   // 1024: two 32-slot windows of chi_terms, or the two planes themselves (chi_lds_pts)
   constexpr bool kQuad = T >= kQuadMinThreads;
   double* const s_xyz = reinterpret_cast<double*>(kQuad ? smem + align_quad_offset(T, cap, scap, b.chi_lds_pts) : smem);   // latency shapes: cap x 3, every slot's 3-D point (ref frame)
@@ -444,7 +448,11 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
     const unsigned long long pyr_slot = kTiled ? b.pyr.tslot_bytes : b.pyr.slot_bytes;
     const uint8_t* ref_img = pyr_base + (size_t)job.ref_slot * pyr_slot + lvl_off;
     const uint8_t* cur_img = pyr_base + (size_t)job.cur_slot * pyr_slot + lvl_off;
+#ifdef PLSVO_STRIP_MIRROR
+    const int pitch = W;                            // the strip mirror is addressed by the level width
+#else
     const int pitch = kTiled ? (W + 15) >> 4 : W;   // tiles per row / bytes per row
+#endif
     int n_slots = 0; bool long_lines = false;
 #pragma unroll
     for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) if (l == level) { n_slots = job.n_slots[l]; long_lines = ((job.long_mask >> l) & 1) != 0; }
@@ -458,9 +466,6 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
 
     if (tid == 0) { s_ctl[0] = 0; s_ctl[2] = 0; s_ctl[5] = 0; s_ctl[7] = 0; s_ctl[8] = 0; s_pose[27] = 0.0; }
     for (int p = tid; p < n_slots; p += T) s_meta[p] = make_int2(SLOT_HOLE, 0);
-#ifdef PLSVO_EXP_PF
-    if constexpr (!kQuad) { for (int p = tid; p < n_slots; p += T) s_prev[p] = -1; }
-#endif
     block_sync<T>();
     TICKS(1);
 
@@ -854,9 +859,6 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
         // before round r's arithmetic.  (Rounds 1-3 of this build gave a slot to a lane PAIR: per-slot work -- projection, Jacobian,
         // line weights, half of the expansion -- was issued twice per slot, a wave-round covered 32 slots and a frame kept 64 slots
         // in flight per SIMD at two waves of 249 VGPRs; a lane per slot issues that work once and keeps 128 slots in flight.)
-#ifdef PLSVO_EXP_PF
-        int pb_cur = 0;
-#endif
         struct SlotA { int2 meta; bool cand; double X, Y, Z; };
         auto stage_a = [&](int pb_) -> SlotA {
           SlotA f;
@@ -901,10 +903,17 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
           if (g.live) {
             const int ui = (int)floorf(g.u), vi = (int)floorf(g.v);
             const int x0 = ui - 2, y0 = vi - 2;
-#ifdef PLSVO_EXP_PF
-            if constexpr (kTiled) s_prev[pb_cur + tid] = x0 | (y0 << 16);
-#endif
             if constexpr (kTiled) {
+#ifdef PLSVO_STRIP_MIRROR
+              // columns x0 .. x0 + 4 of the two bands holding rows y0 .. y0 + 4: wlo[c] / whi[c] = the column dword of the upper / lower band
+              const int q0 = strip_offset(pitch, x0, y0 & ~3), q1 = q0 + (pitch << 2);
+              const uint4 l4 = *reinterpret_cast<const uint4*>(cur_img + q0);
+              const uint4 h4 = *reinterpret_cast<const uint4*>(cur_img + q1);
+              g.wlo[0] = l4.x; g.wlo[1] = l4.y; g.wlo[2] = l4.z; g.wlo[3] = l4.w; g.wlo[4] = *reinterpret_cast<const uint32_t*>(cur_img + q0 + 16);
+              g.whi[0] = h4.x; g.whi[1] = h4.y; g.whi[2] = h4.z; g.whi[3] = h4.w; g.whi[4] = *reinterpret_cast<const uint32_t*>(cur_img + q1 + 16);
+#pragma unroll
+              for (int r = 0; r < 5; ++r) g.wsh[r] = y0 & 3;
+#else
               const int ca = tiled_col_offset(x0 & ~3), cb = tiled_col_offset((x0 & ~3) + 4);
 #pragma unroll
               for (int r = 0; r < 5; ++r) {
@@ -912,6 +921,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
                 g.wsh[r] = x0 & 3;
                 g.wlo[r] = *reinterpret_cast<const uint32_t*>(cur_img + (q + ca)); g.whi[r] = *reinterpret_cast<const uint32_t*>(cur_img + (q + cb));
               }
+#endif
             } else {
 #pragma unroll
               for (int r = 0; r < 5; ++r) {
@@ -931,37 +941,12 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
         //  round cost more to issue than the latency they hide.  tools/patches/r06_lds_dma_prefetch.patch, profiles/r06_lds_dma_prefetch_ab.log)
         SlotA a_nxt = stage_a(0);
         SlotC c_nxt = stage_c(0, a_nxt.cand);
-#ifdef PLSVO_EXP_PF
-        uint32_t pf_sink = 0u;               // destination of the prefetch loads: never read, kept allocated across the rounds (a late return must not land in a register that has been handed to something else)
-#endif
         for (int pb = 0; pb < n_rounds_slots; pb += T) {
           const int p = pb + tid;
           const SlotA sa = a_nxt;
           const SlotC sc = c_nxt;
-#ifdef PLSVO_EXP_PF
-          pb_cur = pb;
-#endif
           const SlotB sb = stage_b(sa);
           a_nxt = stage_a(pb + T);           // (slots beyond the table come back as holes: no loads)
-#ifdef PLSVO_EXP_PF
-          // L2 PREFETCH of the NEXT round's windows, from where they were at the PREVIOUS iteration (a Gauss-Newton step moves a window by
-          // a pixel or less): the lines holding two opposite corners of the old window are asked for now, a round before their real
-          // use, into a register nobody reads -- no projection, no parked data, one LDS word per slot.
-          if constexpr (kTiled) {
-            const int pn = pb + T + tid;
-            int pv = -1;
-            if (pn < n_rounds_slots) pv = s_prev[pn];
-            if (pv >= 0) {
-              const int x0 = pv & 0xffff, y0 = pv >> 16;
-              const int o00 = tiled_row_offset(pitch, y0) + tiled_col_offset(x0 & ~3);
-              const int o11 = tiled_row_offset(pitch, y0 + 4) + tiled_col_offset((x0 & ~3) + 4);
-#ifndef PLSVO_WAVE_EMU
-              asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(o00), "s"(cur_img));
-              asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(o11), "s"(cur_img));
-#endif
-            }
-          }
-#endif
           const bool next_cand = a_nxt.cand;
           const int2 meta = sa.meta;
           const bool hole = meta.x == SLOT_HOLE;
@@ -1035,20 +1020,38 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
               }
             };
             float ra[5], rb[5];
-#ifdef PLSVO_EXP_HOIST
-            RecordRows rec;
-            rec.start(sc.q);                          // (reference-patch rows 0, 1 from the record -- registers only -- BEFORE the first use of the window just asked for)
-            unpack5(wlo[0], whi[0], wsh[0], ra);
+#ifdef PLSVO_STRIP_MIRROR
+            // column-strip mirror (one wave per frame): cw[c] = rows y0 .. y0 + 3 of column c, c4[c] = row y0 + 4; row r of the window is
+            // byte r of every cw (a static byte select)
+            uint32_t cw[5], c4[5];
+            if constexpr (kTiled) {
+#pragma unroll
+              for (int c = 0; c < 5; ++c) { cw[c] = __builtin_amdgcn_alignbyte(whi[c], wlo[c], (uint32_t)wsh[0]); c4[c] = (whi[c] >> (8 * wsh[0])) & 0xffu; }
+            }
+            auto window_row = [&](auto RI, float* o) {
+              constexpr int r = decltype(RI)::value;
+              if constexpr (kTiled) {
+#pragma unroll
+                for (int c = 0; c < 5; ++c) o[c] = (r < 4) ? (float)((cw[c] >> (8 * (r & 3))) & 0xffu) : (float)c4[c];
+              } else {
+                unpack5(wlo[r], whi[r], wsh[r], o);
+              }
+            };
+            window_row(std::integral_constant<int, 0>{}, ra);
 #else
             unpack5(wlo[0], whi[0], wsh[0], ra);
+#endif
             RecordRows rec;
             rec.start(sc.q);
-#endif
             auto patch_row = [&](auto RI) {
               constexpr int r = decltype(RI)::value;
               float* const top = (r & 1) ? rb : ra;
               float* const bot = (r & 1) ? ra : rb;
+#ifdef PLSVO_STRIP_MIRROR
+              window_row(std::integral_constant<int, r + 1>{}, bot);
+#else
               unpack5(wlo[r + 1], whi[r + 1], wsh[r + 1], bot);
+#endif
               float4 chi_t = make_float4(0.f, 0.f, 0.f, 0.f);
               float4 r4, x4, y4;
               rec.template row<r>(r4, x4, y4);

@@ -539,22 +539,28 @@ static int upload(plsvo_ctx* c, DevBuf& buf, const std::vector<T>& v) {
   return PLSVO_OK;
 }
 
-// Static patch-slot layout of one job at one level (align_kernels.hip header): points own slots [0, n_pts); segments follow
-// from the next multiple of 32 in feature order, and a segment with N <= 32 samples never straddles a multiple of 32, so that
-// all its samples sit in one wave-round of the kernel.  Segments without a landmark on entry, or whose end points fail the
-// 3-pixel border test of the level (src/sparse_img_align.cpp:299-301), get no slots (code -1).  Host-only arithmetic.
-// seg_align: the segments' first slot is a multiple of it (32: a wave-round of the throughput shapes; 64: small batches, whose point and
-// segment slots may go to two workgroups -- a multiple of 32 as well, so every launch shape reads either layout)
+// Static patch-slot layout of one job at one level (align_kernels.hip header).  Points own slots [0, n_pts).  The kernel works through the
+// slots in WAVE-ROUNDS of 64 (slots [64 r, 64 r + 64) go to the 64 lanes of one wave) and weights a line from the residual sums its samples
+// left in LDS behind a wave-level fence, so all samples of a segment with N <= 64 must sit inside ONE round; longer segments make the
+// level a two-pass level (workgroup barrier between the passes).  Every round costs the same whether its lanes hold patches or holes, so
+// the segments are PACKED into the rounds: first-fit in decreasing N (ties in feature order), starting in the round the points leave
+// partly empty.  (Rounds 1-5 placed the segments in feature order from the next multiple of 32 behind the points and kept them from
+// straddling multiples of 32 -- a left-over of the lane-pair kernel: 6.0 / 6.7 / 8.75 rounds per pass at levels 3 / 2 / 1 of BASELINE
+// configs[1] where the patches fill 5 / 6 / 8.)  Segments without a landmark on entry, or whose end points fail the 3-pixel border test of
+// the level (src/sparse_img_align.cpp:299-301), get no slots (code -1).  Host-only arithmetic; no result depends on where a segment sits.
+// seg_align: 64 = small batches, whose point and segment slots may go to two workgroups (the segments start at a multiple of 64);
+//            otherwise the segments start right behind the points.
 static int slot_layout(const plsvo_align_in* in, int level, int seg_align, int32_t* seg_code, int32_t* n_slots, int32_t* long_lines, long long* n_patches) {
   if (!in || level < 0 || level >= PLSVO_MAX_LEVELS || in->n_pts < 0 || in->n_seg < 0 || (in->n_seg > 0 && !seg_code)) return PLSVO_E_INVALID;
   const plsvo_align_in& a = *in;
-  long long cur = a.n_seg > 0 ? (((long long)a.n_pts + seg_align - 1) & ~(long long)(seg_align - 1)) : (long long)a.n_pts;
-  long long used = a.n_pts, n_real = a.n_pts;
+  constexpr int kRound = 64;
+  long long n_real = a.n_pts;
   int any_long = 0;
   const double scale = 1.0 / (double)(1 << level);
   const int cw = a.cam.width / (1 << level), ch = a.cam.height / (1 << level);
+  std::vector<int> shorts, longs;     // segments with slots: N <= 64 / longer
   for (int s = 0; s < a.n_seg; ++s) {
-    int code = -1;
+    seg_code[s] = -1;
     const bool alive_on_entry = a.seg_alive_in ? (a.seg_alive_in[s] != 0) : true;
     const double sx = a.seg_spx[2 * s], sy = a.seg_spx[2 * s + 1], ex = a.seg_epx[2 * s], ey = a.seg_epx[2 * s + 1];
     const int isx = (int)(sx * scale), isy = (int)(sy * scale), iex = (int)(ex * scale), iey = (int)(ey * scale);
@@ -562,13 +568,36 @@ static int slot_layout(const plsvo_align_in* in, int level, int seg_align, int32
     if (alive_on_entry && vis) {
       const int N = seg_num_samples(sx, sy, ex, ey, a.seg_len[s], level);
       if (N > 2047) return PLSVO_E_CAPACITY;
-      if (N <= 32) { if ((cur & 31) + N > 32) cur = (cur + 31) & ~31LL; }
-      else any_long = 1;
-      if (cur + N > (1 << 20) - 8) return PLSVO_E_CAPACITY;
-      code = (int)cur | (N << 20);
-      cur += N; used = cur; n_real += N;
+      seg_code[s] = N << 20;             // (the first slot is filled in below)
+      (N <= kRound ? shorts : longs).push_back(s);
+      n_real += N;
     }
-    seg_code[s] = code;
+  }
+  const long long seg0 = (seg_align == 64 && a.n_seg > 0) ? (((long long)a.n_pts + 63) & ~63LL) : (long long)a.n_pts;   // first slot a segment may take
+  long long used = a.n_pts;
+  if (!shorts.empty() || !longs.empty()) {
+    std::stable_sort(shorts.begin(), shorts.end(), [&](int x, int y) { return (seg_code[x] >> 20) > (seg_code[y] >> 20); });
+    const long long r0 = seg0 / kRound;                                      // the round the first segment may share with the last points
+    std::vector<int> fill(1, (int)(seg0 - r0 * kRound));                     // slots taken in round r0 + k
+    for (int s : shorts) {
+      const int N = seg_code[s] >> 20;
+      size_t k = 0;
+      while (k < fill.size() && fill[k] + N > kRound) ++k;
+      if (k == fill.size()) fill.push_back(0);
+      const long long first = (r0 + (long long)k) * kRound + fill[k];
+      if (first + N > (1 << 20) - 8) return PLSVO_E_CAPACITY;
+      seg_code[s] |= (int)first;
+      fill[k] += N;
+      used = std::max(used, first + N);
+    }
+    long long cur = shorts.empty() ? ((seg0 + kRound - 1) / kRound) * kRound : (r0 + (long long)fill.size()) * kRound;   // behind the packed rounds
+    for (int s : longs) {                                                    // two-pass level: any contiguous run of slots will do
+      const int N = seg_code[s] >> 20;
+      if (cur + N > (1 << 20) - 8) return PLSVO_E_CAPACITY;
+      seg_code[s] |= (int)cur;
+      cur += N; used = cur;
+      any_long = 1;
+    }
   }
   if (n_slots) *n_slots = (int32_t)used;
   if (long_lines) *long_lines = any_long;

@@ -322,13 +322,14 @@ def test_device_trace_against_scipy(P, ob, gpu_ctx):
 
 
 def test_sparse_align_long_lines_two_pass_levels(P, ob, gpu_ctx):
-    """segments with more than 32 samples at a level (a 600..1100 px line on a 1280x720 frame) do not fit one wave-round: the
-    kernel runs such a level in two passes (residual sums, workgroup barrier, expansion) -- same results, same parity bar"""
-    st, ref, cur, job = Hh.make_case(ob, 41, 1280, 720, 60, 14, 3, 1, 0, seg_len_range=(600.0, 1100.0))
+    """segments with more than 64 samples at a level (a 1150..1800 px line on a 1920x1080 frame: N = length / 16..23) do not fit one
+    wave-round: the kernel runs such a level in two passes (residual sums, workgroup barrier, expansion) -- same results, same parity bar"""
+    st, ref, cur, job = Hh.make_case(ob, 41, 1920, 1080, 60, 14, 3, 1, 0, seg_len_range=(1150.0, 1800.0))
     n0 = [ob.setup_sampling(s_, e_, L)[0] for s_, e_, L in zip(st.seg_spx, st.seg_epx, st.seg_len)]   # samples at level 0
-    assert max(n0) > 32, "the case must contain a line with more than 32 samples at level 0"
+    assert max(n0) > 64 and min(n0) <= 128, "the case must contain a line with more than 64 samples at level 0 (two-pass) and a level without one"
+    assert P.capi.align_slot_layout(job, 0)[3] and not P.capi.align_slot_layout(job, 1)[3]
     res_o, log_o = ob.sparse_align(job, ref, cur, max_log=200)
-    gpu_ctx.config_pyramids(2, 1280, 720, 3)
+    gpu_ctx.config_pyramids(2, 1920, 1080, 3)
     gpu_ctx.upload_pyramid(0, ref)
     gpu_ctx.upload_pyramid(1, cur)
     gpu_ctx.align_set_trace(200)
