@@ -197,11 +197,13 @@ int plsvo_align_fetch(plsvo_ctx* ctx, int n, plsvo_align_out* out);
 
 /* per-iteration trace: enable before plsvo_align_run; max_records_per_job bounds the trace */
 /* Host-only helper (no device needed): the static patch-slot layout plsvo_align_stage gives one job at one pyramid level.
- * Points own slots [0, n_pts); segments follow from the next multiple of 32 in feature order; a segment with N <= 32 samples
- * (N = 1 + (N0-1)/2^level, LineFeat::setupSampling src/feature.cpp:160-173, src/sparse_img_align.cpp:320) never straddles a
- * multiple of 32.  seg_code[s] = first slot | N << 20, or -1 for a segment without landmark on entry or with an end point inside
- * the 3-pixel border of the level (src/sparse_img_align.cpp:299-301).  n_slots: slots in use; long_lines: some N > 32;
- * n_patches: points + samples (holes not counted).  Returns PLSVO_E_CAPACITY for N > 2047 or more than 2^20 slots. */
+ * Points own slots [0, n_pts); the segments are packed behind them into the kernel's wave-rounds of 64 slots, first-fit in
+ * decreasing N (N = 1 + (N0-1)/2^level, LineFeat::setupSampling src/feature.cpp:160-173, src/sparse_img_align.cpp:320; ties in
+ * feature order), starting in the round the points leave partly empty; a segment with N <= 64 samples never straddles a multiple
+ * of 64, longer ones follow behind the packed rounds.  seg_code[s] = first slot | N << 20, or -1 for a segment without landmark on
+ * entry or with an end point inside the 3-pixel border of the level (src/sparse_img_align.cpp:299-301).  n_slots: slots in use;
+ * long_lines: some N > 64 (the level then runs in two passes); n_patches: points + samples (holes not counted).  No result depends
+ * on where a segment sits.  Returns PLSVO_E_CAPACITY for N > 2047 or more than 2^20 slots. */
 int plsvo_align_slot_layout(const plsvo_align_in* in, int level, int32_t* seg_code, int32_t* n_slots, int32_t* long_lines,
                             long long* n_patches);
 

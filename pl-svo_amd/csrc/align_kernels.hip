@@ -10,8 +10,9 @@
 // Design (not a translation of the CPU loops):
 //   * PATCH SLOTS.  The features of a level are flattened into patch slots (points: 1 patch, segments: N samples; a
 //     patch is 4x4 pixels).  The slot layout is STATIC: the host computes it once per job and level (points own slots
-//     [0, n_pts), segments follow from the next multiple of 32 and a segment with N <= 32 samples never straddles a
-//     multiple of 32), so the device needs no scan, and all samples of a line sit in ONE wave-round of the kernel;
+//     [0, n_pts), the segments are packed behind them into the wave-rounds of 64 slots -- first-fit in decreasing N, a segment
+//     with N <= 64 samples never straddles a multiple of 64), so the device needs no scan, the rounds of a pass are as few as the
+//     patches allow (a round costs the same whether its lanes hold patches or holes), and all samples of a line sit in ONE wave-round;
 //   * ONE PASS PER ITERATION, ONE LANE PER SLOT.  A lane owns a slot for the whole iteration: it warps and projects the 3-D
 //     point, gathers the 5x5 window of the current image through L2 (five rows of aligned dword pairs + v_alignbyte; LDS holds
 //     only the small slot tables, so several workgroups share a CU), rebuilds the reference patch's interpolated intensity and
@@ -24,7 +25,7 @@
 //     accumulated per pixel;
 //   * per-line re-weighting (H += H_line * w / r, Jres += Jres_line * w, cull if r >= 200 or a sample leaves the image,
 //     src/sparse_img_align.cpp:640-688) needs the line's mean |residual| first: every sample lane sums its line's
-//     sample residuals from LDS in fixed order.  A job with a line of more than 32 samples at some level runs that level
+//     sample residuals from LDS in fixed order.  A job with a line of more than 64 samples at some level runs that level
 //     in two passes (residuals, workgroup barrier, expansion) -- same code, selected by a workgroup-uniform flag;
 //   * REDUCTION: 27 + 3 lane-private doubles -> butterfly reduce-scatter inside each 16-lane DPP row (30 exchanges
 //     instead of 4 x 30), rows and waves combined through LDS in fixed order: deterministic.
@@ -73,22 +74,12 @@ template <bool TILED>
 __device__ __forceinline__ uint2 load_row8_raw(const uint8_t* img, int pitch, int x, int y) {
   uint32_t d0, d1, d2, sh;
   if constexpr (TILED) {
-#ifdef PLSVO_STRIP_MIRROR
-    // column-strip mirror (`pitch` = level width): the eight column dwords of the band holding row y, byte y & 3 of each
-    const uint32_t* const cw = reinterpret_cast<const uint32_t*>(img + strip_offset(pitch, x, y & ~3));
-    const uint32_t bsh = 8u * (uint32_t)(y & 3);
-    uint32_t lo = 0u, hi = 0u;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { lo |= ((cw[k] >> bsh) & 0xffu) << (8 * k); hi |= ((cw[4 + k] >> bsh) & 0xffu) << (8 * k); }
-    return make_uint2(lo, hi);
-#else
     const int a = x & ~3;
     sh = (uint32_t)(x & 3);
     const int row = tiled_row_offset(pitch, y);
     d0 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a)));
     d1 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a + 4)));
     d2 = *reinterpret_cast<const uint32_t*>(img + (row + tiled_col_offset(a + 8)));
-#endif
   } else {
     const int off = y * pitch + x, a = off & ~3;
     sh = (uint32_t)(off & 3);
@@ -448,11 +439,7 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
     const unsigned long long pyr_slot = kTiled ? b.pyr.tslot_bytes : b.pyr.slot_bytes;
     const uint8_t* ref_img = pyr_base + (size_t)job.ref_slot * pyr_slot + lvl_off;
     const uint8_t* cur_img = pyr_base + (size_t)job.cur_slot * pyr_slot + lvl_off;
-#ifdef PLSVO_STRIP_MIRROR
-    const int pitch = W;                            // the strip mirror is addressed by the level width
-#else
     const int pitch = kTiled ? (W + 15) >> 4 : W;   // tiles per row / bytes per row
-#endif
     int n_slots = 0; bool long_lines = false;
 #pragma unroll
     for (int l = 0; l < PLSVO_MAX_LEVELS; ++l) if (l == level) { n_slots = job.n_slots[l]; long_lines = ((job.long_mask >> l) & 1) != 0; }
@@ -904,16 +891,6 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
             const int ui = (int)floorf(g.u), vi = (int)floorf(g.v);
             const int x0 = ui - 2, y0 = vi - 2;
             if constexpr (kTiled) {
-#ifdef PLSVO_STRIP_MIRROR
-              // columns x0 .. x0 + 4 of the two bands holding rows y0 .. y0 + 4: wlo[c] / whi[c] = the column dword of the upper / lower band
-              const int q0 = strip_offset(pitch, x0, y0 & ~3), q1 = q0 + (pitch << 2);
-              const uint4 l4 = *reinterpret_cast<const uint4*>(cur_img + q0);
-              const uint4 h4 = *reinterpret_cast<const uint4*>(cur_img + q1);
-              g.wlo[0] = l4.x; g.wlo[1] = l4.y; g.wlo[2] = l4.z; g.wlo[3] = l4.w; g.wlo[4] = *reinterpret_cast<const uint32_t*>(cur_img + q0 + 16);
-              g.whi[0] = h4.x; g.whi[1] = h4.y; g.whi[2] = h4.z; g.whi[3] = h4.w; g.whi[4] = *reinterpret_cast<const uint32_t*>(cur_img + q1 + 16);
-#pragma unroll
-              for (int r = 0; r < 5; ++r) g.wsh[r] = y0 & 3;
-#else
               const int ca = tiled_col_offset(x0 & ~3), cb = tiled_col_offset((x0 & ~3) + 4);
 #pragma unroll
               for (int r = 0; r < 5; ++r) {
@@ -921,7 +898,6 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
                 g.wsh[r] = x0 & 3;
                 g.wlo[r] = *reinterpret_cast<const uint32_t*>(cur_img + (q + ca)); g.whi[r] = *reinterpret_cast<const uint32_t*>(cur_img + (q + cb));
               }
-#endif
             } else {
 #pragma unroll
               for (int r = 0; r < 5; ++r) {
@@ -1020,38 +996,14 @@ __global__ __launch_bounds__(T, kMinWavesPerSimd) void align_fused_kernel(AlignB
               }
             };
             float ra[5], rb[5];
-#ifdef PLSVO_STRIP_MIRROR
-            // column-strip mirror (one wave per frame): cw[c] = rows y0 .. y0 + 3 of column c, c4[c] = row y0 + 4; row r of the window is
-            // byte r of every cw (a static byte select)
-            uint32_t cw[5], c4[5];
-            if constexpr (kTiled) {
-#pragma unroll
-              for (int c = 0; c < 5; ++c) { cw[c] = __builtin_amdgcn_alignbyte(whi[c], wlo[c], (uint32_t)wsh[0]); c4[c] = (whi[c] >> (8 * wsh[0])) & 0xffu; }
-            }
-            auto window_row = [&](auto RI, float* o) {
-              constexpr int r = decltype(RI)::value;
-              if constexpr (kTiled) {
-#pragma unroll
-                for (int c = 0; c < 5; ++c) o[c] = (r < 4) ? (float)((cw[c] >> (8 * (r & 3))) & 0xffu) : (float)c4[c];
-              } else {
-                unpack5(wlo[r], whi[r], wsh[r], o);
-              }
-            };
-            window_row(std::integral_constant<int, 0>{}, ra);
-#else
             unpack5(wlo[0], whi[0], wsh[0], ra);
-#endif
             RecordRows rec;
             rec.start(sc.q);
             auto patch_row = [&](auto RI) {
               constexpr int r = decltype(RI)::value;
               float* const top = (r & 1) ? rb : ra;
               float* const bot = (r & 1) ? ra : rb;
-#ifdef PLSVO_STRIP_MIRROR
-              window_row(std::integral_constant<int, r + 1>{}, bot);
-#else
               unpack5(wlo[r + 1], whi[r + 1], wsh[r + 1], bot);
-#endif
               float4 chi_t = make_float4(0.f, 0.f, 0.f, 0.f);
               float4 r4, x4, y4;
               rec.template row<r>(r4, x4, y4);

@@ -713,10 +713,9 @@ extern "C" int plsvo_align_stage(plsvo_ctx* c, int n, const plsvo_align_in* in) 
     sp.insert(sp.end(), a.seg_p_ref, a.seg_p_ref + 3 * (size_t)a.n_seg);
     sq.insert(sq.end(), a.seg_q_ref, a.seg_q_ref + 3 * (size_t)a.n_seg);
     for (int s = 0; s < a.n_seg; ++s) alive.push_back(a.seg_alive_in ? (a.seg_alive_in[s] ? 1 : 0) : 1);
-    // static patch-slot layout, per level (align_kernels.hip header): points own slots [0, n_pts); segments follow from the
-    // next multiple of 32 in feature order, and a segment with N <= 32 samples never straddles a multiple of 32, so that all
-    // its samples sit in one wave-round of the kernel.  Segments without a landmark on entry, or whose end points fail the
-    // 3-pixel border test of the level (src/sparse_img_align.cpp:299-301), get no slots.
+    // static patch-slot layout, per level (slot_layout above): points own slots [0, n_pts), the segments are packed behind them into
+    // the kernel's wave-rounds of 64 slots; segments without a landmark on entry, or whose end points fail the 3-pixel border test of
+    // the level (src/sparse_img_align.cpp:299-301), get no slots.
     int ub_max = 0;
     long long ub_sum = 0;
     J.long_mask = 0; J.ldlt_flavour = c->ldlt_flavour;

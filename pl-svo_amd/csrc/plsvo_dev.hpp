@@ -32,25 +32,6 @@ inline unsigned int pyr_level_offset(int width, int height, int level) {
 //     ((y >> 3) * tiles_x + (x >> 4)) * 128 + (y & 7) * 16 + (x & 15),        tiles_x = ceil(w / 16)
 // A 5x5 window of a row-major level touches five lines (one per image row: 640 B fetched for 25 B used); in tiles it touches
 // (1 + 4/16)(1 + 4/8) = 1.9 lines on average.  The launch runs within a few per cent of the achievable HBM rate, so lines are time.
-#ifdef PLSVO_STRIP_MIRROR
-// (experiment) COLUMN-STRIP MIRROR: a level is cut into bands of 4 rows; a band is stored as one row of DWORDS, dword x = the four
-// pixels (x, 4b .. 4b + 3) -- pixel (x, y) at (y >> 2) * 4 w + 4 x + (y & 3).  A 5x5 window is columns x0 .. x0 + 4 of exactly two bands:
-// 2 x 20 contiguous bytes = two dwordx4 + two dword requests per lane where the 16 x 8 tiles need ten dword requests.
-#if defined(__HIPCC__)
-__host__ __device__
-#endif
-inline unsigned int pyr_tiled_level_offset(int width, int height, int level) {
-  unsigned long long off = 0;
-  for (int l = 0; l < level; ++l) {
-    const unsigned long long bands = (unsigned long long)(((height >> l) + 3) >> 2);
-    off += (bands * 4ull * (unsigned long long)(width >> l) + 64 + 255) & ~255ull;     // (+64: a request may run a few dwords past a band's end)
-  }
-  return (unsigned int)off;
-}
-#if defined(__HIPCC__)
-__device__ __forceinline__ int strip_offset(int w, int x, int y) { return (y >> 2) * (w << 2) + (x << 2) + (y & 3); }
-#endif
-#else
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -65,7 +46,6 @@ inline unsigned int pyr_tiled_level_offset(int width, int height, int level) {
 #if defined(__HIPCC__)
 __device__ __forceinline__ int tiled_row_offset(int tiles_x, int y) { return (((y >> 3) * tiles_x) << 7) + ((y & 7) << 4); }
 __device__ __forceinline__ int tiled_col_offset(int x) { return ((x >> 4) << 7) + (x & 15); }
-#endif
 #endif
 
 // alignment launch shapes from this many threads per frame on are LATENCY shapes (a frame owns most of a CU): four lanes per slot in the
@@ -91,7 +71,7 @@ struct AlignJobDev {
   int pt_off, n_pts, seg_off, n_seg;        // into the batch feature arrays
   int patch_off, patch_cap;                 // into the batch patch-cache arrays (slots)
   int n_slots[PLSVO_MAX_LEVELS];            // patch slots of the static layout, per level (host: align_slot_layout)
-  int long_mask;                            // bit l: some segment has more than 32 samples at level l (two-pass level)
+  int long_mask;                            // bit l: some segment has more than 64 samples at level l (two-pass level)
   int ldlt_flavour;                         // 320 / 330: zero-pivot rule of Eigen's LDLT (plsvo_wave.hpp::wave_solve6_core)
 };
 

@@ -70,26 +70,6 @@ __global__ __launch_bounds__(256) void copy_level0_kernel(const uint8_t* src, si
   else for (int k = 0; k < 16 && 16 * q + k < w; ++k) d[k] = s[k];
 }
 
-#ifdef PLSVO_STRIP_MIRROR
-// row-major level -> 4-row bands of column dwords (plsvo_dev.hpp): one thread per dword; rows beyond the image edge are written as 0
-__global__ __launch_bounds__(256) void tile_level_kernel(const uint8_t* src, size_t src_pitch, int w, int h, uint8_t* dst, size_t dst_pitch) {
-  const int bands = (h + 3) >> 2;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= bands * w) return;
-  const int bnd = idx / w, x = idx - bnd * w;
-  const uint8_t* s = src + (size_t)blockIdx.y * src_pitch + (size_t)(4 * bnd) * w + x;
-  uint32_t v = 0u;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) if (4 * bnd + r < h) v |= (uint32_t)s[(size_t)r * w] << (8 * r);
-  *reinterpret_cast<uint32_t*>(dst + (size_t)blockIdx.y * dst_pitch + (size_t)idx * 4) = v;
-}
-hipError_t launch_tile_level(const uint8_t* src, size_t src_pitch, int w, int h, uint8_t* dst, size_t dst_pitch, int n_slots, hipStream_t stream) {
-  const int work = ((h + 3) >> 2) * w;
-  if (work <= 0 || n_slots <= 0) return hipSuccess;
-  hipLaunchKernelGGL(tile_level_kernel, dim3((work + 255) / 256, n_slots), dim3(256), 0, stream, src, src_pitch, w, h, dst, dst_pitch);
-  return hipGetLastError();
-}
-#else
 // row-major level -> 16 x 8 tiles (plsvo_dev.hpp): one thread per 16-byte tile row; pixels beyond the image edge are written as 0
 __global__ __launch_bounds__(256) void tile_level_kernel(const uint8_t* src, size_t src_pitch, int w, int h, uint8_t* dst, size_t dst_pitch) {
   const int tiles_x = (w + 15) >> 4, tiles_y = (h + 7) >> 3;
@@ -118,8 +98,6 @@ hipError_t launch_tile_level(const uint8_t* src, size_t src_pitch, int w, int h,
   hipLaunchKernelGGL(tile_level_kernel, dim3((work + 255) / 256, n_slots), dim3(256), 0, stream, src, src_pitch, w, h, dst, dst_pitch);
   return hipGetLastError();
 }
-
-#endif
 
 hipError_t launch_halfsample(const uint8_t* src, size_t src_pitch, int in_w, int in_h, int in_stride, uint8_t* dst,
                              size_t dst_pitch, int n_slots, int rounding, hipStream_t stream) {
