@@ -269,10 +269,25 @@ __device__ void popt_gn_loop(const PoseBatchDev& b, const PoseJobDev& job, PoseS
     double acc[32];   // 0..20 A (upper, row-major), 21..26 b, 27 chi2, 28 #points, 29 #segments, 30..31 unused
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    if constexpr (PO_T == 64) {
+      // (wave per frame, three waves per SIMD: the pose is re-read from LDS for every feature round -- twelve broadcast reads against ~250
+      //  f64 instructions -- instead of living in 24 registers across the loop; the laundered offset keeps the compiler from hoisting them)
+      for (int f = tid; f < nf; f += PO_T) {
+        int off = 0;
+#ifndef PLSVO_WAVE_EMU
+        asm volatile("" : "+v"(off));
+#endif
+        double P[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) P[k] = s_pose[off + k];
+        popt_accumulate_feature(b, job, f, P, scale_pt, scale_ls, iter == 0, init_vec, obs, acc);
+      }
+    } else {
     double P[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) P[k] = s_pose[k];
     for (int f = tid; f < nf; f += PO_T) popt_accumulate_feature(b, job, f, P, scale_pt, scale_ls, iter == 0, init_vec, obs, acc);
+    }
     {
       double out2[2];
       row_reduce_scatter32(acc, out2);
@@ -375,7 +390,18 @@ __global__ __launch_bounds__(PO_T) PLSVO_PO_OCC(PO_T) void pose_opt_kernel(PoseB
   }
 
   // ---- scale pass :57-95 ----
-  {
+  if constexpr (PO_T == 64) {   // (the pose from LDS per feature round: see popt_gn_loop)
+    for (int f = tid; f < nf; f += PO_T) {
+      int off = 0;
+#ifndef PLSVO_WAVE_EMU
+      asm volatile("" : "+v"(off));
+#endif
+      double P[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) P[k] = s_pose[off + k];
+      errs[f] = popt_scale_error(b, job, f, P, vec + 3 * nf);
+    }
+  } else {
     double P[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) P[k] = s_pose[k];
@@ -416,6 +442,14 @@ __global__ __launch_bounds__(PO_T) PLSVO_PO_OCC(PO_T) void pose_opt_kernel(PoseB
 #pragma unroll
     for (int k = 0; k < 12; ++k) P[k] = s_pose[k];
     for (int f = tid; f < nf; f += PO_T) {
+      if constexpr (PO_T == 64) {   // (the pose from LDS per feature round: see popt_gn_loop)
+        int off = 0;
+#ifndef PLSVO_WAVE_EMU
+        asm volatile("" : "+v"(off));
+#endif
+#pragma unroll
+        for (int k = 0; k < 12; ++k) P[k] = s_pose[off + k];
+      }
       int deleted;
       vec[2 * nf + f] = popt_cull_feature(b, job, f, P, thr_pt, thr_ls, vec + 3 * nf, deleted);
       del_pt += deleted == 1; del_ls += deleted == 2;
