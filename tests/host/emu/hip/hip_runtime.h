@@ -155,6 +155,11 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (voi
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new WaveEmuEvent(); return hipSuccess; }
+#define hipEventDisableTiming 2u
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new WaveEmuEvent(); return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = -1; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (void*)1; return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }   // (streams execute at once: nothing to wait for)
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
