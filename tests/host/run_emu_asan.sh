@@ -1,7 +1,7 @@
 #!/bin/bash
 # The GPU parity tests against an AddressSanitizer build of the host emulation (tests/host/build_emu.sh): every load and store of the
 # kernels and of the C ABI checked against the bounds of the hipMalloc'ed buffers.  ~6 minutes on 8 cores; not part of the pytest suite.
-# Round 3: 92 passed (all three seed sweeps at full length included), no AddressSanitizer report.  Round 4: 100 passed, round 5: 117 passed, no report.
+# Round 3: 92 passed (all three seed sweeps at full length included), no AddressSanitizer report.  Round 4: 100 passed, round 5: 117 passed, round 6: 118 passed (60-seed sweeps), no report.
 # usage: tests/host/run_emu_asan.sh [pytest -k expression]
 R=$(cd $(dirname $0)/../.. && pwd)
 CXX=${EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}

@@ -1091,6 +1091,22 @@ def test_launch_order_follows_the_measured_work_of_the_last_run(P, ob, threads):
             assert iters[order[0]] >= iters[order[-1]]                # longest first (bins of 128 patch-iterations: not a strict sort)
             for k in range(B):
                 assert np.array_equal(res[k].T, single[k].T) and res[k].n_meas == single[k].n_meas and res[k].iters_per_level == single[k].iters_per_level, (rep, k)
+        # PLSVO_OPT_ALIGN_REORDER = 0 (round 6): back to the stage call's order at once, every later launch keeps it, results unchanged;
+        # = 1: the next launch sorts again (what bench.py switches between: its timed steps run in the staged order)
+        ctx.set_launch_order_refresh(align=False)
+        assert np.array_equal(ctx.align_launch_order(B), order0)
+        for rep in range(2):
+            ctx.align_run()
+            res = ctx.align_fetch()
+            assert np.array_equal(ctx.align_launch_order(B), order0)
+            for k in range(B):
+                assert np.array_equal(res[k].T, single[k].T) and res[k].iters_per_level == single[k].iters_per_level, (rep, k)
+        ctx.set_launch_order_refresh(align=True)
+        ctx.align_run()
+        ctx.align_run()
+        order = ctx.align_launch_order(B)
+        iters = np.array([sum(r.iters_per_level) for r in ctx.align_fetch()])
+        assert sorted(order.tolist()) == list(range(B)) and iters[order[0]] >= iters[order[-1]]
         ctx.align_stage(jobs)                                        # staging again resets the order to the host's
         assert np.array_equal(ctx.align_launch_order(B), order0)
     finally:
